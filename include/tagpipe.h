@@ -1,0 +1,239 @@
+/*
+ * tagpipe.h — C ABI of the MI355X batch tag pipeline (libtagpipe_hip.so).
+ *
+ * The reference (Mumicanso8323/ImageCaptioner, Program.cs) has no FFI seam:
+ * every function on the path is `private static` in one class.  This header
+ * defines the seam a maintainer would P/Invoke: it wraps exactly the pure
+ * span of the per-image loop body — Program.cs:223-229 and 292-329 with the
+ * OpenAI branch off, fed by ParseTagCandidatesFromLine (Program.cs:574-605) —
+ * and is called once per BATCH of files instead of once per image.
+ *
+ * Plain C types only; no callbacks; no exceptions cross the boundary.
+ * Every function returns 0 on success or a negative TP_E_* code; the message
+ * for the calling thread's last error is available from tp_last_error().
+ * One context may be used by one thread at a time.
+ */
+#ifndef TAGPIPE_H_
+#define TAGPIPE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TP_OK              0
+#define TP_E_INVALID_ARG  -1
+#define TP_E_CONFIG       -2  /* malformed JSON / unsupported table content (reference: "Fatal error occurred.", Program.cs:371-375) */
+#define TP_E_DEVICE       -3  /* HIP runtime failure, no device, kernel fault */
+#define TP_E_CAPACITY     -4  /* caller-provided output buffer too small; required sizes are reported */
+#define TP_E_NOMEM        -5
+
+/* tp_verdict.coverage bits: 1 = category present (Program.cs:1058-1064, 1087-1092). */
+#define TP_COV_IDENTITY    0x01u
+#define TP_COV_HAIR        0x02u
+#define TP_COV_EYES        0x04u
+#define TP_COV_OUTFIT      0x08u
+#define TP_COV_POSE_ACTION 0x10u
+#define TP_COV_BACKGROUND  0x20u
+
+/* tp_verdict.flags bits. */
+#define TP_F_LOW           0x01u  /* MissingCoreBuckets(finalTags), Program.cs:319, 1097-1101 */
+#define TP_F_ELIGIBLE      0x02u  /* evidence has feet and penis, Program.cs:309 */
+#define TP_F_FOOTJOB       0x04u  /* ... and the final tags have footjob, Program.cs:311 */
+#define TP_F_FALLBACK      0x08u  /* fewer than 3 selected tags: minimal fallback line used, Program.cs:297-298 */
+#define TP_F_LINE_REJECTED 0x10u  /* NormalizeRawTagLine returned "" (blank or LooksBad), Program.cs:590, 596 */
+#define TP_F_UNSUPPORTED   0x20u  /* input holds bytes this build does not process; caption is empty */
+#define TP_F_SAFE_REJECT   0x40u  /* DetectSafeModeRejectReason hit, Program.cs:329, 942-945 */
+
+/* Candidate sources and their SourceRank (Program.cs:398, 712-717). */
+#define TP_SRC_PRIMARY_JOY   0
+#define TP_SRC_SECONDARY_JOY 1
+#define TP_SRC_OPENAI        2
+
+/*
+ * Per-file verdict record, 16 bytes.  The reference keeps these facts in
+ * locals of the loop body (coverage: Program.cs:227; isLow: :319; counters:
+ * :309-312; rejectReason: :329) and in the lists it hands to AppendAudit
+ * (:334); this record is their fixed-size part.
+ */
+typedef struct tp_verdict {
+    uint8_t  coverage;      /* TP_COV_* of EvaluateCoverage(finalSelection.Tags) */
+    uint8_t  flags;         /* TP_F_* */
+    uint16_t n_tags;        /* tags in the emitted caption line */
+    uint16_t n_candidates;  /* finalCandidates.Count */
+    uint16_t n_selected;    /* finalSelection.Tags.Count (before the fallback) */
+    int16_t  safe_hit;      /* index into the SafeModeRejectTags list (Program.cs:43-45 order) of the hit, else -1 */
+    uint16_t n_evidence;    /* evidenceTags.Count after ExpandImpliedTags */
+    uint16_t n_unknown;     /* GetUnknownTags(finalTags).Count, Program.cs:314 */
+    uint16_t n_dropped;     /* finalSelection.DroppedTagsWithReason.Count */
+} tp_verdict;
+
+/* Batch-wide counters (the Interlocked counters of Program.cs:194-195 plus build-side status counts). */
+typedef struct tp_counters {
+    uint64_t files;
+    uint64_t low;
+    uint64_t action_eligible;
+    uint64_t action_footjob;
+    uint64_t fallback;
+    uint64_t line_rejected;
+    uint64_t unsupported;
+    uint64_t safe_rejected;
+} tp_counters;
+
+/*
+ * Configuration, mirroring what Main loads before the loop (Program.cs:156-165).
+ * Each table source is given either as in-memory bytes (data/len, wins when
+ * data != NULL) or as a path (NULL or a missing file = table absent, as the
+ * reference's File.Exists checks).  Formats are the reference's own.
+ */
+typedef struct tp_source {
+    const char*    path;
+    const uint8_t* data;
+    uint64_t       len;
+} tp_source;
+
+typedef struct tp_config {
+    uint32_t  struct_size;            /* sizeof(tp_config), for ABI growth */
+    tp_source lexicon;                /* rules/lexicon.json,         LoadLexicon        Program.cs:1275-1305 */
+    tp_source actions;                /* rules/actions.json,         LoadActions        Program.cs:1307-1338 */
+    tp_source required_facets;        /* rules/required_facets.json, LoadRequiredFacets Program.cs:1374-1406 */
+    tp_source profile;                /* profiles/<name>.json,       LoadProfile        Program.cs:918-931  */
+    tp_source vocabulary;             /* top_tags.txt or .json,      LoadKnownTagDictionary Program.cs:983-1053 */
+    int32_t   vocabulary_is_json;     /* 1 = parse as JSON (the reference decides by the ".json" extension, Program.cs:1016-1017);
+                                         0 = text; -1 = decide from vocabulary.path's extension */
+    tp_source allowlist;              /* allowlist.txt, LoadTagFile Program.cs:1429-1439 */
+    tp_source denylist;               /* denylist.txt */
+    const char* trigger;              /* --trigger, default "sgrui" (Program.cs:1540) */
+    const char* auto_prefix_tags;     /* --auto-prefix-tags   (Program.cs:158, 165) */
+    const char* minimal_subject_tags; /* --minimal-subject-tags (Program.cs:165) */
+    const char* newline;              /* Environment.NewLine written after each caption (Program.cs:317): "\n" or "\r\n"; NULL = "\n" */
+    int32_t   no_profile;             /* --no-profile */
+    int32_t   strict_known;           /* --strict-known-tags value when explicit */
+    int32_t   strict_known_explicit;  /* either strict flag was given (Program.cs:999-1002, 1538) */
+    int32_t   safe_mode;              /* default on (Program.cs:1543) */
+    double    line_weight;            /* sourceWeight for line ingest; the self-check uses 1.0 (Program.cs:1958) */
+    int32_t   line_source;            /* TP_SRC_*; default parameter is OpenAI (Program.cs:574) */
+    int32_t   device;                 /* HIP device ordinal */
+} tp_config;
+
+/* Fill *cfg with the reference's defaults (safe mode on, trigger "sgrui", weight 1.0, source OpenAI, "\n"). */
+void tp_config_init(tp_config* cfg);
+
+typedef struct tp_ctx tp_ctx;
+
+/*
+ * Load and compile the tables in the reference's order (Program.cs:158-165:
+ * allow/deny lists, vocabulary, profile, force-allow set, then the rule
+ * engine JSONs) and upload them to the device.  Returns NULL on failure.
+ */
+tp_ctx* tp_create(const tp_config* cfg);
+void    tp_destroy(tp_ctx* ctx);
+const char* tp_last_error(void);
+
+/* Facts about the compiled tables (sizes of the optional detail arrays below). */
+typedef struct tp_table_info {
+    uint32_t n_strings;        /* interned strings (histogram length) */
+    uint32_t n_action_rules;   /* ActiveActionRules.Length */
+    uint32_t n_action_subtypes;/* total subtypes over all rules */
+    uint32_t n_facets;         /* ActiveRequiredFacets.Length */
+    uint32_t fired_words;      /* u32 words per file in the fired-rule bitmap: ceil((rules + subtypes) / 32) */
+    uint32_t n_known_tags;     /* KnownTags.Count */
+    uint32_t strict_known;     /* ActiveStrictKnownTags after load */
+    uint32_t known_found;      /* KnownTagDictionaryFound */
+} tp_table_info;
+int tp_get_table_info(const tp_ctx* ctx, tp_table_info* out);
+
+/* The interned string with the given id (histogram index -> tag).  Pointer valid until tp_destroy. */
+int tp_get_string(const tp_ctx* ctx, uint32_t id, const char** utf8, uint32_t* len);
+
+/*
+ * Result of one batch, owned by the library until tp_release.
+ * captions[caption_offsets[i] .. caption_offsets[i+1]) is file i's caption line
+ * including the configured newline: the bytes File.WriteAllTextAsync writes at
+ * Program.cs:317.
+ */
+typedef struct tp_result {
+    uint64_t        n_files;
+    const uint8_t*  captions;
+    const uint64_t* caption_offsets;   /* n_files + 1 */
+    const tp_verdict* verdicts;        /* n_files */
+    tp_counters     counters;
+    const uint64_t* histogram;         /* n_strings counts: files whose caption holds the interned tag (build-defined, no reference counterpart) */
+    uint64_t        histogram_other;   /* caption tags that are not interned strings */
+    /* Detail arrays for the audit consumers (Program.cs:334): */
+    const uint32_t* fired;             /* n_files * fired_words: bit r = action rule r fired; bit n_action_rules + s = subtype s (global index) fired (Program.cs:741, 748) */
+    const uint16_t* facet_choice;      /* n_files * n_facets: rule index chosen, 0xFFFF = default tag (Program.cs:760-773) */
+    void*           opaque;
+} tp_result;
+
+/*
+ * Line ingest (ParseTagCandidatesFromLine, Program.cs:574-587): file i's raw
+ * text is arena[offsets[i] .. offsets[i+1]).  Host pointers; the call uploads,
+ * runs the kernels and downloads the result.
+ */
+int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uint64_t n_files, tp_result* out);
+
+/*
+ * Scored ingest (candidates shaped like ParseJoyTags output, Program.cs:463-489):
+ * file i owns tags tag_begin[i] .. tag_begin[i+1]; tag t's raw text is
+ * arena[tag_offsets[t] .. tag_offsets[t+1]), with score scores[t] and source
+ * sources[t] (TP_SRC_*).  Each tag is normalised once, blank ones are skipped,
+ * order is the running index, and the list is sorted by score descending then
+ * order (Program.cs:483-487) before SelectTags.
+ */
+int tp_run_scored(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin,
+                  const double* scores, const uint8_t* sources, uint64_t n_files, tp_result* out);
+
+void tp_release(tp_ctx* ctx, tp_result* res);
+
+/*
+ * Device-resident variant of tp_run_lines for callers that already hold the
+ * corpus in HBM (and for benchmarking the kernels without PCIe): every pointer
+ * is a device pointer on the context's device; the caller provides the output
+ * buffers.  histogram (n_strings u64) and counters are ACCUMULATED into, so a
+ * caller can shard one corpus over several calls (or all-reduce them across
+ * GPUs).  fired / facet_choice may be NULL.  Work is enqueued on `stream`
+ * (a hipStream_t, NULL = default stream); the call synchronises the stream
+ * once to learn the caption size.  If caption_capacity is too small the call
+ * returns TP_E_CAPACITY and *caption_bytes holds the required size.
+ */
+typedef struct tp_device_io {
+    const uint8_t*  arena;            /* in  */
+    const uint64_t* offsets;          /* in, n_files + 1 */
+    uint64_t        n_files;
+    uint8_t*        captions;         /* out */
+    uint64_t        caption_capacity;
+    uint64_t*       caption_offsets;  /* out, n_files + 1 */
+    tp_verdict*     verdicts;         /* out, n_files */
+    uint64_t*       histogram;        /* in/out, n_strings + 1 (last = other), may be NULL */
+    tp_counters*    counters;         /* in/out, may be NULL */
+    uint32_t*       fired;            /* out, may be NULL */
+    uint16_t*       facet_choice;     /* out, may be NULL */
+    void*           stream;
+} tp_device_io;
+int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes);
+
+/*
+ * Corpus-wide tag table in the format the reference reads as top_tags.txt
+ * (one tag per line, Program.cs:1021-1028), ordered by count descending then
+ * by the tag's bytes ascending; tags with count 0 are omitted.  Build-defined:
+ * the reference never writes this file.  `histogram` is host memory of
+ * n_strings counts.  Writes at most `capacity` bytes to `out`; *needed is the
+ * full size.
+ */
+int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* out, uint64_t capacity, uint64_t* needed);
+
+/* Timing of the most recent run on this context (milliseconds, from HIP events on the run's stream). */
+typedef struct tp_timing {
+    float total_ms;     /* first kernel start to last kernel end */
+    float select_ms;    /* the per-file pipeline kernel (dominant) */
+    float emit_ms;      /* caption byte emission */
+    float other_ms;     /* scans, counters, histogram */
+} tp_timing;
+int tp_get_last_timing(const tp_ctx* ctx, tp_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAGPIPE_H_ */
