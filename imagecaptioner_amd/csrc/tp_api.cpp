@@ -1,0 +1,495 @@
+// C ABI of the batch tag pipeline (include/tagpipe.h): context life cycle, table upload, batch runs.
+// Every run goes through the HIP kernels; there is no host implementation of the pipeline in this library.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tagpipe.h"
+#include "tp_launch.h"
+#include "tp_pipeline.h"
+#include "tp_tables.hpp"
+
+using namespace tp;
+
+namespace {
+
+thread_local std::string g_error;
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+struct HipFail { hipError_t e; const char* what; };
+#define HIP_OK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) throw HipFail{e__, #expr}; } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void need(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
+        if (bytes <= cap) return;
+        size_t want = std::max(bytes, cap + cap / 2);
+        want = (want + 255) & ~(size_t)255;
+        void* q = nullptr;
+        HIP_OK(hipMalloc(&q, want));
+        if (keep && p && cap) {
+            HIP_OK(hipMemcpyAsync(q, p, cap, hipMemcpyDeviceToDevice, s));
+            HIP_OK(hipStreamSynchronize(s));
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+template <class T>
+const T* upload(std::vector<void*>& owned, const std::vector<T>& v) {
+    void* d = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_OK(hipMalloc(&d, bytes));
+    owned.push_back(d);
+    if (!v.empty()) HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return (const T*)d;
+}
+
+struct HostResult {
+    std::vector<uint8_t> captions;
+    std::vector<uint64_t> caption_offsets, histogram;
+    std::vector<tp_verdict> verdicts;
+    std::vector<uint32_t> fired;
+    std::vector<uint16_t> facet_choice;
+};
+
+}  // namespace
+
+struct tp_ctx {
+    int device = 0;
+    HostTables ht;
+    DevTables dt;
+    std::vector<void*> table_mem;
+    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, scalars, workspace;
+    DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources;           // host-pointer entry points stage their inputs here
+    DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
+    std::vector<hipEvent_t> events;
+    tp_timing timing{};
+    size_t ws_budget = (size_t)8 << 30;
+
+    ~tp_ctx() {
+        (void)hipSetDevice(device);
+        for (void* p : table_mem) (void)hipFree(p);
+        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
+                          &in_scores, &in_sources, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets})
+            b->release();
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+    hipEvent_t event(size_t i) {
+        while (events.size() <= i) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); events.push_back(e); }
+        return events[i];
+    }
+};
+
+namespace {
+
+struct RunIo {
+    const uint8_t* arena; const uint64_t* offsets; const uint64_t* tag_begin; const double* scores; const uint8_t* sources;
+    uint64_t n_files;
+    uint8_t* captions; uint64_t caption_capacity; bool grow_captions;   // grow_captions: captions live in ctx->out_captions and may be reallocated
+    uint64_t* caption_offsets; tp_verdict* verdicts; uint64_t* histogram; tp_counters* counters; uint32_t* fired; uint16_t* facet_choice;
+    hipStream_t stream; int mode;
+};
+
+// The device-side run: sizes -> workspace offsets -> per chunk {pipeline, caption offsets, emit}.
+int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes) {
+    HIP_OK(hipSetDevice(c->device));
+    hipStream_t s = io.stream;
+    const uint64_t n = io.n_files;
+    const uint64_t n_waves = (n + 63) / 64;
+    c->timing = tp_timing{};
+    c->scalars.need(64);
+    uint64_t* d_total = c->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
+    uint32_t* d_status = (uint32_t*)(d_total + 2);
+    HIP_OK(hipMemsetAsync(c->scalars.p, 0, 64, s));
+    if (n == 0) {
+        HIP_OK(hipMemsetAsync(io.caption_offsets, 0, 8, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (caption_bytes) *caption_bytes = 0;
+        return TP_OK;
+    }
+    c->wave_T.need(n_waves * 4); c->wave_LB.need(n_waves * 4); c->wave_bytes.need(n_waves * 8); c->wave_off.need((n_waves + 1) * 8);
+    c->tile_sums.need(scan_tiles_needed(std::max(n, n_waves)) * 8);
+    c->cap_len.need(n * 4); c->n_final.need(n * 4);
+
+    size_t ev = 0;
+    hipEvent_t e_begin = c->event(ev++), e_end = c->event(ev++);
+    HIP_OK(hipEventRecord(e_begin, s));
+    HIP_OK(launch_wave_sizes(c->dt, io.arena, io.offsets, io.tag_begin, n, c->wave_T.as<uint32_t>(), c->wave_LB.as<uint32_t>(), c->wave_bytes.as<uint64_t>(), d_status, s));
+    HIP_OK(launch_scan_u64(c->wave_bytes.as<uint64_t>(), n_waves, c->wave_off.as<uint64_t>(), c->tile_sums.as<uint64_t>(), nullptr, nullptr, s));
+    std::vector<uint64_t> wave_off(n_waves + 1);
+    uint32_t status = 0;
+    HIP_OK(hipMemcpyAsync(wave_off.data(), c->wave_off.p, (n_waves + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (status) return fail(TP_E_INVALID_ARG, "a file is longer than 2 GiB");
+
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pipe_ev, emit_ev;
+    uint64_t total = 0;
+    bool over_capacity = false;
+    int chunk = 0;
+    for (uint64_t w0 = 0; w0 < n_waves;) {
+        uint64_t w1 = w0 + 1;
+        while (w1 < n_waves && wave_off[w1 + 1] - wave_off[w0] <= c->ws_budget) ++w1;
+        c->workspace.need(wave_off[w1] - wave_off[w0]);
+        uint64_t f0 = w0 * 64, f1 = std::min(n, w1 * 64);
+        PipelineArgs pa{};
+        pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
+        pa.file0 = f0; pa.file_end = f1;
+        pa.wave_T = c->wave_T.as<uint32_t>(); pa.wave_LB = c->wave_LB.as<uint32_t>(); pa.wave_off = c->wave_off.as<uint64_t>();
+        pa.workspace = c->workspace.as<uint8_t>();
+        pa.verdicts = io.verdicts; pa.n_final = c->n_final.as<uint32_t>(); pa.cap_len = c->cap_len.as<uint32_t>();
+        pa.fired = io.fired; pa.facet_choice = io.facet_choice; pa.mode = io.mode;
+        hipEvent_t p0 = c->event(ev++), p1 = c->event(ev++);
+        HIP_OK(hipEventRecord(p0, s));
+        HIP_OK(launch_pipeline(c->dt, pa, s));
+        HIP_OK(hipEventRecord(p1, s));
+        pipe_ev.emplace_back(p0, p1);
+        // caption offsets of the chunk, continuing the running total
+        HIP_OK(launch_scan_u32(c->cap_len.as<uint32_t>() + f0, f1 - f0, io.caption_offsets + f0, c->tile_sums.as<uint64_t>(), d_total + (chunk & 1),
+                               d_total + ((chunk + 1) & 1), s));
+        HIP_OK(hipMemcpyAsync(&total, d_total + ((chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (io.mode == 0) {
+            if (io.grow_captions) {
+                c->out_captions.need(std::max<uint64_t>(total, 16), true, s);
+                io.captions = c->out_captions.as<uint8_t>();
+                io.caption_capacity = c->out_captions.cap;
+            }
+            if (total > io.caption_capacity) over_capacity = true;
+            if (!over_capacity) {
+                EmitArgs ea{};
+                ea.file0 = f0; ea.file_end = f1;
+                ea.wave_T = pa.wave_T; ea.wave_LB = pa.wave_LB; ea.wave_off = pa.wave_off; ea.workspace = pa.workspace;
+                ea.n_final = pa.n_final; ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
+                ea.histogram = io.histogram; ea.counters = io.counters;
+                hipEvent_t q0 = c->event(ev++), q1 = c->event(ev++);
+                HIP_OK(hipEventRecord(q0, s));
+                HIP_OK(launch_emit(c->dt, ea, s));
+                HIP_OK(hipEventRecord(q1, s));
+                emit_ev.emplace_back(q0, q1);
+            }
+        }
+        w0 = w1;
+        ++chunk;
+    }
+    HIP_OK(hipEventRecord(e_end, s));
+    HIP_OK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e_begin, e_end));
+    c->timing.total_ms = ms;
+    for (auto& p : pipe_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.select_ms += ms; }
+    for (auto& p : emit_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.emit_ms += ms; }
+    c->timing.other_ms = c->timing.total_ms - c->timing.select_ms - c->timing.emit_ms;
+    if (caption_bytes) *caption_bytes = total;
+    if (over_capacity) return fail(TP_E_CAPACITY, "caption buffer too small: " + std::to_string(total) + " bytes needed");
+    return TP_OK;
+}
+
+template <class F>
+int guarded(F&& body) {
+    try {
+        return body();
+    } catch (const HipFail& h) {
+        return fail(TP_E_DEVICE, std::string("HIP error: ") + hipGetErrorString(h.e) + " in " + h.what);
+    } catch (const ConfigError& e) {
+        return fail(TP_E_CONFIG, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(TP_E_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(TP_E_INVALID_ARG, e.what());
+    }
+}
+
+// Host-pointer run shared by tp_run_lines and tp_run_scored.
+int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64_t* offsets, uint64_t n_offsets, const uint64_t* tag_begin,
+             const double* scores, const uint8_t* sources, uint64_t n_tags, uint64_t n_files, tp_result* out) {
+    HIP_OK(hipSetDevice(c->device));
+    hipStream_t s = nullptr;
+    const DevTables& t = c->dt;
+    c->in_arena.need(arena_bytes + 64);
+    c->in_offsets.need(n_offsets * 8);
+    if (arena_bytes) HIP_OK(hipMemcpyAsync(c->in_arena.p, arena, arena_bytes, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(c->in_offsets.p, offsets, n_offsets * 8, hipMemcpyHostToDevice, s));
+    if (tag_begin) {
+        c->in_tag_begin.need((n_files + 1) * 8); c->in_scores.need(std::max<uint64_t>(n_tags, 1) * 8); c->in_sources.need(std::max<uint64_t>(n_tags, 1));
+        HIP_OK(hipMemcpyAsync(c->in_tag_begin.p, tag_begin, (n_files + 1) * 8, hipMemcpyHostToDevice, s));
+        if (n_tags) {
+            HIP_OK(hipMemcpyAsync(c->in_scores.p, scores, n_tags * 8, hipMemcpyHostToDevice, s));
+            HIP_OK(hipMemcpyAsync(c->in_sources.p, sources, n_tags, hipMemcpyHostToDevice, s));
+        }
+    }
+    const size_t hist_n = (size_t)t.n_strings + 1;
+    c->out_offsets.need((n_files + 1) * 8);
+    c->out_verdicts.need(std::max<uint64_t>(n_files, 1) * sizeof(tp_verdict));
+    c->out_hist.need(hist_n * 8);
+    c->out_counters.need(sizeof(tp_counters));
+    c->out_fired.need(std::max<uint64_t>(n_files * t.fired_words, 1) * 4);
+    c->out_facets.need(std::max<uint64_t>(n_files * t.n_facets, 1) * 2);
+    c->out_captions.need(std::max<uint64_t>(arena_bytes + n_files * 96, 4096));
+    HIP_OK(hipMemsetAsync(c->out_hist.p, 0, hist_n * 8, s));
+    HIP_OK(hipMemsetAsync(c->out_counters.p, 0, sizeof(tp_counters), s));
+
+    RunIo io{};
+    io.arena = c->in_arena.as<uint8_t>(); io.offsets = c->in_offsets.as<uint64_t>();
+    io.tag_begin = tag_begin ? c->in_tag_begin.as<uint64_t>() : nullptr;
+    io.scores = tag_begin ? c->in_scores.as<double>() : nullptr;
+    io.sources = tag_begin ? c->in_sources.as<uint8_t>() : nullptr;
+    io.n_files = n_files;
+    io.captions = c->out_captions.as<uint8_t>(); io.caption_capacity = c->out_captions.cap; io.grow_captions = true;
+    io.caption_offsets = c->out_offsets.as<uint64_t>(); io.verdicts = c->out_verdicts.as<tp_verdict>();
+    io.histogram = c->out_hist.as<uint64_t>(); io.counters = c->out_counters.as<tp_counters>();
+    io.fired = c->out_fired.as<uint32_t>(); io.facet_choice = c->out_facets.as<uint16_t>();
+    io.stream = s; io.mode = 0;
+    uint64_t cap_bytes = 0;
+    int rc = run_device(c, io, &cap_bytes);
+    if (rc != TP_OK) return rc;
+
+    std::unique_ptr<HostResult> r(new HostResult());
+    r->captions.resize(std::max<uint64_t>(cap_bytes, 1));
+    r->caption_offsets.resize(n_files + 1);
+    r->verdicts.resize(std::max<uint64_t>(n_files, 1));
+    r->histogram.resize(hist_n);
+    r->fired.resize(std::max<uint64_t>(n_files * t.fired_words, 1));
+    r->facet_choice.resize(std::max<uint64_t>(n_files * t.n_facets, 1));
+    tp_counters ctr{};
+    if (cap_bytes) HIP_OK(hipMemcpy(r->captions.data(), c->out_captions.p, cap_bytes, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(r->caption_offsets.data(), c->out_offsets.p, (n_files + 1) * 8, hipMemcpyDeviceToHost));
+    if (n_files) HIP_OK(hipMemcpy(r->verdicts.data(), c->out_verdicts.p, n_files * sizeof(tp_verdict), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(r->histogram.data(), c->out_hist.p, hist_n * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&ctr, c->out_counters.p, sizeof ctr, hipMemcpyDeviceToHost));
+    if (n_files * t.fired_words) HIP_OK(hipMemcpy(r->fired.data(), c->out_fired.p, n_files * t.fired_words * 4, hipMemcpyDeviceToHost));
+    if (n_files * t.n_facets) HIP_OK(hipMemcpy(r->facet_choice.data(), c->out_facets.p, n_files * t.n_facets * 2, hipMemcpyDeviceToHost));
+    out->n_files = n_files;
+    out->captions = r->captions.data();
+    out->caption_offsets = r->caption_offsets.data();
+    out->verdicts = r->verdicts.data();
+    out->counters = ctr;
+    out->histogram = r->histogram.data();
+    out->histogram_other = r->histogram[t.n_strings];
+    out->fired = r->fired.data();
+    out->facet_choice = r->facet_choice.data();
+    out->opaque = r.release();
+    return TP_OK;
+}
+
+// SelectTags of the minimal fallback line (Program.cs:298), evaluated once with the pipeline kernel itself.
+void compute_fallback(tp_ctx* c) {
+    const std::vector<uint8_t>& line = c->ht.fallback_line;
+    hipStream_t s = nullptr;
+    c->in_arena.need(line.size() + 64);
+    c->in_offsets.need(16);
+    uint64_t offs[2] = {0, line.size()};
+    if (!line.empty()) HIP_OK(hipMemcpy(c->in_arena.p, line.data(), line.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(c->in_offsets.p, offs, 16, hipMemcpyHostToDevice));
+    c->out_offsets.need(16); c->out_verdicts.need(sizeof(tp_verdict));
+    RunIo io{};
+    io.arena = c->in_arena.as<uint8_t>(); io.offsets = c->in_offsets.as<uint64_t>(); io.n_files = 1;
+    io.caption_offsets = c->out_offsets.as<uint64_t>(); io.verdicts = c->out_verdicts.as<tp_verdict>();
+    io.stream = s; io.mode = 1;
+    // The fallback line always takes the line-ingest defaults of Program.cs:298: weight 1.0, source OpenAI.
+    DevTables saved = c->dt;
+    c->dt.line_weight = 1.0;
+    c->dt.line_source = TP_SRC_OPENAI;
+    int rc = run_device(c, io, nullptr);
+    c->dt = saved;
+    if (rc != TP_OK) throw ConfigError("could not evaluate the minimal fallback line: " + g_error);
+    uint32_t nfin = 0;
+    HIP_OK(hipMemcpy(&nfin, c->n_final.p, 4, hipMemcpyDeviceToHost));
+    tp_verdict v{};
+    HIP_OK(hipMemcpy(&v, c->out_verdicts.p, sizeof v, hipMemcpyDeviceToHost));
+    if (v.flags & TP_F_UNSUPPORTED) throw ConfigError("the minimal fallback line holds text this build does not process");
+    if (nfin > (uint32_t)MAX_FALLBACK) throw ConfigError("internal: fallback selection too long");
+    // the final list of file 0 sits in lane 0 of the first wavefront's workspace
+    uint32_t T = 0, LB = 0;
+    HIP_OK(hipMemcpy(&T, c->wave_T.p, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&LB, c->wave_LB.p, 4, hipMemcpyDeviceToHost));
+    WsLayout lay = ws_layout(T, LB, c->dt.final_cap, c->dt.evidence_grow, c->dt.lit_words);
+    c->dt.n_fallback = nfin;
+    for (uint32_t k = 0; k < nfin; ++k) {
+        uint64_t h = 0;
+        HIP_OK(hipMemcpy(&h, c->workspace.as<uint8_t>() + lay.o_fin + (size_t)k * 64 * 8, 8, hipMemcpyDeviceToHost));
+        if (h >> 32) throw ConfigError("internal: fallback tag outside the tables");
+        c->dt.fallback_ids[k] = (uint32_t)h;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tp_last_error(void) { return g_error.c_str(); }
+
+void tp_config_init(tp_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->vocabulary_is_json = -1;
+    cfg->trigger = "sgrui";
+    cfg->auto_prefix_tags = "";
+    cfg->minimal_subject_tags = "";
+    cfg->newline = "\n";
+    cfg->safe_mode = 1;
+    cfg->line_weight = 1.0;
+    cfg->line_source = TP_SRC_OPENAI;
+}
+
+tp_ctx* tp_create(const tp_config* cfg) {
+    if (!cfg || cfg->struct_size != sizeof(tp_config)) { fail(TP_E_INVALID_ARG, "tp_config is null or has the wrong struct_size"); return nullptr; }
+    std::unique_ptr<tp_ctx> c(new tp_ctx());
+    int rc = guarded([&]() {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0) return fail(TP_E_DEVICE, "no HIP device is available: this library only runs on a GPU");
+        if (cfg->device < 0 || cfg->device >= count) return fail(TP_E_INVALID_ARG, "device ordinal out of range");
+        c->device = cfg->device;
+        HIP_OK(hipSetDevice(c->device));
+        if (const char* b = std::getenv("TAGPIPE_WORKSPACE_BYTES")) { unsigned long long v = std::strtoull(b, nullptr, 10); if (v >= (1ull << 20)) c->ws_budget = (size_t)v; }
+        compile_tables(*cfg, c->ht);
+        const HostTables& h = c->ht;
+        DevTables& d = c->dt;
+        d = h.scalars;
+        d.str_bytes = upload(c->table_mem, h.str_bytes);
+        d.str_off = upload(c->table_mem, h.str_off);
+        d.flags = upload(c->table_mem, h.flags);
+        d.next = upload(c->table_mem, h.next);
+        d.alias1 = upload(c->table_mem, h.alias1);
+        d.lit = upload(c->table_mem, h.lit);
+        d.imp_off = upload(c->table_mem, h.imp_off);
+        d.imp_ids = upload(c->table_mem, h.imp_ids);
+        d.ht_hash = upload(c->table_mem, h.ht_hash);
+        d.ht_id = upload(c->table_mem, h.ht_id);
+        d.dfa_next = upload(c->table_mem, h.dfa_next);
+        d.dfa_out = upload(c->table_mem, h.dfa_out);
+        d.pool = upload(c->table_mem, h.pool);
+        d.rules = upload(c->table_mem, h.rules);
+        d.subs = upload(c->table_mem, h.subs);
+        d.facets = upload(c->table_mem, h.facets);
+        d.facet_rules = upload(c->table_mem, h.facet_rules);
+        compute_fallback(c.get());
+        return TP_OK;
+    });
+    if (rc != TP_OK) return nullptr;
+    return c.release();
+}
+
+void tp_destroy(tp_ctx* ctx) { delete ctx; }
+
+int tp_get_table_info(const tp_ctx* ctx, tp_table_info* out) {
+    if (!ctx || !out) return fail(TP_E_INVALID_ARG, "null argument");
+    const DevTables& t = ctx->dt;
+    out->n_strings = t.n_strings;
+    out->n_action_rules = t.n_rules;
+    out->n_action_subtypes = t.n_subs;
+    out->n_facets = t.n_facets;
+    out->fired_words = t.fired_words;
+    out->n_known_tags = ctx->ht.n_known;
+    out->strict_known = ctx->ht.strict ? 1 : 0;
+    out->known_found = ctx->ht.known_found ? 1 : 0;
+    return TP_OK;
+}
+
+int tp_get_string(const tp_ctx* ctx, uint32_t id, const char** utf8, uint32_t* len) {
+    if (!ctx || !utf8 || !len || id >= ctx->dt.n_strings) return fail(TP_E_INVALID_ARG, "bad string id");
+    *utf8 = ctx->ht.strings[id].c_str();
+    *len = (uint32_t)ctx->ht.strings[id].size();
+    return TP_OK;
+}
+
+int tp_get_name(const tp_ctx* ctx, int kind, uint32_t index, const char** utf8, uint32_t* len) {
+    if (!ctx || !utf8 || !len) return fail(TP_E_INVALID_ARG, "null argument");
+    const HostTables& h = ctx->ht;
+    const std::string* s = nullptr;
+    switch (kind) {
+        case TP_NAME_ACTION_RULE: if (index < h.rule_names.size()) s = &h.rule_names[index]; break;
+        case TP_NAME_ACTION_SUBTYPE: if (index < h.sub_names.size()) s = &h.sub_names[index]; break;
+        case TP_NAME_FACET: if (index < h.facet_names.size()) s = &h.facet_names[index]; break;
+        case TP_NAME_FACET_DEFAULT: if (index < h.facet_defaults.size()) s = &h.facet_defaults[index]; break;
+        case TP_NAME_FACET_RULE: {
+            uint32_t f = index >> 16, r = index & 0xFFFF;
+            if (f < h.facet_rule_tags.size() && r < h.facet_rule_tags[f].size()) s = &h.facet_rule_tags[f][r];
+            break;
+        }
+        default: break;
+    }
+    if (!s) return fail(TP_E_INVALID_ARG, "name index out of range");
+    *utf8 = s->c_str();
+    *len = (uint32_t)s->size();
+    return TP_OK;
+}
+
+int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uint64_t n_files, tp_result* out) {
+    if (!ctx || !out || !offsets || (n_files && offsets[n_files] && !arena)) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_files; ++i) if (offsets[i + 1] < offsets[i]) return fail(TP_E_INVALID_ARG, "offsets must be non-decreasing");
+    return guarded([&]() { return run_host(ctx, arena, offsets[n_files], offsets, n_files + 1, nullptr, nullptr, nullptr, 0, n_files, out); });
+}
+
+int tp_run_scored(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const double* scores, const uint8_t* sources,
+                  uint64_t n_files, tp_result* out) {
+    if (!ctx || !out || !tag_offsets || !tag_begin) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_files; ++i) if (tag_begin[i + 1] < tag_begin[i]) return fail(TP_E_INVALID_ARG, "tag_begin must be non-decreasing");
+    uint64_t n_tags = tag_begin[n_files];
+    if (n_tags && (!scores || !sources)) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_tags; ++i) {
+        if (tag_offsets[i + 1] < tag_offsets[i]) return fail(TP_E_INVALID_ARG, "tag_offsets must be non-decreasing");
+        if (!(scores[i] == scores[i]) || scores[i] - scores[i] != 0.0) return fail(TP_E_INVALID_ARG, "scores must be finite");
+    }
+    if (tag_offsets[n_tags] && !arena) return fail(TP_E_INVALID_ARG, "null argument");
+    return guarded([&]() { return run_host(ctx, arena, tag_offsets[n_tags], tag_offsets, n_tags + 1, tag_begin, scores, sources, n_tags, n_files, out); });
+}
+
+void tp_release(tp_ctx* ctx, tp_result* res) {
+    (void)ctx;
+    if (res && res->opaque) { delete (HostResult*)res->opaque; std::memset(res, 0, sizeof *res); }
+}
+
+int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes) {
+    if (!ctx || !io || !io->offsets || !io->caption_offsets || (io->n_files && (!io->verdicts || !io->captions))) return fail(TP_E_INVALID_ARG, "null argument");
+    return guarded([&]() {
+        RunIo r{};
+        r.arena = io->arena; r.offsets = io->offsets; r.n_files = io->n_files;
+        r.captions = io->captions; r.caption_capacity = io->caption_capacity; r.grow_captions = false;
+        r.caption_offsets = io->caption_offsets; r.verdicts = io->verdicts; r.histogram = io->histogram; r.counters = io->counters;
+        r.fired = io->fired; r.facet_choice = io->facet_choice; r.stream = (hipStream_t)io->stream; r.mode = 0;
+        return run_device(ctx, r, caption_bytes);
+    });
+}
+
+int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* out, uint64_t capacity, uint64_t* needed) {
+    if (!ctx || !histogram || !needed) return fail(TP_E_INVALID_ARG, "null argument");
+    return guarded([&]() {
+        const HostTables& h = ctx->ht;
+        std::vector<uint32_t> ids;
+        for (uint32_t i = 0; i < ctx->dt.n_strings; ++i) if (histogram[i]) ids.push_back(i);
+        std::sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
+            if (histogram[a] != histogram[b]) return histogram[a] > histogram[b];
+            return h.strings[a] < h.strings[b];
+        });
+        uint64_t size = 0;
+        for (uint32_t i : ids) size += h.strings[i].size() + 1;
+        *needed = size;
+        if (!out || capacity < size) return size ? fail(TP_E_CAPACITY, "output buffer too small") : TP_OK;
+        uint64_t o = 0;
+        for (uint32_t i : ids) { std::memcpy(out + o, h.strings[i].data(), h.strings[i].size()); o += h.strings[i].size(); out[o++] = '\n'; }
+        return TP_OK;
+    });
+}
+
+int tp_get_last_timing(const tp_ctx* ctx, tp_timing* out) {
+    if (!ctx || !out) return fail(TP_E_INVALID_ARG, "null argument");
+    *out = ctx->timing;
+    return TP_OK;
+}
+
+}  // extern "C"

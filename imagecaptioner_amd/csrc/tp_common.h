@@ -1,0 +1,154 @@
+// Shared host/device definitions of the batch tag pipeline: string handles,
+// per-string attribute bits, the device table image, hashing.
+//
+// Everything the per-file pipeline compares is an INTERNED string (an id into a
+// table compiled on the host from the rule/lexicon/vocabulary files) or a
+// DYNAMIC string (normalised bytes of an input token that is in no table).
+// The reference re-applies NormalizeTag (Program.cs:1149-1158) at about eight
+// sites per tag; for an interned id that is one table read (next[id]), for a
+// dynamic string it is the identity unless the string ends in a quote character.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define TP_HD __host__ __device__ inline
+#else
+#define TP_HD inline
+#endif
+
+namespace tp {
+
+// ---- string handle -----------------------------------------------------------------------------
+// interned: the id (upper 32 bits zero).
+// dynamic : bit63 | bit62 = ends in a quote (one more NormalizeTag changes it) | attr bits 48..55 |
+//           length 32..47 | byte offset into the file's normalised-token buffer 0..31.
+typedef uint64_t H;
+constexpr H H_DYN = 1ull << 63;
+constexpr H H_UNSTABLE = 1ull << 62;
+TP_HD bool h_is_dyn(H h) { return (h & H_DYN) != 0; }
+TP_HD uint32_t h_id(H h) { return (uint32_t)h; }
+TP_HD uint32_t h_off(H h) { return (uint32_t)h; }
+TP_HD uint32_t h_len(H h) { return (uint32_t)(h >> 32) & 0xFFFFu; }
+constexpr uint32_t MAX_DYN_LEN = 0xFFFFu;
+
+// ---- attribute bits (same positions for interned flags[] words and dynamic handles) ---------------
+enum : uint32_t {
+    FL_BLANK = 1u << 0,        // string.IsNullOrWhiteSpace
+    FL_VALID = 1u << 1,        // IsValidTag, Program.cs:1135-1139
+    FL_DROP = 1u << 2,         // ShouldDropTag under the loaded configuration, Program.cs:1121-1133
+    FL_LEN2 = 1u << 3,         // at least two UTF-16 code units, Program.cs:600
+    FL_BUCKET_SHIFT = 4,       // ClassifyTag, Program.cs:1103-1111 (3 bits)
+    FL_BUCKET_MASK = 7u << 4,
+    FL_HAIR = 1u << 7,         // HairCoverageRegex, Program.cs:53
+    FL_EYES = 1u << 8,         // EyeCoverageRegex, Program.cs:54
+    FL_DYN_BITS = 0x1FEu,      // bits 1..8 travel inside a dynamic handle
+    FL_BANNED = 1u << 9,       // BannedFinalTags, Program.cs:33-35
+    FL_SAFE = 1u << 10,        // SafeModeRejectTags member, Program.cs:43-45
+    FL_SAFE_IDX_SHIFT = 11,    // index in that list (5 bits)
+    FL_KNOWN = 1u << 16,       // KnownTags member
+    FL_EDGE = 1u << 17,        // NormalizeTag changes it, or it has implied tags: ExpandImpliedTags can act on it
+    FL_NFEET = 1u << 18,       // NormalizeTag(it) == NormalizeTag("feet"), Program.cs:309, 719
+    FL_NPENIS = 1u << 19,
+    FL_NFOOTJOB = 1u << 20,
+};
+enum Bucket : uint32_t { B_IDENTITY = 0, B_FACE = 1, B_OUTFIT = 2, B_POSE = 3, B_BACKGROUND = 4, B_STYLE = 5, B_OTHER = 6 };
+TP_HD uint32_t fl_bucket(uint32_t f) { return (f & FL_BUCKET_MASK) >> FL_BUCKET_SHIFT; }
+
+TP_HD H h_make_dyn(uint32_t off, uint32_t len, uint32_t attr_bits, bool unstable) {
+    return H_DYN | (unstable ? H_UNSTABLE : 0) | ((uint64_t)((attr_bits & FL_DYN_BITS) >> 1) << 48) | ((uint64_t)len << 32) | off;
+}
+TP_HD uint32_t h_dyn_flags(H h) { return ((uint32_t)(h >> 48) & 0xFFu) << 1; }
+
+// ---- substring classifier (Aho-Corasick automaton over the literals of Program.cs:48-58) -------------
+enum : uint32_t {
+    CM_FACE = 1u << 0, CM_OUTFIT = 1u << 1, CM_POSE = 1u << 2, CM_BACKGROUND = 1u << 3, CM_STYLE = 1u << 4,
+    CM_HAIR = 1u << 5, CM_EYES = 1u << 6,
+    CM_SORRY = 1u << 7,      // the one DropTagsContains entry a normalised tag can hold
+    CM_WATERMARK = 1u << 8,  // allowlist clause, Program.cs:1130
+};
+constexpr int DFA_SYMS = 28;  // a..z, '_', everything else
+TP_HD uint32_t dfa_sym(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint32_t)(c - 'a') : (c == '_' ? 26u : 27u); }
+
+// ---- byte classes (ASCII) ----------------------------------------------------------------------------
+TP_HD bool is_ws8(uint8_t c) { return c == 0x20 || (c >= 0x09 && c <= 0x0D); }       // char.IsWhiteSpace below U+0080
+TP_HD bool is_quote8(uint8_t c) { return c == '"' || c == '\'' || c == '`'; }         // Program.cs:1150
+TP_HD bool is_punct8(uint8_t c) { return c == ';' || c == '.'; }                      // ASCII part of [;。、\.], Program.cs:1151
+TP_HD uint8_t lower8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
+TP_HD bool is_tag_first8(uint8_t c) { return (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9'); }   // ValidTagRegex, Program.cs:40
+TP_HD bool is_tag_rest8(uint8_t c) {
+    return is_tag_first8(c) || c == '_' || c == '(' || c == ')' || c == '!' || c == '\'' || c == '/' || c == '-';
+}
+
+// ---- hashing (FNV-1a 64 with a final avalanche; equality is always verified on bytes) ------------------
+constexpr uint64_t HASH_SEED = 0xcbf29ce484222325ull;
+TP_HD uint64_t hash_step(uint64_t h, uint8_t c) { return (h ^ c) * 0x100000001b3ull; }
+TP_HD uint64_t hash_fin(uint64_t h) {
+    h ^= h >> 32;
+    h *= 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    return h;
+}
+
+// ---- compiled rules --------------------------------------------------------------------------------------
+// Literal lists are [off, off+cnt) ranges of DevTables::pool holding indices into the per-file evidence bitset.
+struct DRule { uint32_t parent_id, all_off, all_cnt, any_off, any_cnt, forb_off, forb_cnt, sub_off, sub_cnt; };  // ActionRule, Program.cs:129
+struct DSub { uint32_t tag_id, any_off, any_cnt, all_off, all_cnt; };                                            // ActionSubtypeRule / FacetRule, :130-131
+struct DFacet { uint32_t def_id, rule_off, rule_cnt; };                                                          // RequiredFacet, :132
+
+constexpr uint32_t NO_ID = 0xFFFFFFFFu;
+constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
+constexpr int MAX_TOTAL_TAGS = 42;        // Program.cs:38
+constexpr int MAX_ALWAYS_ADD = 64;
+constexpr int MAX_FALLBACK = MAX_TOTAL_TAGS;
+
+// The table image as the kernels see it (all pointers are device pointers; on the host-side
+// logic check they are host pointers).
+struct DevTables {
+    // interned strings
+    uint32_t n_strings;
+    const uint8_t* str_bytes;
+    const uint32_t* str_off;     // n_strings + 1
+    const uint32_t* flags;       // FL_*
+    const uint32_t* next;        // id of NormalizeTag(string)
+    const uint32_t* alias1;      // id of the alias lookup alone (Program.cs:1155-1156) on the string as it stands
+    const uint32_t* lit;         // evidence-bitset index of the string when a rule names it, else NO_ID
+    const uint32_t* imp_off;     // n_strings + 1, ranges of imp_ids
+    const uint32_t* imp_ids;     // NormalizeTag(implied) ids, blank ones removed (Program.cs:1171-1175)
+    // open-addressing hash table over the strings' bytes
+    const uint64_t* ht_hash;     // 0 = empty slot (a real hash of 0 is stored as 1)
+    const uint32_t* ht_id;
+    uint32_t ht_mask;
+    // classifier automaton
+    const uint16_t* dfa_next;    // [state * DFA_SYMS + sym]
+    const uint16_t* dfa_out;     // CM_* reached in state
+    // rules
+    uint32_t n_lits, lit_words;
+    const uint32_t* pool;
+    const DRule* rules; uint32_t n_rules;
+    const DSub* subs; uint32_t n_subs;
+    const DFacet* facets; uint32_t n_facets;
+    const DSub* facet_rules;
+    uint32_t fired_words;
+    // configuration
+    uint32_t trigger_id;         // NormalizeTag(options.Trigger): what AddOne adds first (Program.cs:664, 693) and EvaluateCoverage looks for (:1058)
+    uint32_t girl_add_id;        // NormalizeTag("1girl") (Program.cs:665)
+    uint32_t girl_lit_id;        // "1girl" as EvaluateCoverage compares it (Program.cs:1059)
+    uint32_t n_always; uint32_t always_ids[MAX_ALWAYS_ADD];   // what AddOne makes of each profile always-add tag (Program.cs:666-668)
+    uint32_t n_fallback; uint32_t fallback_ids[MAX_FALLBACK]; // SelectTags of the minimal fallback line (Program.cs:298), computed at load
+    uint32_t feet_n, penis_n, footjob_n;                       // NormalizeTag of the three probe tags (Program.cs:309-311)
+    uint32_t drop_unknown;       // KnownTagDictionaryFound && ActiveStrictKnownTags: every string outside the tables is dropped (Program.cs:1131)
+    uint32_t allow_nonempty;     // AllowlistTags.Count > 0 (Program.cs:1130)
+    uint32_t known_active;       // KnownTagDictionaryFound && KnownTags.Count > 0 (Program.cs:818)
+    uint32_t safe_mode;
+    double line_weight;
+    uint32_t line_source;
+    uint32_t newline_len; uint8_t newline[4];
+    uint32_t final_cap;          // capacity of the per-file final-tag list
+    uint32_t evidence_grow;      // evidence list capacity = candidates + this
+};
+
+TP_HD int source_rank(uint32_t s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : 3; }   // Program.cs:712-717
+
+}  // namespace tp

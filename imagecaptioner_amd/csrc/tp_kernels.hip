@@ -1,0 +1,267 @@
+// HIP kernels of the batch tag pipeline for gfx950 (MI355X) and their launchers.
+//
+// Kernel map (all integer/byte work, HBM- and latency-bound; no MFMA):
+//   k_wave_sizes   one thread per file: token upper bound (comma count, 8 bytes per step) and line length; a wavefront
+//                  reduces both to its maximum and records the byte size of its interleaved workspace.
+//   k_scan_*       three-pass exclusive scan (u32/u64 -> u64) for workspace offsets and caption offsets.
+//   k_pipeline     one thread per file: the whole per-file pipeline (tp_pipeline.h); lane-private arrays are interleaved
+//                  across the wavefront's 64 lanes so equal element indices share 512-byte rows.
+//   k_emit         one wavefront per file: caption bytes from the final handle list (wave prefix sum of tag lengths),
+//                  tag histogram (block-private LDS counters for the low, frequent ids; global atomics for the tail),
+//                  batch counters.
+#include <hip/hip_runtime.h>
+
+#include "tp_launch.h"
+#include "tp_pipeline.h"
+
+namespace tp {
+
+// ------------------------------------------------------------------------------------------------
+// k_wave_sizes
+// ------------------------------------------------------------------------------------------------
+__device__ inline uint32_t count_commas(const uint8_t* p, uint32_t n) {
+    uint32_t c = 0, i = 0;
+    while (i < n && (((uintptr_t)(p + i)) & 7)) { c += (p[i] == ','); ++i; }
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w = *(const uint64_t*)(p + i) ^ 0x2C2C2C2C2C2C2C2Cull;   // zero byte where the input holds ','
+        uint64_t t = (w & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full;
+        t = ~(t | w | 0x7F7F7F7F7F7F7F7Full);
+        c += (uint32_t)__popcll(t);
+    }
+    for (; i < n; ++i) c += (p[i] == ',');
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_wave_sizes(DevTables t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin,
+                                                    uint64_t n_files, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status) {
+    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t T = 1, LB = 0;
+    if (f < n_files) {
+        if (tag_begin) {   // scored ingest: tag count and total text length are read off the offset arrays
+            uint64_t lo = tag_begin[f], hi = tag_begin[f + 1];
+            uint64_t ntag = hi - lo, bytes = offsets[hi] - offsets[lo];
+            if (ntag > 0x7FFFFFFFull || bytes > 0x7FFFFFFFull) { atomicOr(status, 1u); ntag = 0; bytes = 0; }
+            T = (uint32_t)ntag;
+            LB = (uint32_t)bytes;
+        } else {
+            uint64_t len = offsets[f + 1] - offsets[f];
+            if (len > 0x7FFFFFFFull) { atomicOr(status, 1u); len = 0; }
+            LB = (uint32_t)len;
+            T = count_commas(arena + offsets[f], LB) + 1;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t oT = __shfl_xor(T, d), oL = __shfl_xor(LB, d);
+        T = T > oT ? T : oT;
+        LB = LB > oL ? LB : oL;
+    }
+    if ((threadIdx.x & 63) == 0 && (f < n_files)) {
+        uint64_t w = f >> 6;
+        WsLayout L = ws_layout(T, LB, t.final_cap, t.evidence_grow, t.lit_words);
+        wave_T[w] = T;
+        wave_LB[w] = LB;
+        wave_bytes[w] = L.total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan: out[i] = base + sum(in[0..i)), out[n] = base + total
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256, SCAN_PER_THREAD = 16, SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
+
+template <class Tin>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(const Tin* in, uint64_t n, uint64_t* out, uint64_t* tile_sums) {
+    __shared__ uint64_t wave_tot[SCAN_THREADS / 64];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    uint64_t v[SCAN_PER_THREAD];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { v[k] = (base + k < n) ? (uint64_t)in[base + k] : 0; sum += v[k]; }
+    uint64_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { uint64_t o = __shfl_up(incl, d); if ((int)(threadIdx.x & 63) >= d) incl += o; }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t prefix = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) prefix += wave_tot[w];
+    uint64_t run = prefix + incl - sum;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == SCAN_THREADS - 1) tile_sums[blockIdx.x] = prefix + incl;
+}
+__global__ __launch_bounds__(64) void k_scan_sums(uint64_t* tile_sums, uint64_t n_tiles) {
+    // one wavefront walks the tile sums 64 at a time
+    uint64_t carry = 0;
+    for (uint64_t b = 0; b < n_tiles; b += 64) {
+        uint64_t i = b + threadIdx.x;
+        uint64_t x = i < n_tiles ? tile_sums[i] : 0;
+        uint64_t incl = x;
+        for (int d = 1; d < 64; d <<= 1) { uint64_t o = __shfl_up(incl, d); if ((int)threadIdx.x >= d) incl += o; }
+        if (i < n_tiles) tile_sums[i] = carry + incl - x;
+        carry += __shfl(incl, 63);
+    }
+    if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
+}
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_add(uint64_t* out, uint64_t n, const uint64_t* tile_sums, uint64_t n_tiles, const uint64_t* base_ptr,
+                                                           uint64_t* total_out) {
+    uint64_t base = base_ptr ? *base_ptr : 0;
+    uint64_t add = tile_sums[blockIdx.x] + base;
+    uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE;
+    for (int k = threadIdx.x; k < SCAN_TILE; k += SCAN_THREADS) if (i0 + k < n) out[i0 + k] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[n] = tile_sums[n_tiles] + base;
+        if (total_out) *total_out = tile_sums[n_tiles] + base;
+    }
+}
+
+template <class Tin>
+static hipError_t scan_exclusive(const Tin* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s) {
+    uint64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (n_tiles == 0) n_tiles = 1;
+    hipLaunchKernelGGL(k_scan_tiles<Tin>, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s, in, n, out, tile_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, s, tile_sums, n_tiles);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s, out, n, tile_sums, n_tiles, base_ptr, total_out);
+    return hipGetLastError();
+}
+uint64_t scan_tiles_needed(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 2; }
+
+// ------------------------------------------------------------------------------------------------
+// k_pipeline
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
+    uint64_t local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // file index inside the chunk
+    uint64_t f = a.file0 + local;
+    if (f >= a.file_end) return;
+    uint64_t w = f >> 6;
+    uint32_t lane = (uint32_t)(f & 63);
+    WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
+    uint8_t* wave_base = a.workspace + (a.wave_off[w] - a.wave_off[a.file0 >> 6]);
+    FileWs ws = ws_bind(wave_base, L, lane);
+    FileIn in;
+    if (a.tag_begin) {
+        in.text = nullptr; in.len = 0;
+        in.arena = a.arena; in.tag_offsets = a.offsets; in.tag_lo = a.tag_begin[f]; in.tag_hi = a.tag_begin[f + 1];
+        in.scores = a.scores; in.sources = a.sources;
+    } else {
+        uint64_t o = a.offsets[f];
+        in.text = a.arena + o; in.len = (uint32_t)(a.offsets[f + 1] - o);
+        in.arena = nullptr; in.tag_offsets = nullptr; in.tag_lo = in.tag_hi = 0; in.scores = nullptr; in.sources = nullptr;
+    }
+    FileOut out;
+    process_file(t, in, ws, out, a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, a.mode);
+    a.verdicts[f] = out.verdict;
+    a.n_final[f] = out.n_final;
+    a.cap_len[f] = out.caption_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_emit
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t HOT_IDS = 2048;   // ids below this are counted in LDS; the table compiler gives the frequent tags the low ids
+
+__global__ __launch_bounds__(256) void k_emit(DevTables t, EmitArgs a) {
+    __shared__ uint32_t hot[HOT_IDS];
+    for (uint32_t i = threadIdx.x; i < HOT_IDS; i += blockDim.x) hot[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t hot_n = t.n_strings < HOT_IDS ? t.n_strings : HOT_IDS;
+    uint64_t c_files = 0, c_low = 0, c_elig = 0, c_foot = 0, c_fb = 0, c_rej = 0, c_uns = 0, c_safe = 0, c_other = 0;
+
+    for (uint64_t f = a.file0 + wave_global; f < a.file_end; f += n_waves) {
+        uint64_t w = f >> 6;
+        WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
+        uint8_t* wave_base = a.workspace + (a.wave_off[w] - a.wave_off[a.file0 >> 6]);
+        FileWs ws = ws_bind(wave_base, L, (uint32_t)(f & 63));
+        uint32_t nfin = a.n_final[f];
+        uint64_t out0 = a.caption_offsets[f];
+        uint32_t total = (uint32_t)(a.caption_offsets[f + 1] - out0);
+        uint8_t fl = a.verdicts[f].flags;
+        if (lane == 0) {
+            ++c_files;
+            c_low += (fl & TP_F_LOW) != 0; c_elig += (fl & TP_F_ELIGIBLE) != 0; c_foot += (fl & TP_F_FOOTJOB) != 0; c_fb += (fl & TP_F_FALLBACK) != 0;
+            c_rej += (fl & TP_F_LINE_REJECTED) != 0; c_uns += (fl & TP_F_UNSUPPORTED) != 0; c_safe += (fl & TP_F_SAFE_REJECT) != 0;
+        }
+        if (total == 0) continue;   // unsupported file: nothing is written
+        uint32_t running = 0;
+        for (uint32_t k0 = 0; k0 < nfin; k0 += 64) {
+            uint32_t k = k0 + lane;
+            bool live = k < nfin;
+            H h = live ? ws.fin[k] : 0;
+            const uint8_t* src = nullptr;
+            uint32_t len = 0;
+            if (live) {
+                if (h_is_dyn(h)) { src = ws.norm + h_off(h); len = h_len(h); }
+                else { uint32_t id = h_id(h); uint32_t o = t.str_off[id]; src = t.str_bytes + o; len = t.str_off[id + 1] - o; }
+            }
+            bool sep = live && (k + 1 < nfin);
+            uint32_t seg = len + (sep ? 2u : 0u);
+            uint32_t incl = seg;
+            for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+            uint8_t* dst = a.captions + out0 + running + (incl - seg);
+            for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+            if (sep) { dst[len] = ','; dst[len + 1] = ' '; }
+            running += __shfl(incl, 63);
+            if (live && a.histogram) {
+                if (h_is_dyn(h)) ++c_other;
+                else if (h_id(h) < hot_n) atomicAdd(&hot[h_id(h)], 1u);
+                else atomicAdd((unsigned long long*)&a.histogram[h_id(h)], 1ull);
+            }
+        }
+        if (lane < t.newline_len) a.captions[out0 + running + lane] = t.newline[lane];
+    }
+    __syncthreads();
+    if (a.histogram) {
+        for (uint32_t i = threadIdx.x; i < hot_n; i += blockDim.x) {
+            uint32_t c = hot[i];
+            if (c) atomicAdd((unsigned long long*)&a.histogram[i], (unsigned long long)c);
+        }
+        for (int d = 32; d >= 1; d >>= 1) c_other += __shfl_xor(c_other, d);
+        if (lane == 0 && c_other) atomicAdd((unsigned long long*)&a.histogram[t.n_strings], (unsigned long long)c_other);
+    }
+    if (a.counters && lane == 0) {
+        unsigned long long* c = (unsigned long long*)a.counters;
+        if (c_files) atomicAdd(&c[0], (unsigned long long)c_files);
+        if (c_low) atomicAdd(&c[1], (unsigned long long)c_low);
+        if (c_elig) atomicAdd(&c[2], (unsigned long long)c_elig);
+        if (c_foot) atomicAdd(&c[3], (unsigned long long)c_foot);
+        if (c_fb) atomicAdd(&c[4], (unsigned long long)c_fb);
+        if (c_rej) atomicAdd(&c[5], (unsigned long long)c_rej);
+        if (c_uns) atomicAdd(&c[6], (unsigned long long)c_uns);
+        if (c_safe) atomicAdd(&c[7], (unsigned long long)c_safe);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, uint64_t n_files,
+                             uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s) {
+    if (n_files == 0) return hipSuccess;
+    unsigned blocks = (unsigned)((n_files + 255) / 256);
+    hipLaunchKernelGGL(k_wave_sizes, dim3(blocks), dim3(256), 0, s, t, arena, offsets, tag_begin, n_files, wave_T, wave_LB, wave_bytes, status);
+    return hipGetLastError();
+}
+hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s) {
+    return scan_exclusive<uint64_t>(in, n, out, tile_sums, base_ptr, total_out, s);
+}
+hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s) {
+    return scan_exclusive<uint32_t>(in, n, out, tile_sums, base_ptr, total_out, s);
+}
+hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_t s) {
+    uint64_t n = a.file_end - a.file0;
+    if (n == 0) return hipSuccess;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_pipeline, dim3(blocks), dim3(256), 0, s, t, a);
+    return hipGetLastError();
+}
+hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
+    uint64_t n = a.file_end - a.file0;
+    if (n == 0) return hipSuccess;
+    uint64_t want = (n + 3) / 4;                    // four wavefronts (files in flight) per block
+    unsigned blocks = (unsigned)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, t, a);
+    return hipGetLastError();
+}
+
+}  // namespace tp

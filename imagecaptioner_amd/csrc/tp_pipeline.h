@@ -1,0 +1,785 @@
+// The per-file tag pipeline: one sequential pass over one file's tags, written
+// so that the same source runs as a GPU thread (one file per lane, private
+// arrays interleaved across the 64 lanes of a wavefront so that lanes touching
+// the same element index hit one contiguous 512-byte row) and, for logic checks
+// without a GPU, as a plain host function.
+//
+// It restates the pure span of the reference's loop body, Program.cs:223-229
+// and 292-329 with the OpenAI branch off, fed by ParseTagCandidatesFromLine
+// (Program.cs:574-605) or by scored candidates shaped like ParseJoyTags output
+// (Program.cs:463-489).  Function-by-function citations are inline.
+#pragma once
+#include <math.h>
+
+#include "../../include/tagpipe.h"
+#include "tp_common.h"
+
+namespace tp {
+
+// Element k of a lane-private array: rows of 64 elements, one per lane.
+template <class T>
+struct LaneArr {
+    T* base;
+    TP_HD T& operator[](uint32_t k) const { return base[(size_t)k * 64]; }
+};
+
+// Byte layout of one wavefront's workspace (64 files).  T = the largest token
+// count among its files, LB = the largest line length.
+struct WsLayout {
+    uint64_t o_hnd, o_score, o_order, o_sorted, o_src, o_dl, o_ev, o_snap, o_fin, o_ebits, o_line, o_norm, total;
+    uint32_t cap_t, cap_e, cap_snap, cap_f, cap_norm;
+};
+TP_HD uint64_t ws_align(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
+TP_HD WsLayout ws_layout(uint32_t T, uint32_t LB, uint32_t final_cap, uint32_t evidence_grow, uint32_t lit_words) {
+    WsLayout L;
+    if (T < 1) T = 1;
+    L.cap_t = T;
+    L.cap_e = T + evidence_grow;
+    L.cap_f = final_cap;
+    L.cap_snap = L.cap_e > L.cap_f ? L.cap_e : L.cap_f;
+    L.cap_norm = (LB + 16 + 15) & ~15u;
+    uint64_t o = 0;
+    L.o_hnd = o;    o = ws_align(o + (uint64_t)T * 64 * 8);
+    L.o_score = o;  o = ws_align(o + (uint64_t)T * 64 * 8);
+    L.o_order = o;  o = ws_align(o + (uint64_t)T * 64 * 4);
+    L.o_sorted = o; o = ws_align(o + (uint64_t)T * 64 * 4);
+    L.o_src = o;    o = ws_align(o + (uint64_t)T * 64);
+    L.o_dl = o;     o = ws_align(o + (uint64_t)T * 64 * 8);
+    L.o_ev = o;     o = ws_align(o + (uint64_t)L.cap_e * 64 * 8);
+    L.o_snap = o;   o = ws_align(o + (uint64_t)L.cap_snap * 64 * 8);
+    L.o_fin = o;    o = ws_align(o + (uint64_t)L.cap_f * 64 * 8);
+    L.o_ebits = o;  o = ws_align(o + (uint64_t)(lit_words ? lit_words : 1) * 64 * 4);
+    L.o_line = o;   o = ws_align(o + (uint64_t)L.cap_norm * 64);
+    L.o_norm = o;   o = ws_align(o + (uint64_t)L.cap_norm * 64);
+    L.total = o;
+    return L;
+}
+
+struct FileWs {
+    LaneArr<H> hnd, dl, ev, snap, fin;
+    LaneArr<double> score;
+    LaneArr<uint32_t> order, sorted, ebits;
+    LaneArr<uint8_t> src;
+    uint8_t* line;   // thread-contiguous, cap_norm bytes: CRLF-collapsed copy of the raw line when needed
+    uint8_t* norm;   // thread-contiguous, cap_norm bytes: bytes of dynamic strings
+    uint32_t cap_t, cap_e, cap_snap, cap_f, cap_norm;
+};
+TP_HD FileWs ws_bind(uint8_t* wave_base, const WsLayout& L, uint32_t lane) {
+    FileWs w;
+    w.hnd.base = (H*)(wave_base + L.o_hnd) + lane;
+    w.score.base = (double*)(wave_base + L.o_score) + lane;
+    w.order.base = (uint32_t*)(wave_base + L.o_order) + lane;
+    w.sorted.base = (uint32_t*)(wave_base + L.o_sorted) + lane;
+    w.src.base = (uint8_t*)(wave_base + L.o_src) + lane;
+    w.dl.base = (H*)(wave_base + L.o_dl) + lane;
+    w.ev.base = (H*)(wave_base + L.o_ev) + lane;
+    w.snap.base = (H*)(wave_base + L.o_snap) + lane;
+    w.fin.base = (H*)(wave_base + L.o_fin) + lane;
+    w.ebits.base = (uint32_t*)(wave_base + L.o_ebits) + lane;
+    w.line = wave_base + L.o_line + (size_t)lane * L.cap_norm;
+    w.norm = wave_base + L.o_norm + (size_t)lane * L.cap_norm;
+    w.cap_t = L.cap_t; w.cap_e = L.cap_e; w.cap_snap = L.cap_snap; w.cap_f = L.cap_f; w.cap_norm = L.cap_norm;
+    return w;
+}
+
+struct FileIn {
+    // line ingest
+    const uint8_t* text;
+    uint32_t len;
+    // scored ingest (text == nullptr)
+    const uint8_t* arena;
+    const uint64_t* tag_offsets;
+    uint64_t tag_lo, tag_hi;
+    const double* scores;
+    const uint8_t* sources;
+};
+struct FileOut {
+    tp_verdict verdict;
+    uint32_t n_final;      // handles left in ws.fin: the caption's tags, in order
+    uint32_t caption_len;  // bytes of the caption line including the newline
+};
+
+// ================================================================================================
+// string helpers
+// ================================================================================================
+TP_HD const uint8_t* str_ptr(const DevTables& t, uint32_t id) { return t.str_bytes + t.str_off[id]; }
+TP_HD uint32_t str_len(const DevTables& t, uint32_t id) { return t.str_off[id + 1] - t.str_off[id]; }
+
+TP_HD uint32_t hflags(const DevTables& t, H h) {
+    if (!h_is_dyn(h)) return t.flags[h_id(h)];
+    return h_dyn_flags(h) | ((h & H_UNSTABLE) ? (uint32_t)FL_EDGE : 0u);
+}
+TP_HD uint32_t hbytes(const DevTables& t, H h) { return h_is_dyn(h) ? h_len(h) : str_len(t, h_id(h)); }
+
+TP_HD bool heq(const FileWs& ws, H a, H b) {
+    if (!h_is_dyn(a) || !h_is_dyn(b)) return a == b;   // a dynamic string is in no table, so mixed pairs differ
+    uint32_t n = h_len(a);
+    if (n != h_len(b)) return false;
+    const uint8_t* p = ws.norm + h_off(a);
+    const uint8_t* q = ws.norm + h_off(b);
+    for (uint32_t i = 0; i < n; ++i) if (p[i] != q[i]) return false;
+    return true;
+}
+TP_HD bool lfind(const FileWs& ws, const LaneArr<H>& arr, uint32_t n, H h) {
+    for (uint32_t i = 0; i < n; ++i) if (heq(ws, arr[i], h)) return true;
+    return false;
+}
+
+// Attributes of a string that is in no table (ASCII, already normalised).
+TP_HD uint32_t classify_dyn(const DevTables& t, const uint8_t* p, uint32_t n) {
+    bool valid = n > 0 && is_tag_first8(p[0]);
+    uint32_t state = 0, mask = 0;
+    // CharacterNameRegex ^[a-z0-9]+(_[a-z0-9]+){1,3}$ (Program.cs:47)
+    uint32_t segs = 0, seglen = 0;
+    bool name_ok = true;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint8_t c = p[i];
+        if (i > 0 && !is_tag_rest8(c)) valid = false;
+        state = t.dfa_next[state * DFA_SYMS + dfa_sym(c)];
+        mask |= t.dfa_out[state];
+        if (is_tag_first8(c)) { if (seglen == 0) ++segs; ++seglen; }
+        else if (c == '_') { if (seglen == 0) name_ok = false; seglen = 0; }
+        else name_ok = false;
+    }
+    if (seglen == 0) name_ok = false;
+    bool is_name = name_ok && segs >= 2 && segs <= 4 && !(mask & (CM_FACE | CM_OUTFIT | CM_POSE | CM_BACKGROUND | CM_STYLE));   // IsLikelyCharacterName, Program.cs:1113-1119
+    uint32_t bucket = is_name ? B_IDENTITY : (mask & CM_FACE) ? B_FACE : (mask & CM_OUTFIT) ? B_OUTFIT : (mask & CM_POSE) ? B_POSE
+                      : (mask & CM_BACKGROUND) ? B_BACKGROUND : (mask & CM_STYLE) ? B_STYLE : B_OTHER;                           // ClassifyTag, Program.cs:1103-1111
+    bool rating = n >= 6 && p[0] == 'r' && p[1] == 'a' && p[2] == 't' && p[3] == 'i' && p[4] == 'n' && p[5] == 'g';
+    bool drop = !valid || (mask & CM_SORRY) || (t.allow_nonempty && (rating || (mask & CM_WATERMARK))) || t.drop_unknown;    // ShouldDropTag, Program.cs:1121-1133
+    return (valid ? (uint32_t)FL_VALID : 0u) | (drop ? (uint32_t)FL_DROP : 0u) | (n >= 2 ? (uint32_t)FL_LEN2 : 0u) | (bucket << FL_BUCKET_SHIFT) |
+           ((mask & CM_HAIR) ? (uint32_t)FL_HAIR : 0u) | ((mask & CM_EYES) ? (uint32_t)FL_EYES : 0u);
+}
+
+// Hash-table probe with the candidate bytes given as plain memory.
+TP_HD uint32_t probe_bytes(const DevTables& t, const uint8_t* p, uint32_t n, uint64_t hash) {
+    if (hash == 0) hash = 1;
+    uint32_t slot = (uint32_t)hash & t.ht_mask;
+    for (;;) {
+        uint64_t hh = t.ht_hash[slot];
+        if (hh == 0) return NO_ID;
+        if (hh == hash) {
+            uint32_t id = t.ht_id[slot];
+            if (str_len(t, id) == n) {
+                const uint8_t* q = str_ptr(t, id);
+                uint32_t i = 0;
+                while (i < n && q[i] == p[i]) ++i;
+                if (i == n) return id;
+            }
+        }
+        slot = (slot + 1) & t.ht_mask;
+    }
+}
+
+// Streams NormalizeTagBasic's last three steps (\s+ -> "_", _+ -> "_", ToLowerInvariant; Program.cs:1152-1154)
+// over the span left by the trims.
+struct NormIt {
+    const uint8_t* s;
+    uint32_t i, j;
+    bool last_us;
+    TP_HD NormIt(const uint8_t* s_, uint32_t i_, uint32_t j_) : s(s_), i(i_), j(j_), last_us(false) {}
+    TP_HD int next() {
+        while (i < j) {
+            uint8_t c = s[i++];
+            if (is_ws8(c) || c == '_') {
+                if (last_us) continue;
+                last_us = true;
+                return '_';
+            }
+            last_us = false;
+            return lower8(c);
+        }
+        return -1;
+    }
+};
+
+// One raw token -> the handle NormalizeTag (Program.cs:1149-1158) gives it.  Returns false when the token is empty
+// after trimming (Split's RemoveEmptyEntries, Program.cs:1183-1185).  `final_nl_rule` applies the regex `$` rule of
+// Program.cs:1151 (it also matches before a final '\n'): only scored ingest can see a real '\n' there.
+TP_HD bool make_token(const DevTables& t, FileWs& ws, uint32_t& norm_used, const uint8_t* s, uint32_t i, uint32_t j, bool final_nl_rule,
+                      H& out, bool& unsupported) {
+    while (i < j && is_ws8(s[i])) ++i;                 // TrimEntries / Trim()
+    while (j > i && is_ws8(s[j - 1])) --j;
+    if (i == j) return false;
+    while (i < j && is_quote8(s[i])) ++i;              // Trim('"', '\'', '`')
+    while (j > i && is_quote8(s[j - 1])) --j;
+    uint32_t tail = j;                                 // [;。、\.]+$
+    if (final_nl_rule && j > i && s[j - 1] == '\n') {
+        uint32_t q = j - 1;
+        while (q > i && is_punct8(s[q - 1])) --q;
+        // the punctuation run before the final newline goes, the newline stays (and becomes '_')
+        if (q < j - 1) {
+            // normalise [i,q) followed by the newline: handled by hashing the two pieces in sequence below
+            tail = q;
+        } else {
+            tail = j;
+        }
+        // pass 1: hash + length
+        uint64_t hsh = HASH_SEED;
+        uint32_t n = 0;
+        bool last_us = false;
+        {
+            NormIt it(s, i, tail);
+            for (int c; (c = it.next()) >= 0;) { hsh = hash_step(hsh, (uint8_t)c); ++n; }
+            last_us = it.last_us;
+        }
+        bool add_us = (tail < j) && !last_us;          // the kept '\n' -> '_' unless it merges with a preceding '_'
+        if (tail == j) add_us = false;                 // newline already inside [i,tail)
+        if (add_us) { hsh = hash_step(hsh, '_'); ++n; }
+        hsh = hash_fin(hsh);
+        // materialise (rare path) and look it up
+        if (n > MAX_DYN_LEN || norm_used + n > ws.cap_norm) { unsupported = true; return false; }
+        uint8_t* dst = ws.norm + norm_used;
+        {
+            NormIt it(s, i, tail);
+            uint32_t k = 0;
+            for (int c; (c = it.next()) >= 0;) dst[k++] = (uint8_t)c;
+            if (add_us) dst[k++] = '_';
+        }
+        uint32_t id = probe_bytes(t, dst, n, hsh);
+        if (id != NO_ID) { out = t.alias1[id]; return true; }
+        out = h_make_dyn(norm_used, n, classify_dyn(t, dst, n), n > 0 && is_quote8(dst[n - 1]));
+        norm_used += n;
+        return true;
+    }
+    while (tail > i && is_punct8(s[tail - 1])) --tail;
+    j = tail;
+    // pass 1: hash and length of the normalised form
+    uint64_t hsh = HASH_SEED;
+    uint32_t n = 0;
+    {
+        NormIt it(s, i, j);
+        for (int c; (c = it.next()) >= 0;) { hsh = hash_step(hsh, (uint8_t)c); ++n; }
+    }
+    hsh = hash_fin(hsh);
+    if (hsh == 0) hsh = 1;
+    // probe, verifying the bytes against the stream
+    uint32_t slot = (uint32_t)hsh & t.ht_mask;
+    for (;;) {
+        uint64_t hh = t.ht_hash[slot];
+        if (hh == 0) break;
+        if (hh == hsh) {
+            uint32_t id = t.ht_id[slot];
+            if (str_len(t, id) == n) {
+                const uint8_t* q = str_ptr(t, id);
+                NormIt it(s, i, j);
+                uint32_t k = 0;
+                for (; k < n; ++k) if ((int)q[k] != it.next()) break;
+                if (k == n) { out = t.alias1[id]; return true; }
+            }
+        }
+        slot = (slot + 1) & t.ht_mask;
+    }
+    // in no table: keep the bytes
+    if (n > MAX_DYN_LEN || norm_used + n > ws.cap_norm) { unsupported = true; return false; }
+    uint8_t* dst = ws.norm + norm_used;
+    {
+        NormIt it(s, i, j);
+        uint32_t k = 0;
+        for (int c; (c = it.next()) >= 0;) dst[k++] = (uint8_t)c;
+    }
+    out = h_make_dyn(norm_used, n, classify_dyn(t, dst, n), n > 0 && is_quote8(dst[n - 1]));
+    norm_used += n;
+    return true;
+}
+
+// NormalizeTag applied to a string the pipeline already holds (Program.cs:1149-1158).
+TP_HD H norm_hop(const DevTables& t, const FileWs& ws, H h) {
+    if (!h_is_dyn(h)) return t.next[h_id(h)];
+    if (!(h & H_UNSTABLE)) return h;
+    // An already-normalised string that ends in a quote: the quote trim and then the punctuation strip shorten it.
+    const uint8_t* p = ws.norm + h_off(h);
+    uint32_t n = h_len(h);
+    while (n > 0 && is_quote8(p[n - 1])) --n;
+    while (n > 0 && is_punct8(p[n - 1])) --n;
+    if (n == 0) return t.alias1[EMPTY_ID];
+    uint64_t hsh = HASH_SEED;
+    for (uint32_t k = 0; k < n; ++k) hsh = hash_step(hsh, p[k]);
+    uint32_t id = probe_bytes(t, p, n, hash_fin(hsh));
+    if (id != NO_ID) return t.alias1[id];
+    return h_make_dyn(h_off(h), n, classify_dyn(t, p, n), is_quote8(p[n - 1]));
+}
+
+// ExpandImpliedTags (Program.cs:1160-1179) on an insertion-ordered set.
+TP_HD void expand_implied(const DevTables& t, FileWs& ws, const LaneArr<H>& L, uint32_t& n, uint32_t cap, bool& overflow) {
+    bool any = false;
+    for (uint32_t i = 0; i < n; ++i) if (hflags(t, L[i]) & FL_EDGE) { any = true; break; }
+    if (!any) return;   // every NormalizeTag is the identity and nothing has implied tags: the loop body cannot change the set
+    bool changed;
+    do {
+        changed = false;
+        uint32_t ns = 0;
+        for (uint32_t i = 0; i < n; ++i) {             // snapshot = tags.Select(NormalizeTag).Where(non-blank).Distinct().ToList()
+            H s = norm_hop(t, ws, L[i]);
+            if (hflags(t, s) & FL_BLANK) continue;
+            if (lfind(ws, ws.snap, ns, s)) continue;
+            if (ns >= ws.cap_snap) { overflow = true; return; }
+            ws.snap[ns++] = s;
+        }
+        for (uint32_t k = 0; k < ns; ++k) {
+            H tag = ws.snap[k];
+            if (!lfind(ws, L, n, tag)) {
+                if (n >= cap) { overflow = true; return; }
+                L[n++] = tag;
+                changed = true;
+            }
+            if (!h_is_dyn(tag)) {
+                uint32_t a = t.imp_off[h_id(tag)], b = t.imp_off[h_id(tag) + 1];
+                for (uint32_t m = a; m < b; ++m) {
+                    H imp = t.imp_ids[m];
+                    if (lfind(ws, L, n, imp)) continue;
+                    if (n >= cap) { overflow = true; return; }
+                    L[n++] = imp;
+                    changed = true;
+                }
+            }
+        }
+    } while (changed);
+}
+
+TP_HD bool ebit(const FileWs& ws, uint32_t idx) { return (ws.ebits[idx >> 5] >> (idx & 31)) & 1u; }
+TP_HD bool all_set(const DevTables& t, const FileWs& ws, uint32_t off, uint32_t cnt) {
+    for (uint32_t k = 0; k < cnt; ++k) if (!ebit(ws, t.pool[off + k])) return false;
+    return true;
+}
+TP_HD bool any_set(const DevTables& t, const FileWs& ws, uint32_t off, uint32_t cnt) {
+    for (uint32_t k = 0; k < cnt; ++k) if (ebit(ws, t.pool[off + k])) return true;
+    return false;
+}
+// MatchesSubtypeRule / MatchesFacetRule (Program.cs:784-794)
+TP_HD bool match_any_all(const DevTables& t, const FileWs& ws, const DSub& r) {
+    if (r.any_cnt && !any_set(t, ws, r.any_off, r.any_cnt)) return false;
+    if (r.all_cnt && !all_set(t, ws, r.all_off, r.all_cnt)) return false;
+    return true;
+}
+
+TP_HD bool match_ci(const uint8_t* s, uint32_t pos, uint32_t end, const char* pat, uint32_t plen, bool nl_is_space) {
+    if (pos + plen > end) return false;
+    for (uint32_t k = 0; k < plen; ++k) {
+        uint8_t c = s[pos + k];
+        if (nl_is_space && c == '\n') c = ' ';
+        if (lower8(c) != (uint8_t)pat[k]) return false;
+    }
+    return true;
+}
+TP_HD void trim_span(const uint8_t* s, uint32_t& a, uint32_t& b) {
+    while (a < b && is_ws8(s[a])) ++a;
+    while (b > a && is_ws8(s[b - 1])) --b;
+}
+// DropTagsContains (Program.cs:56-58) over a line whose '\n' count as ' ' (Program.cs:595); the U+2019 entry cannot
+// occur in ASCII input.
+TP_HD bool has_refusal_phrase(const uint8_t* s, uint32_t a, uint32_t b) {
+    for (uint32_t p = a; p < b; ++p) {
+        switch (lower8(s[p])) {
+            case 'n': if (match_ci(s, p, b, "negative:", 9, true)) return true; break;
+            case 'p': if (match_ci(s, p, b, "positive:", 9, true)) return true; break;
+            case 's': if (match_ci(s, p, b, "sorry", 5, true)) return true; break;
+            case 'i':
+                if (p + 1 < b && (s[p + 1] == ' ' || s[p + 1] == '\n' || s[p + 1] == '\'')) {
+                    if (match_ci(s, p, b, "i can't", 7, true) || match_ci(s, p, b, "i cannot", 8, true) ||
+                        match_ci(s, p, b, "i'm not able", 12, true) || match_ci(s, p, b, "i won't", 7, true)) return true;
+                }
+                break;
+            case 'c': if (match_ci(s, p, b, "cannot provide", 14, true)) return true; break;
+            case 'u': if (match_ci(s, p, b, "unable to", 9, true)) return true; break;
+            case 'a': if (match_ci(s, p, b, "as an ai", 8, true)) return true; break;
+            default: break;
+        }
+    }
+    return false;
+}
+
+// ================================================================================================
+// The pipeline.  mode 0: whole span.  mode 1: stop after SelectTags and leave its result in ws.fin
+// (used once at load time to evaluate the minimal fallback line, Program.cs:298).
+// ================================================================================================
+TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOut& out, uint32_t* fired, uint16_t* facet_choice, int mode) {
+    tp_verdict& v = out.verdict;
+    v.coverage = 0; v.flags = 0; v.n_tags = 0; v.n_candidates = 0; v.n_selected = 0; v.safe_hit = -1; v.n_evidence = 0; v.n_unknown = 0; v.n_dropped = 0;
+    out.n_final = 0;
+    out.caption_len = 0;
+    if (fired) for (uint32_t w = 0; w < t.fired_words; ++w) fired[w] = 0;
+    if (facet_choice) for (uint32_t f = 0; f < t.n_facets; ++f) facet_choice[f] = 0xFFFF;
+
+    bool unsupported = false, overflow = false, rejected = false;
+    uint32_t n = 0;          // candidates
+    uint32_t norm_used = 0;
+
+    if (in.text) {
+        // ---------------- NormalizeRawTagLine (Program.cs:589-605) ----------------
+        const uint8_t* s = in.text;
+        uint32_t a = 0, b = in.len;
+        bool has_colon = false, has_tick = false, has_crlf = false;
+        for (uint32_t p = 0; p < b; ++p) {
+            uint8_t c = s[p];
+            if (c >= 0x80) unsupported = true;
+            has_colon |= (c == ':');
+            has_tick |= (c == '`');
+            if (c == '\r' && p + 1 < b && s[p + 1] == '\n') has_crlf = true;
+        }
+        if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
+        if (has_crlf) {                                         // raw.Replace("\r\n", "\n")
+            uint32_t k = 0;
+            for (uint32_t p = 0; p < b; ++p) {
+                if (s[p] == '\r' && p + 1 < b && s[p + 1] == '\n') continue;
+                ws.line[k++] = s[p];
+            }
+            s = ws.line;
+            b = k;
+        }
+        trim_span(s, a, b);                                     // .Trim()  (a blank raw line ends here too, Program.cs:590)
+        if (a < b && has_colon) {
+            // ExtractAfterPrefixLine(s, "POSITIVE:"), Program.cs:1199-1205
+            uint32_t p = a;
+            for (;;) {
+                uint32_t e = p;
+                while (e < b && s[e] != '\n') ++e;
+                uint32_t la = p, lb = e;
+                trim_span(s, la, lb);
+                if (match_ci(s, la, lb, "positive:", 9, false)) {
+                    la += 9;
+                    trim_span(s, la, lb);
+                    if (la < lb) { a = la; b = lb; }            // only a non-blank remainder replaces s (Program.cs:593)
+                    break;
+                }
+                if (e >= b) break;
+                p = e + 1;
+            }
+            // CutAfterPrefix(s, "NEGATIVE:"), Program.cs:1207-1210
+            for (uint32_t q = a; q + 9 <= b; ++q) {
+                if (match_ci(s, q, b, "negative:", 9, false)) { b = q; trim_span(s, a, b); break; }
+            }
+        }
+        if (a < b && has_tick) {
+            // StripCodeFences, Program.cs:1189-1197
+            trim_span(s, a, b);
+            if (b - a >= 3 && s[a] == '`' && s[a + 1] == '`' && s[a + 2] == '`') {
+                uint32_t q = a;
+                while (q < b && s[q] != '\n') ++q;
+                if (q < b) a = q + 1;
+                if (b - a >= 3) {
+                    for (uint32_t r = b - 3 + 1; r-- > a;) {
+                        if (s[r] == '`' && s[r + 1] == '`' && s[r + 2] == '`') { b = r; break; }
+                    }
+                }
+                trim_span(s, a, b);
+            }
+        }
+        trim_span(s, a, b);                                     // .Replace("\n", " ").Trim()
+        // LooksBad, Program.cs:1141-1147
+        if (a >= b) rejected = true;
+        else {
+            uint32_t commas = 0;
+            for (uint32_t p = a; p < b; ++p) commas += (s[p] == ',');
+            if (has_refusal_phrase(s, a, b) || (commas < 2 && (b - a) > 40)) rejected = true;
+        }
+        if (!rejected) {
+            // SplitTags -> NormalizeTag -> Length >= 2 -> !ShouldDropTag -> Distinct (Program.cs:598-602); the join and the second
+            // SplitTags (Program.cs:604, 578) return the same strings because no surviving tag holds ',' or white space.
+            uint32_t i = a;
+            for (;;) {
+                uint32_t j = i;
+                while (j < b && s[j] != ',') ++j;
+                H h;
+                if (make_token(t, ws, norm_used, s, i, j, false, h, unsupported)) {
+                    uint32_t f = hflags(t, h);
+                    if ((f & FL_LEN2) && !(f & FL_DROP) && !lfind(ws, ws.hnd, n, h)) {
+                        if (n >= ws.cap_t) { unsupported = true; }
+                        else ws.hnd[n++] = h;
+                    }
+                }
+                if (unsupported) break;
+                if (j >= b) break;
+                i = j + 1;
+            }
+        }
+        if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
+        // ParseTagCandidatesFromLine scores, Program.cs:581-583
+        for (uint32_t i = 0; i < n; ++i) {
+            double base = fmax(0.05, 1.0 - (double)(int)i * 0.01);
+            ws.score[i] = base * t.line_weight;
+            ws.order[i] = i;
+            ws.src[i] = (uint8_t)t.line_source;
+        }
+    } else {
+        // ---------------- scored ingest, shaped like ParseJoyTags (Program.cs:473-487) ----------------
+        uint32_t order = 0;
+        for (uint64_t k = in.tag_lo; k < in.tag_hi; ++k) {
+            const uint8_t* s = in.arena + in.tag_offsets[k];
+            uint32_t len = (uint32_t)(in.tag_offsets[k + 1] - in.tag_offsets[k]);
+            for (uint32_t p = 0; p < len; ++p) if (s[p] >= 0x80) unsupported = true;
+            if (unsupported) break;
+            H h;
+            bool nonempty = make_token(t, ws, norm_used, s, 0, len, true, h, unsupported);
+            if (unsupported) break;
+            if (!nonempty) h = t.alias1[EMPTY_ID];                // NormalizeTag("") still goes through the alias lookup
+            if (hflags(t, h) & FL_BLANK) continue;
+            if (n >= ws.cap_t) { unsupported = true; break; }
+            // insertion by (score descending, order ascending): OrderByDescending(Score).ThenBy(Order), Program.cs:487
+            double sc = in.scores[k];
+            uint32_t pos = n;
+            while (pos > 0 && ws.score[pos - 1] < sc) {
+                ws.hnd[pos] = ws.hnd[pos - 1]; ws.score[pos] = ws.score[pos - 1]; ws.order[pos] = ws.order[pos - 1]; ws.src[pos] = ws.src[pos - 1];
+                --pos;
+            }
+            ws.hnd[pos] = h; ws.score[pos] = sc; ws.order[pos] = order++; ws.src[pos] = in.sources[k];
+            ++n;
+        }
+        if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
+    }
+    v.n_candidates = (uint16_t)(n > 0xFFFF ? 0xFFFF : n);
+
+    // ---------------- DetermineStyleQualityCap (Program.cs:702-710) ----------------
+    int style_cap;
+    {
+        H strong[4];
+        int ns = 0;
+        for (uint32_t i = 0; i < n && ns < 4; ++i) {
+            H h = ws.hnd[i];
+            if (fl_bucket(hflags(t, h)) != B_STYLE || !(ws.score[i] >= 0.60)) continue;
+            bool seen = false;
+            for (int k = 0; k < ns; ++k) if (heq(ws, strong[k], h)) seen = true;
+            if (!seen) strong[ns++] = h;
+        }
+        style_cap = ns < 2 ? 2 : ns;                             // Clamp(n, 2, 4)
+    }
+
+    // ---------------- SelectTags, first half (Program.cs:625-655) + BuildEvidenceTags (Program.cs:721-729) ----------------
+    // Both walk the candidates in order applying NormalizeTag once, so they share the walk.  The unique list is compacted
+    // in place: entry nu is written only after candidate i >= nu has been read.
+    uint32_t nu = 0, ndl = 0, ne = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        H h2 = norm_hop(t, ws, ws.hnd[i]);
+        double sc = ws.score[i];
+        uint32_t od = ws.order[i];
+        uint32_t sr = ws.src[i];
+        uint32_t f2 = hflags(t, h2);
+        if (f2 & FL_BLANK) continue;
+        if (!(sc < 0.28) && mode == 0) {                          // evidence keeps invalid and dropped tags too
+            if (!lfind(ws, ws.ev, ne, h2)) {
+                if (ne >= ws.cap_e) overflow = true; else ws.ev[ne++] = h2;
+            }
+        }
+        if (!(f2 & FL_VALID) || (f2 & FL_DROP)) {                 // "{n}:invalid_tag" / "{n}:policy_drop", made distinct at Program.cs:682
+            if (!lfind(ws, ws.dl, ndl, h2)) ws.dl[ndl++] = h2;
+            continue;
+        }
+        uint32_t j = 0;
+        for (; j < nu; ++j) if (heq(ws, ws.hnd[j], h2)) break;
+        if (j == nu) {
+            ws.hnd[nu] = h2; ws.score[nu] = sc; ws.order[nu] = od; ws.src[nu] = (uint8_t)(sr | (fl_bucket(f2) << 4));
+            ++nu;
+            continue;
+        }
+        double osc = ws.score[j];
+        uint32_t osr = ws.src[j] & 0xF;
+        bool prefer_new = sc > osc;
+        if (fabs(sc - osc) <= 0.03) prefer_new = source_rank(sr) < source_rank(osr);
+        ws.score[j] = sc > osc ? sc : osc;                        // Math.Max
+        if (od < ws.order[j]) ws.order[j] = od;                   // Math.Min
+        ws.src[j] = (uint8_t)((prefer_new ? sr : osr) | (ws.src[j] & 0xF0));
+    }
+    v.n_dropped = (uint16_t)(ndl > 0xFFFF ? 0xFFFF : ndl);
+
+    // OrderByDescending(Score).ThenBy(SourceRank).ThenBy(Order), Program.cs:651-655.  Orders are distinct, so the key is total.
+    for (uint32_t k = 0; k < nu; ++k) {
+        double sc = ws.score[k];
+        int rk = source_rank(ws.src[k] & 0xF);
+        uint32_t od = ws.order[k];
+        uint32_t pos = k;
+        while (pos > 0) {
+            uint32_t q = ws.sorted[pos - 1];
+            double qs = ws.score[q];
+            int qr = source_rank(ws.src[q] & 0xF);
+            bool q_first = (qs > sc) || (qs == sc && (qr < rk || (qr == rk && ws.order[q] < od)));
+            if (q_first) break;
+            ws.sorted[pos] = q;
+            --pos;
+        }
+        ws.sorted[pos] = k;
+    }
+
+    // ---------------- SelectTags, second half (Program.cs:661-699) ----------------
+    uint32_t nr = 0;   // result list, built in ws.fin
+    auto add_one = [&](H tag) -> bool {                           // AddOne, Program.cs:692-699
+        H nn = norm_hop(t, ws, tag);
+        uint32_t f = hflags(t, nn);
+        if ((f & FL_BLANK) || nr >= (uint32_t)MAX_TOTAL_TAGS) return false;
+        if (!(f & FL_VALID)) return false;
+        if ((f & FL_DROP) || lfind(ws, ws.fin, nr, nn)) return false;
+        ws.fin[nr++] = nn;
+        return true;
+    };
+    // AddOne normalises its argument; trigger_id / girl_add_id / always_ids already are those normalised forms, so they
+    // are added through the tail of AddOne only.
+    auto add_normalised = [&](uint32_t id) {
+        uint32_t f = t.flags[id];
+        if ((f & FL_BLANK) || nr >= (uint32_t)MAX_TOTAL_TAGS) return;
+        if (!(f & FL_VALID)) return;
+        if ((f & FL_DROP) || lfind(ws, ws.fin, nr, (H)id)) return;
+        ws.fin[nr++] = (H)id;
+    };
+    add_normalised(t.trigger_id);
+    add_normalised(t.girl_add_id);
+    for (uint32_t k = 0; k < t.n_always; ++k) add_normalised(t.always_ids[k]);
+    {
+        const int caps[6] = {3, 10, 8, 6, 4, style_cap};          // Program.cs:609-616
+        for (uint32_t bkt = 0; bkt < 6; ++bkt) {                  // FillBucket, Program.cs:684-690
+            int used = 0;
+            for (uint32_t k = 0; k < nu; ++k) {
+                uint32_t q = ws.sorted[k];
+                if ((uint32_t)(ws.src[q] >> 4) != bkt) continue;
+                if (nr >= (uint32_t)MAX_TOTAL_TAGS || used >= caps[bkt]) break;
+                if (add_one(ws.hnd[q])) ++used;
+            }
+        }
+        for (uint32_t k = 0; k < nu; ++k) {                       // final sweep, Program.cs:677-680
+            if (nr >= (uint32_t)MAX_TOTAL_TAGS) break;
+            add_one(ws.hnd[ws.sorted[k]]);
+        }
+    }
+    v.n_selected = (uint16_t)nr;
+    if (mode == 1) { out.n_final = nr; return; }
+
+    // ---------------- EvaluateCoverage (Program.cs:1056-1095) and normalizedFinalSet (Program.cs:303) ----------------
+    // Both start from Select(NormalizeTag).Where(non-blank).Distinct() of the selected tags: computed once, in place.
+    uint32_t nf = 0;
+    for (uint32_t i = 0; i < nr; ++i) {
+        H h4 = norm_hop(t, ws, ws.fin[i]);
+        if (hflags(t, h4) & FL_BLANK) continue;
+        if (lfind(ws, ws.fin, nf, h4)) continue;
+        ws.fin[nf++] = h4;
+    }
+    {
+        bool has_trigger = false, has_girl = false, hair = false, eyes = false, outfit = false, pose = false, bg = false;
+        for (uint32_t i = 0; i < nf; ++i) {
+            H h = ws.fin[i];
+            uint32_t f = hflags(t, h);
+            if (h == (H)t.trigger_id) has_trigger = true;
+            if (h == (H)t.girl_lit_id) has_girl = true;
+            hair |= (f & FL_HAIR) != 0;
+            eyes |= (f & FL_EYES) != 0;
+            uint32_t bk = fl_bucket(f);
+            outfit |= bk == B_OUTFIT;
+            pose |= bk == B_POSE;
+            bg |= bk == B_BACKGROUND;
+        }
+        v.coverage = (uint8_t)(((has_trigger && has_girl) ? TP_COV_IDENTITY : 0) | (hair ? TP_COV_HAIR : 0) | (eyes ? TP_COV_EYES : 0) |
+                               (outfit ? TP_COV_OUTFIT : 0) | (pose ? TP_COV_POSE_ACTION : 0) | (bg ? TP_COV_BACKGROUND : 0));
+    }
+    uint32_t flags = rejected ? TP_F_LINE_REJECTED : 0;
+    if (nr < 3) {                                                 // Program.cs:297-298
+        flags |= TP_F_FALLBACK;
+        nf = 0;
+        for (uint32_t i = 0; i < t.n_fallback; ++i) {
+            H h4 = t.next[t.fallback_ids[i]];
+            if (t.flags[h_id(h4)] & FL_BLANK) continue;
+            if (lfind(ws, ws.fin, nf, h4)) continue;
+            ws.fin[nf++] = h4;
+        }
+    }
+
+    // ---------------- evidence closure (Program.cs:301-302) ----------------
+    expand_implied(t, ws, ws.ev, ne, ws.cap_e, overflow);
+    v.n_evidence = (uint16_t)(ne > 0xFFFF ? 0xFFFF : ne);
+    for (uint32_t w = 0; w < t.lit_words; ++w) ws.ebits[w] = 0;
+    bool ev_feet = false, ev_penis = false;
+    for (uint32_t i = 0; i < ne; ++i) {
+        H e = ws.ev[i];
+        if (!h_is_dyn(e)) {
+            uint32_t id = h_id(e);
+            uint32_t li = t.lit[id];
+            if (li != NO_ID) ws.ebits[li >> 5] |= 1u << (li & 31);
+            uint32_t f = t.flags[id];
+            ev_feet |= (f & FL_NFEET) != 0;                       // HasTag(evidenceTags, "feet"), Program.cs:309, 719
+            ev_penis |= (f & FL_NPENIS) != 0;
+        } else if (e & H_UNSTABLE) {
+            H ne2 = norm_hop(t, ws, e);
+            ev_feet |= ne2 == (H)t.feet_n;
+            ev_penis |= ne2 == (H)t.penis_n;
+        }
+    }
+
+    // ---------------- final set closure (Program.cs:304-305) ----------------
+    expand_implied(t, ws, ws.fin, nf, ws.cap_f, overflow);
+
+    // ---------------- InferActionTags (Program.cs:731-753) ----------------
+    {
+        uint32_t ni = 0;
+        for (uint32_t i = 0; i < nf; ++i) {                       // Select(NormalizeTag).Where(non-blank).Distinct()
+            H h5 = norm_hop(t, ws, ws.fin[i]);
+            if (hflags(t, h5) & FL_BLANK) continue;
+            if (lfind(ws, ws.fin, ni, h5)) continue;
+            ws.fin[ni++] = h5;
+        }
+        nf = ni;
+        for (uint32_t r = 0; r < t.n_rules; ++r) {
+            const DRule& rule = t.rules[r];
+            // MatchesActionRule, Program.cs:777-782
+            if (rule.all_cnt && !all_set(t, ws, rule.all_off, rule.all_cnt)) continue;
+            if (rule.any_cnt && !any_set(t, ws, rule.any_off, rule.any_cnt)) continue;
+            if (any_set(t, ws, rule.forb_off, rule.forb_cnt)) continue;
+            if (!lfind(ws, ws.fin, nf, (H)rule.parent_id)) { if (nf >= ws.cap_f) overflow = true; else ws.fin[nf++] = rule.parent_id; }
+            if (fired) fired[r >> 5] |= 1u << (r & 31);
+            for (uint32_t sidx = rule.sub_off; sidx < rule.sub_off + rule.sub_cnt; ++sidx) {
+                const DSub& st = t.subs[sidx];
+                if (!match_any_all(t, ws, st)) continue;
+                if (!lfind(ws, ws.fin, nf, (H)st.tag_id)) { if (nf >= ws.cap_f) overflow = true; else ws.fin[nf++] = st.tag_id; }
+                uint32_t bit = t.n_rules + sidx;
+                if (fired) fired[bit >> 5] |= 1u << (bit & 31);
+            }
+        }
+    }
+    // ---------------- EnsureRequiredFacets (Program.cs:755-775) ----------------
+    for (uint32_t f = 0; f < t.n_facets; ++f) {
+        const DFacet& facet = t.facets[f];
+        uint32_t selected = facet.def_id;
+        for (uint32_t r = 0; r < facet.rule_cnt; ++r) {
+            const DSub& fr = t.facet_rules[facet.rule_off + r];
+            if (!match_any_all(t, ws, fr)) continue;
+            selected = fr.tag_id;
+            if (facet_choice) facet_choice[f] = (uint16_t)r;
+            break;
+        }
+        if (!lfind(ws, ws.fin, nf, (H)selected)) { if (nf >= ws.cap_f) overflow = true; else ws.fin[nf++] = selected; }
+    }
+
+    // ---------------- verdicts on the final list (Program.cs:319, 329) ----------------
+    {
+        bool face = false, outfit = false;
+        int safe = -1;
+        for (uint32_t i = 0; i < nf; ++i) {
+            uint32_t f = hflags(t, ws.fin[i]);
+            uint32_t bk = fl_bucket(f);
+            face |= bk == B_FACE;                                 // MissingCoreBuckets, Program.cs:1097-1101
+            outfit |= bk == B_OUTFIT;
+            if (safe < 0 && !h_is_dyn(ws.fin[i]) && (f & FL_SAFE)) safe = (int)((f >> FL_SAFE_IDX_SHIFT) & 31);   // DetectSafeModeRejectReason, Program.cs:942-945
+        }
+        if (!face || !outfit) flags |= TP_F_LOW;
+        if (t.safe_mode && safe >= 0) { flags |= TP_F_SAFE_REJECT; v.safe_hit = (int16_t)safe; }
+    }
+
+    // ---------------- FormatCaptionSingleLine (Program.cs:971-974) and GetUnknownTags (Program.cs:817-824) ----------------
+    // Both take Select(NormalizeTag).Where(non-blank).Distinct() of the final list.
+    uint32_t nc = 0, bytes = 0, unknown = 0;
+    bool footjob = false;
+    for (uint32_t i = 0; i < nf; ++i) {
+        H h6 = norm_hop(t, ws, ws.fin[i]);
+        uint32_t f = hflags(t, h6);
+        if (f & FL_BLANK) continue;
+        if (lfind(ws, ws.fin, nc, h6)) continue;
+        ws.fin[nc++] = h6;
+        bytes += hbytes(t, h6);
+        if (t.known_active && (h_is_dyn(h6) || !(f & FL_KNOWN))) ++unknown;
+        if (h6 == (H)t.footjob_n) footjob = true;                 // HasTag(finalTags, "footjob"), Program.cs:311
+    }
+    if (overflow) { v.flags = TP_F_UNSUPPORTED; out.n_final = 0; out.caption_len = 0; return; }
+    if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (footjob) flags |= TP_F_FOOTJOB; }
+    v.flags = (uint8_t)flags;
+    v.n_tags = (uint16_t)(nc > 0xFFFF ? 0xFFFF : nc);
+    v.n_unknown = (uint16_t)(unknown > 0xFFFF ? 0xFFFF : unknown);
+    out.n_final = nc;
+    out.caption_len = bytes + (nc ? 2 * (nc - 1) : 0) + t.newline_len;    // string.Join(", ", …) + Environment.NewLine, Program.cs:316-317
+}
+
+}  // namespace tp

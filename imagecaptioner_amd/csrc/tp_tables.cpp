@@ -1,0 +1,974 @@
+// Host-side table compiler (see tp_tables.hpp).
+//
+// Loader semantics follow Program.cs line by line, including the load-order
+// quirk: allow/deny lists, the vocabulary and the profile are normalised with
+// the BUILT-IN default lexicon (Program.cs:159-161 run before :163), while the
+// per-string attributes the kernels read are computed with the final one.
+#include "tp_tables.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "tp_json.hpp"
+
+namespace tp {
+namespace {
+
+typedef std::u16string W;
+typedef char16_t wc;
+
+#include "tp_case_tables.inc"
+
+wc case_map(const uint32_t* tab, size_t n, wc c) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        uint32_t key = tab[mid] >> 16;
+        if (key == c) return (wc)(tab[mid] & 0xFFFF);
+        if (key < c) lo = mid + 1; else hi = mid;
+    }
+    return c;
+}
+wc lower_invariant(wc c) {   // char.ToLowerInvariant
+    if (c < 0x80) return (c >= 'A' && c <= 'Z') ? (wc)(c | 0x20) : c;
+    return case_map(kCaseLower, sizeof kCaseLower / sizeof kCaseLower[0], c);
+}
+wc upper_ordinal(wc c) {     // the folding StringComparer.OrdinalIgnoreCase compares with
+    if (c < 0x80) return (c >= 'a' && c <= 'z') ? (wc)(c & ~0x20) : c;
+    return case_map(kCaseUpper, sizeof kCaseUpper / sizeof kCaseUpper[0], c);
+}
+bool is_space(wc c) {        // char.IsWhiteSpace (also what \s matches)
+    switch (c) {
+        case 0x20: case 0x85: case 0xA0: case 0x1680: case 0x2028: case 0x2029: case 0x202F: case 0x205F: case 0x3000: return true;
+        default: return (c >= 0x09 && c <= 0x0D) || (c >= 0x2000 && c <= 0x200A);
+    }
+}
+W lowered(W s) { for (auto& c : s) c = lower_invariant(c); return s; }
+W folded(W s) { for (auto& c : s) c = upper_ordinal(c); return s; }
+bool blank(const W& s) { return std::all_of(s.begin(), s.end(), is_space); }
+W trimmed(const W& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && is_space(s[a])) ++a;
+    while (b > a && is_space(s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+W widen(const char* ascii) { W w; while (*ascii) w.push_back((wc)(unsigned char)*ascii++); return w; }
+
+W from_utf8(const uint8_t* p, size_t n) {
+    W out;
+    for (size_t i = 0; i < n;) {
+        uint32_t b = p[i];
+        if (b < 0x80) { out.push_back((wc)b); ++i; continue; }
+        int extra = (b >= 0xF0 && b <= 0xF4) ? 3 : (b >= 0xE0) ? 2 : (b >= 0xC2) ? 1 : -1;
+        uint32_t cp = 0;
+        bool good = extra > 0 && i + extra < n;
+        if (good) {
+            cp = extra == 1 ? (b & 0x1F) : extra == 2 ? (b & 0x0F) : (b & 0x07);
+            for (int k = 1; k <= extra && good; ++k) {
+                if ((p[i + k] & 0xC0) != 0x80) good = false; else cp = (cp << 6) | (p[i + k] & 0x3F);
+            }
+            if (good && ((extra == 2 && cp < 0x800) || (extra == 3 && (cp < 0x10000 || cp > 0x10FFFF)) || (cp >= 0xD800 && cp <= 0xDFFF))) good = false;
+        }
+        if (!good) { out.push_back(0xFFFD); ++i; continue; }
+        if (cp >= 0x10000) { cp -= 0x10000; out.push_back((wc)(0xD800 | (cp >> 10))); out.push_back((wc)(0xDC00 | (cp & 0x3FF))); }
+        else out.push_back((wc)cp);
+        i += extra + 1;
+    }
+    return out;
+}
+std::string to_utf8(const W& s) {
+    std::string o;
+    for (size_t i = 0; i < s.size(); ++i) {
+        uint32_t cp = s[i];
+        if (cp >= 0xD800 && cp < 0xDC00 && i + 1 < s.size() && s[i + 1] >= 0xDC00 && s[i + 1] < 0xE000) { cp = 0x10000 + ((cp - 0xD800) << 10) + (s[i + 1] - 0xDC00); ++i; }
+        else if (cp >= 0xD800 && cp < 0xE000) cp = 0xFFFD;
+        if (cp < 0x80) o += (char)cp;
+        else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+        else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+        else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    }
+    return o;
+}
+
+// Case-insensitive containers keyed by the ordinal folding.
+struct FoldSet {
+    std::unordered_set<W> keys;
+    std::vector<W> order;
+    bool insert(const W& s) { if (!keys.insert(folded(s)).second) return false; order.push_back(s); return true; }
+    bool contains(const W& s) const { return keys.count(folded(s)) != 0; }
+    size_t size() const { return order.size(); }
+};
+template <class V>
+struct FoldMap {
+    std::unordered_map<W, std::pair<W, V>> m;   // folded key -> (key as first inserted, value); `d[k] = v` keeps the first key
+    void put(const W& k, const V& v) {
+        auto it = m.find(folded(k));
+        if (it == m.end()) m.emplace(folded(k), std::make_pair(k, v)); else it->second.second = v;
+    }
+    const V* get(const W& k) const { auto it = m.find(folded(k)); return it == m.end() ? nullptr : &it->second.second; }
+};
+std::vector<W> unique_fold(const std::vector<W>& v) { FoldSet s; for (auto& x : v) s.insert(x); return s.order; }
+
+// ---- NormalizeTagBasic, Program.cs:1267-1273 --------------------------------------------------------
+W normalize_basic(const W& raw) {
+    W t = trimmed(raw);
+    size_t a = 0, b = t.size();
+    auto quote = [](wc c) { return c == '"' || c == '\'' || c == '`'; };
+    while (a < b && quote(t[a])) ++a;
+    while (b > a && quote(t[b - 1])) --b;
+    auto punct = [](wc c) { return c == ';' || c == '.' || c == 0x3002 || c == 0x3001; };
+    if (b > a && t[b - 1] == '\n') {          // `$` also matches before a final '\n': that run goes, the '\n' stays
+        size_t q = b - 1;
+        while (q > a && punct(t[q - 1])) --q;
+        t = t.substr(a, q - a) + W(1, (wc)'\n');
+    } else {
+        while (b > a && punct(t[b - 1])) --b;
+        t = t.substr(a, b - a);
+    }
+    W out;
+    for (wc c : t) {
+        wc e = is_space(c) ? (wc)'_' : c;
+        if (e == '_' && !out.empty() && out.back() == '_') continue;
+        out.push_back(e);
+    }
+    return lowered(out);
+}
+
+struct ActionSub { W tag; std::vector<W> any, all; };
+struct Action { W parent; std::vector<W> all, any, forb; std::vector<ActionSub> subs; };
+struct FacetR { W tag; std::vector<W> any, all; };
+struct FacetDef { W name, def; std::vector<FacetR> rules; };
+
+bool read_source(const tp_source& src, std::vector<uint8_t>& out) {
+    out.clear();
+    if (src.data) { out.assign(src.data, src.data + src.len); return true; }
+    if (!src.path || !src.path[0]) return false;
+    std::ifstream f(src.path, std::ios::binary);
+    if (!f.good()) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return true;
+}
+W text_of(const std::vector<uint8_t>& b) {
+    size_t skip = (b.size() >= 3 && b[0] == 0xEF && b[1] == 0xBB && b[2] == 0xBF) ? 3 : 0;
+    return from_utf8(b.data() + skip, b.size() - skip);
+}
+std::vector<W> lines_of(const W& text) {     // File.ReadLines: "\n", "\r" and "\r\n" end a line
+    std::vector<W> out;
+    W cur;
+    bool open = false;
+    for (size_t i = 0; i < text.size(); ++i) {
+        wc c = text[i];
+        if (c == '\n' || c == '\r') {
+            if (c == '\r' && i + 1 < text.size() && text[i + 1] == '\n') ++i;
+            out.push_back(cur);
+            cur.clear();
+            open = false;
+        } else { cur.push_back(c); open = true; }
+    }
+    if (open) out.push_back(cur);
+    return out;
+}
+std::vector<W> split_tags(const W& s) {       // SplitTags, Program.cs:1181-1187
+    std::vector<W> out;
+    if (blank(s)) return out;
+    size_t start = 0;
+    while (true) {
+        size_t comma = s.find((wc)',', start);
+        W part = trimmed(s.substr(start, comma == W::npos ? W::npos : comma - start));
+        if (!part.empty() && !blank(part)) out.push_back(part);
+        if (comma == W::npos) break;
+        start = comma + 1;
+    }
+    return out;
+}
+
+const char* const kSafeList[20] = {"nsfw", "nude", "naked", "nipples", "breasts", "pussy", "cameltoe", "sex", "penis", "cum", "orgasm", "masturbation",
+                                   "fellatio", "anal", "vaginal", "hentai", "explicit", "porn", "bdsm", "futanari"};   // Program.cs:43-45
+
+struct ClassLits { uint32_t bit; const char* alts; };
+const ClassLits kClassLits[] = {
+    {CM_FACE, "hair|eyes|eyebrows|eyelashes|pupil|bangs|twintails|ponytail|braid|ahoge|blush|smile|frown|angry|surprised|open_mouth|closed_mouth|tears|looking_"},   // Program.cs:48
+    {CM_OUTFIT, "dress|skirt|shirt|jacket|coat|hoodie|sweater|uniform|kimono|swimsuit|socks|stockings|pantyhose|shoes|boots|gloves|hat|ribbon|bow|tie|neckwear|blazer|pants|shorts"},   // :49
+    {CM_POSE, "pose|standing|sitting|lying|kneeling|crouching|walking|running|jumping|leaning|holding|raising|arms|hands|fingers|looking_at_viewer|looking_away|from_side|from_behind"},   // :50
+    {CM_BACKGROUND, "indoors|outdoors|room|bedroom|street|city|school|classroom|park|forest|beach|sky|night|sunset|window|bed|chair|office|kitchen|bathroom"},   // :51
+    {CM_STYLE, "lighting|backlighting|rim_light|soft_light|hard_light|shadow|bloom|depth_of_field|bokeh|monochrome|highres|absurdres|masterpiece|best_quality|high_quality|detailed"},   // :52
+    {CM_HAIR, "hair|bangs|twintails|ponytail|braid|ahoge"},   // :53
+    {CM_EYES, "eyes|eyelashes|eyebrows|pupil|heterochromia"},   // :54
+    {CM_SORRY, "sorry"},   // :57
+    {CM_WATERMARK, "watermark"},   // :1130
+};
+
+// Aho-Corasick automaton over the class literals, as a dense goto table.
+void build_dfa(std::vector<uint16_t>& next, std::vector<uint16_t>& outm) {
+    std::vector<std::vector<int>> go(1, std::vector<int>(DFA_SYMS, -1));
+    std::vector<uint32_t> out(1, 0);
+    for (const ClassLits& cl : kClassLits) {
+        const char* p = cl.alts;
+        int st = 0;
+        for (;; ++p) {
+            if (*p == '|' || *p == 0) {
+                out[st] |= cl.bit;
+                st = 0;
+                if (!*p) break;
+                continue;
+            }
+            uint32_t sy = dfa_sym((uint8_t)*p);
+            if (go[st][sy] < 0) { go[st][sy] = (int)go.size(); go.emplace_back(DFA_SYMS, -1); out.push_back(0); }
+            st = go[st][sy];
+        }
+    }
+    size_t ns = go.size();
+    if (ns > 65535) throw ConfigError("classifier automaton too large");
+    std::vector<int> fail(ns, 0), queue;
+    for (int sy = 0; sy < DFA_SYMS; ++sy) {
+        if (go[0][sy] < 0) go[0][sy] = 0; else { fail[go[0][sy]] = 0; queue.push_back(go[0][sy]); }
+    }
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        int s = queue[qi];
+        out[s] |= out[fail[s]];
+        for (int sy = 0; sy < DFA_SYMS; ++sy) {
+            int nx = go[s][sy];
+            if (nx < 0) go[s][sy] = go[fail[s]][sy];
+            else { fail[nx] = go[fail[s]][sy]; queue.push_back(nx); }
+        }
+    }
+    next.resize(ns * DFA_SYMS);
+    outm.resize(ns);
+    for (size_t s = 0; s < ns; ++s) {
+        outm[s] = (uint16_t)out[s];
+        for (int sy = 0; sy < DFA_SYMS; ++sy) next[s * DFA_SYMS + sy] = (uint16_t)go[s][sy];
+    }
+}
+uint32_t class_mask(const std::vector<uint16_t>& next, const std::vector<uint16_t>& outm, const W& lower_text) {
+    uint32_t st = 0, mask = 0;
+    for (wc c : lower_text) {
+        uint32_t sy = c < 0x80 ? dfa_sym((uint8_t)c) : 27u;
+        st = next[st * DFA_SYMS + sy];
+        mask |= outm[st];
+    }
+    return mask;
+}
+
+// The loaded state of Program (its static fields), built in Main's order.
+struct Loader {
+    std::vector<uint16_t> dfa_next, dfa_out;
+    FoldSet subject, banned, builtin_deny, action_tags, safe_reject, allow, deny, known, force_allow;
+    FoldMap<W> builtin_aliases;              // ActionTagAliases, Program.cs:71-78
+    FoldMap<W> aliases;                      // ActiveLexicon.Aliases
+    FoldMap<std::vector<W>> implied;         // ActiveLexicon.Implied
+    std::vector<Action> actions;
+    std::vector<FacetDef> facets;
+    bool known_found = false, strict = false, strict_explicit = false;
+    bool has_profile = false;
+    std::vector<W> always_add;
+    W trigger;
+
+    Loader() {
+        build_dfa(dfa_next, dfa_out);
+        for (auto s : {"1girl", "1boy", "solo", "multiple_girls", "multiple_boys", "2girls", "2boys", "girl", "boy"}) subject.insert(widen(s));       // :27-29
+        for (auto s : {"1boy", "boy", "multiple_boys", "2boys", "3boys", "4boys", "male_focus", "yaoi", "male"}) banned.insert(widen(s));          // :33-35
+        for (auto s : {"watermark", "signature", "text", "logo", "jpeg_artifacts", "lowres", "worst_quality", "rating", "artist_name"}) builtin_deny.insert(widen(s));   // :60-62
+        for (auto s : {"footjob", "penis_between_feet", "foot_on_penis", "foot_sole_stimulation", "trampling_penis", "handjob", "penis_in_hand", "hand_wrapping_penis",
+                       "squeezing_penis", "sex", "vaginal_penetration", "missionary", "doggystyle", "cowgirl_position", "blowjob", "penis_in_mouth", "fellatio"})
+            action_tags.insert(widen(s));                                                                                                              // :64-69
+        for (auto s : kSafeList) safe_reject.insert(widen(s));
+        builtin_aliases.put(widen("pedal_stimulation"), widen("footjob"));
+        builtin_aliases.put(widen("feet_stimulation"), widen("footjob"));
+        builtin_aliases.put(widen("foot_stimulation"), widen("footjob"));
+        builtin_aliases.put(widen("sexual_intercourse"), widen("sex"));
+        builtin_aliases.put(widen("paizuri_sex"), widen("sex"));
+        builtin_aliases.put(widen("fellatio"), widen("blowjob"));
+        default_lexicon();
+        actions = builtin_actions();
+    }
+
+    // BuildDefaultLexicon, Program.cs:1228-1253
+    void default_lexicon() {
+        aliases = FoldMap<W>();
+        implied = FoldMap<std::vector<W>>();
+        for (auto& kv : builtin_aliases.m) aliases.put(normalize_basic(kv.second.first), normalize_basic(kv.second.second));
+        const char* al[][2] = {{"sole", "foot_sole"}, {"soles", "foot_sole"}, {"foot", "feet"}, {"hands", "hand"}, {"fingers", "hand"}, {"licking", "oral"}};
+        for (auto& p : al) aliases.put(widen(p[0]), widen(p[1]));
+        auto imp = [&](const char* k, std::initializer_list<const char*> v) { std::vector<W> l; for (auto s : v) l.push_back(widen(s)); implied.put(widen(k), l); };
+        imp("barefoot", {"feet"}); imp("foot", {"feet"}); imp("toes", {"feet"}); imp("sole", {"feet"}); imp("soles", {"feet"}); imp("foot_sole", {"feet"});
+        imp("hands", {"hand"}); imp("fingers", {"hand"}); imp("oral", {"mouth"}); imp("licking", {"oral", "mouth"});
+    }
+    // ActionInferenceRules, Program.cs:80-126
+    static std::vector<Action> builtin_actions() {
+        auto L = [](std::initializer_list<const char*> v) { std::vector<W> l; for (auto s : v) l.push_back(widen(s)); return l; };
+        auto S = [&](const char* tag, std::initializer_list<const char*> any) { return ActionSub{widen(tag), L(any), {}}; };
+        return {
+            Action{widen("footjob"), L({"feet", "penis"}), {}, {},
+                   {S("penis_between_feet", {"between_feet", "between", "sandwiched", "foot_sandwich"}), S("foot_on_penis", {"foot_on_penis", "footjob", "foot_press", "foot_pressing"}),
+                    S("foot_sole_stimulation", {"sole", "foot_sole", "sole_focus", "underside"}), S("trampling_penis", {"stepping", "trampling", "step_on", "weight_on_penis"})}},
+            Action{widen("handjob"), L({"penis", "hand"}), {}, L({"vaginal_penetration", "anal_penetration", "vaginal", "anal", "insertion", "penetration"}),
+                   {S("penis_in_hand", {"penis_in_hand", "holding_penis", "holding"}), S("hand_wrapping_penis", {"grip", "gripping", "hand_wrapping_penis", "wrapped_hand"}),
+                    S("squeezing_penis", {"squeezing", "stroking", "jerking", "pumping_motion"})}},
+            Action{widen("sex"), L({"penis"}), L({"vagina", "vaginal", "vaginal_penetration", "insertion", "penetration", "intercourse"}), {},
+                   {S("vaginal_penetration", {"vaginal_penetration", "vaginal", "penis_in_vagina", "insertion", "penetration"}), S("missionary", {"missionary", "missionary_position", "face_to_face"}),
+                    S("doggystyle", {"doggystyle", "doggy_style", "from_behind", "rear_entry"}), S("cowgirl_position", {"cowgirl", "cowgirl_position", "female_on_top"})}},
+            Action{widen("blowjob"), L({"penis"}), L({"mouth", "oral", "fellatio", "sucking"}), {},
+                   {S("penis_in_mouth", {"penis_in_mouth", "deepthroat", "mouth_penetration"}), S("fellatio", {"fellatio", "oral", "oral_sex"})}},
+        };
+    }
+    // BuildDefaultRequiredFacets, Program.cs:1255-1265
+    static std::vector<FacetDef> builtin_facets() {
+        auto L = [](std::initializer_list<const char*> v) { std::vector<W> l; for (auto s : v) l.push_back(widen(s)); return l; };
+        auto R = [&](const char* tag, std::initializer_list<const char*> any) { return FacetR{widen(tag), L(any), {}}; };
+        return {
+            FacetDef{widen("viewpoint"), widen("unknown_pov"), {R("male_pov", {"male_pov", "pov_male", "from_male_pov"}), R("third_person", {"third_person", "third_person_view"})}},
+            FacetDef{widen("gaze"), widen("unknown_gaze"), {R("looking_at_camera", {"looking_at_viewer", "looking_at_camera"}), R("looking_at_partner", {"looking_at_male", "looking_at_partner"}), R("looking_at_object", {"looking_at_penis", "looking_at_object"})}},
+            FacetDef{widen("underwear"), widen("unknown_underwear"), {R("panties_aside", {"panties_aside"}), R("panties_off", {"panties_off", "no_panties"}), R("panties_on", {"panties_on", "wearing_panties"})}},
+            FacetDef{widen("fluids"), widen("unknown_fluids"), {R("semen_present", {"semen", "cum"}), R("precum_present", {"pre_ejaculate", "precum"}), R("no_fluids", {"no_fluids"})}},
+            FacetDef{widen("ejaculation"), widen("unknown_ejaculation"), {R("ejaculation", {"ejaculation", "cumshot"}), R("no_ejaculation", {"no_ejaculation"})}},
+            FacetDef{widen("expression"), widen("unknown_expression"), {R("ahegao", {"ahegao"}), R("smile", {"smile", "smiling"}), R("neutral", {"neutral_expression"})}},
+            FacetDef{widen("mouth_shape"), widen("unknown_mouth"), {R("tongue_out", {"tongue_out"}), R("mouth_open", {"open_mouth"}), R("mouth_closed", {"closed_mouth"})}},
+        };
+    }
+
+    // the alias lookups of NormalizeTag, Program.cs:1155-1156
+    W alias_of(const W& t) const {
+        if (const W* v = aliases.get(t)) return *v;
+        if (const W* v = builtin_aliases.get(t)) return *v;
+        return t;
+    }
+    W normalize(const W& raw) const { return alias_of(normalize_basic(raw)); }   // NormalizeTag, Program.cs:1149-1158
+
+    static bool valid_tag(const W& s) {                                           // IsValidTag, Program.cs:1135-1139
+        if (blank(s) || s[0] == ':') return false;
+        size_t n = s.size();
+        if (s[n - 1] == '\n') --n;                                                // `$` accepts a final '\n'
+        if (n == 0) return false;
+        for (size_t i = 0; i < n; ++i) {
+            wc c = s[i];
+            if (c >= 0x80) return false;
+            if (!(i == 0 ? is_tag_first8((uint8_t)c) : is_tag_rest8((uint8_t)c))) return false;
+        }
+        return true;
+    }
+    static bool has(const W& s, const char* needle) { return s.find(widen(needle)) != W::npos; }
+    bool should_drop(const W& t) const {                                          // ShouldDropTag, Program.cs:1121-1133
+        W lower = lowered(t);
+        if (force_allow.contains(lower)) return false;
+        if (!valid_tag(lower)) return true;
+        for (auto s : {"negative:", "positive:", "sorry", "i can't", "i cannot", "cannot provide", "unable to", "as an ai", "i'm not able", "i won't"})
+            if (has(lower, s)) return true;
+        { W w = widen("i won"); w.push_back(0x2019); w.push_back('t'); if (lower.find(w) != W::npos) return true; }
+        if (lower.compare(0, 7, widen("rating:")) == 0) return true;
+        if (builtin_deny.contains(lower) || banned.contains(lower) || deny.contains(lower)) return true;
+        if (allow.size() > 0 && !allow.contains(lower) && (lower.compare(0, 6, widen("rating")) == 0 || has(lower, "watermark"))) return true;
+        if (known_found && strict && !known.contains(lower)) return true;
+        return false;
+    }
+    bool name_like(const W& s) const {                                            // CharacterNameRegex, Program.cs:47
+        size_t n = s.size();
+        if (n && s[n - 1] == '\n') --n;
+        int segs = 0;
+        size_t run = 0;
+        for (size_t i = 0; i < n; ++i) {
+            wc c = s[i];
+            bool alnum = (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9');
+            if (alnum) { if (run == 0) ++segs; ++run; }
+            else if (c == '_') { if (run == 0) return false; run = 0; }
+            else return false;
+        }
+        return run > 0 && segs >= 2 && segs <= 4;
+    }
+    uint32_t bucket_of(const W& s, uint32_t mask) const {                         // ClassifyTag + IsLikelyCharacterName, Program.cs:1103-1119
+        bool any5 = mask & (CM_FACE | CM_OUTFIT | CM_POSE | CM_BACKGROUND | CM_STYLE);
+        if (subject.contains(s) || (name_like(s) && !any5)) return B_IDENTITY;
+        if (mask & CM_FACE) return B_FACE;
+        if (mask & CM_OUTFIT) return B_OUTFIT;
+        if ((mask & CM_POSE) || action_tags.contains(s)) return B_POSE;
+        if (mask & CM_BACKGROUND) return B_BACKGROUND;
+        if (mask & CM_STYLE) return B_STYLE;
+        return B_OTHER;
+    }
+
+    // LoadTagFile, Program.cs:1429-1439
+    FoldSet load_tag_file(const tp_source& src) const {
+        FoldSet set;
+        std::vector<uint8_t> bytes;
+        if (!read_source(src, bytes)) return set;
+        for (auto& line : lines_of(text_of(bytes))) {
+            W t = trimmed(line);
+            if (blank(t) || t[0] == '#') continue;
+            set.insert(normalize(t));
+        }
+        return set;
+    }
+    // ExtractKnownTagsFromJson, Program.cs:1036-1053
+    void known_from_json(const JDoc& d, int32_t n, FoldSet& tags) const {
+        switch (d.kind(n)) {
+            case JKind::String: { W t = normalize(d.str(n)); if (!blank(t)) tags.insert(t); break; }
+            case JKind::Array: for (int32_t c = d.nodes[n].first; c >= 0; c = d.nodes[c].next) known_from_json(d, c, tags); break;
+            case JKind::Object:
+                for (int32_t c = d.nodes[n].first; c >= 0; c = d.nodes[c].next) {
+                    known_from_json(d, c, tags);
+                    W t = normalize(d.member_name(c));
+                    if (!blank(t)) tags.insert(t);
+                }
+                break;
+            default: break;
+        }
+    }
+    // LoadKnownTagDictionary + TryLoadKnownTagsFromFile, Program.cs:983-1034
+    void load_vocabulary(const tp_config& cfg) {
+        known = FoldSet();
+        known_found = false;
+        std::vector<uint8_t> bytes;
+        if (read_source(cfg.vocabulary, bytes)) {
+            bool json = cfg.vocabulary_is_json == 1;
+            if (cfg.vocabulary_is_json < 0 && cfg.vocabulary.path) {
+                std::string p = cfg.vocabulary.path;
+                size_t dot = p.rfind('.');
+                std::string ext = dot == std::string::npos ? std::string() : p.substr(dot);
+                std::transform(ext.begin(), ext.end(), ext.begin(), [](unsigned char ch) { return (char)std::tolower(ch); });
+                json = ext == ".json";
+            }
+            FoldSet loaded;
+            bool ok = true;
+            try {
+                if (json) {
+                    JDoc d = JDoc::parse(bytes.data(), bytes.size());
+                    known_from_json(d, d.root, loaded);
+                } else {
+                    for (auto& line : lines_of(text_of(bytes))) {
+                        W cleaned = trimmed(line);
+                        if (blank(cleaned)) continue;
+                        size_t start = 0;
+                        while (true) {
+                            size_t cut = cleaned.find_first_of(u",;", start);
+                            W piece = trimmed(cleaned.substr(start, cut == W::npos ? W::npos : cut - start));
+                            if (!piece.empty()) { W t = normalize(piece); if (!blank(t)) loaded.insert(t); }
+                            if (cut == W::npos) break;
+                            start = cut + 1;
+                        }
+                    }
+                }
+            } catch (const JsonFail&) { ok = false; }
+            if (ok && loaded.size() > 0) {
+                known = loaded;
+                known_found = true;
+                if (!strict_explicit) strict = true;
+                return;
+            }
+        }
+        if (!strict_explicit) strict = false;
+    }
+    // LoadProfile, Program.cs:918-931.  Only keys equal to Trigger / AlwaysAdd / PreferKeep ignoring case bind.
+    void load_profile(const tp_config& cfg) {
+        has_profile = false;
+        always_add.clear();
+        std::vector<uint8_t> bytes;
+        if (!read_source(cfg.profile, bytes)) return;
+        W trig = widen("sgrui");
+        bool trig_null = false, list_broken = false;
+        std::vector<W> always;
+        try {
+            JDoc d = JDoc::parse(bytes.data(), bytes.size());
+            if (d.kind(d.root) != JKind::Object) return;       // null -> no profile; any other kind fails to bind
+            auto is_key = [&](int32_t c, const char* want) { return folded(d.member_name(c)) == folded(widen(want)); };
+            auto bind_list = [&](int32_t c, std::vector<W>* into, bool* broken) {
+                if (into) into->clear();
+                if (broken) *broken = false;
+                if (d.kind(c) == JKind::Null) { if (broken) *broken = true; return; }
+                if (d.kind(c) != JKind::Array) throw JsonFail("list expected");
+                for (int32_t e = d.nodes[c].first; e >= 0; e = d.nodes[e].next) {
+                    if (d.kind(e) == JKind::Null) { if (broken) *broken = true; }
+                    else if (d.kind(e) == JKind::String) { if (into) into->push_back(d.str(e)); }
+                    else throw JsonFail("string expected");
+                }
+            };
+            for (int32_t c = d.nodes[d.root].first; c >= 0; c = d.nodes[c].next) {
+                if (is_key(c, "Trigger")) {
+                    if (d.kind(c) == JKind::Null) trig_null = true;
+                    else if (d.kind(c) == JKind::String) { trig = d.str(c); trig_null = false; }
+                    else throw JsonFail("string expected");
+                } else if (is_key(c, "AlwaysAdd")) bind_list(c, &always, &list_broken);
+                else if (is_key(c, "PreferKeep")) bind_list(c, nullptr, nullptr);
+            }
+        } catch (const JsonFail&) { return; }
+        if (!trig_null && !blank(trig)) trigger = normalize(trig);                 // Program.cs:925
+        if (list_broken) return;                                                  // Program.cs:926 throws on a null list or element: caught, no profile
+        std::vector<W> aa;
+        for (auto& t : always) { W n = normalize(t); if (!blank(n)) aa.push_back(n); }
+        always_add = unique_fold(aa);
+        has_profile = true;
+    }
+
+    // ParseStringArray, Program.cs:1408-1415
+    static std::vector<W> string_array(const JDoc& d, int32_t n) {
+        std::vector<W> out;
+        if (d.kind(n) == JKind::String) { W s = normalize_basic(d.str(n)); if (!blank(s)) out.push_back(s); return out; }
+        if (d.kind(n) != JKind::Array) return out;
+        for (int32_t c = d.nodes[n].first; c >= 0; c = d.nodes[c].next) { W s = normalize_basic(d.string_or_empty(c)); if (!blank(s)) out.push_back(s); }
+        return unique_fold(out);
+    }
+    static std::vector<W> opt_array(const JDoc& d, int32_t obj, const char16_t* key) {
+        int32_t m = d.member(obj, key);
+        return m < 0 ? std::vector<W>() : string_array(d, m);
+    }
+    // LoadLexicon, Program.cs:1275-1305 (merges over the defaults)
+    void load_lexicon(const tp_source& src) {
+        std::vector<uint8_t> bytes;
+        if (!read_source(src, bytes)) return;
+        JDoc d = JDoc::parse(bytes.data(), bytes.size());
+        auto obj = [&](const char16_t* key) { int32_t m = d.member(d.root, key); return (m >= 0 && d.kind(m) == JKind::Object) ? m : -1; };
+        FoldMap<W> al = aliases;
+        FoldMap<std::vector<W>> im = implied;
+        for (const char16_t* key : {u"aliases", u"normalization"}) {
+            int32_t o = obj(key);
+            if (o < 0) continue;
+            for (int32_t c = d.nodes[o].first; c >= 0; c = d.nodes[c].next) al.put(normalize_basic(d.member_name(c)), normalize_basic(d.string_or_empty(c)));
+        }
+        if (int32_t o = obj(u"synonyms"); o >= 0) {
+            for (int32_t c = d.nodes[o].first; c >= 0; c = d.nodes[c].next) {
+                if (d.kind(c) != JKind::Array) continue;
+                W canonical = normalize_basic(d.member_name(c));
+                for (int32_t e = d.nodes[c].first; e >= 0; e = d.nodes[e].next) al.put(normalize_basic(d.string_or_empty(e)), canonical);
+            }
+        }
+        for (const char16_t* key : {u"implied", u"implied_tags"}) {
+            int32_t o = obj(key);
+            if (o < 0) continue;
+            for (int32_t c = d.nodes[o].first; c >= 0; c = d.nodes[c].next) im.put(normalize_basic(d.member_name(c)), string_array(d, c));
+        }
+        aliases = al;
+        implied = im;
+    }
+    // ParseActionRule, Program.cs:1340-1372
+    static bool parse_action(const JDoc& d, int32_t item, Action& out) {
+        if (d.kind(item) != JKind::Object) return false;
+        W parent;
+        int32_t pt = d.member(item, u"parent_tag");
+        if (pt >= 0) parent = d.string_or_empty(pt);
+        if (blank(parent)) {
+            int32_t pe = d.member(item, u"parent");
+            if (pe >= 0) {
+                if (d.kind(pe) == JKind::String) parent = d.str(pe);
+                else if (d.kind(pe) == JKind::Array) {
+                    parent.clear();
+                    for (int32_t c = d.nodes[pe].first; c >= 0; c = d.nodes[c].next) {
+                        W s = d.string_or_empty(c);
+                        if (!blank(s)) { parent = s; break; }
+                    }
+                }
+            }
+        }
+        if (blank(parent)) return false;
+        out.all = opt_array(d, item, u"required_all");
+        out.any = opt_array(d, item, u"required_any");
+        out.forb = opt_array(d, item, u"forbidden_any");
+        out.subs.clear();
+        int32_t se = d.member(item, u"subtypes");
+        if (se >= 0 && d.kind(se) == JKind::Array) {
+            for (int32_t st = d.nodes[se].first; st >= 0; st = d.nodes[st].next) {
+                if (d.kind(st) == JKind::String) {
+                    W tag = normalize_basic(d.str(st));
+                    if (!blank(tag)) out.subs.push_back(ActionSub{tag, {tag}, {}});
+                } else if (d.kind(st) == JKind::Object) {
+                    int32_t te = d.member(st, u"tag");
+                    W tag = te >= 0 ? normalize_basic(d.string_or_empty(te)) : W();
+                    if (blank(tag)) continue;
+                    out.subs.push_back(ActionSub{tag, opt_array(d, st, u"match_any"), opt_array(d, st, u"match_all")});
+                }
+            }
+        }
+        out.parent = normalize_basic(parent);
+        return true;
+    }
+    // LoadActions, Program.cs:1307-1338 (replaces the built-in rules when at least one parses)
+    void load_actions(const tp_source& src) {
+        std::vector<uint8_t> bytes;
+        if (!read_source(src, bytes)) return;
+        JDoc d = JDoc::parse(bytes.data(), bytes.size());
+        std::vector<Action> list;
+        if (d.kind(d.root) == JKind::Array) {
+            for (int32_t c = d.nodes[d.root].first; c >= 0; c = d.nodes[c].next) { Action a; if (parse_action(d, c, a)) list.push_back(a); }
+        } else if (d.kind(d.root) == JKind::Object) {
+            if (d.member(d.root, u"parent_tag") >= 0 || d.member(d.root, u"parent") >= 0) {
+                Action a;
+                if (parse_action(d, d.root, a)) list.push_back(a);
+            } else {
+                for (int32_t c = d.nodes[d.root].first; c >= 0; c = d.nodes[c].next) {
+                    if (d.kind(c) != JKind::Object) continue;
+                    std::vector<W> parents = opt_array(d, c, u"parent"), subtypes = opt_array(d, c, u"subtypes");
+                    for (auto& parent : parents) {
+                        if (blank(parent)) continue;
+                        Action a;
+                        a.parent = parent;
+                        a.all = {parent};
+                        for (auto& st : subtypes) a.subs.push_back(ActionSub{st, {st}, {}});
+                        list.push_back(a);
+                    }
+                }
+            }
+        }
+        if (!list.empty()) actions = list;
+    }
+    // LoadRequiredFacets, Program.cs:1374-1406
+    void load_facets(const tp_source& src) {
+        std::vector<uint8_t> bytes;
+        if (!read_source(src, bytes)) return;
+        JDoc d = JDoc::parse(bytes.data(), bytes.size());
+        if (d.kind(d.root) != JKind::Object) return;
+        std::vector<FacetDef> list;
+        W unknown_prefix = widen("unknown_");
+        auto is_unknown = [&](const W& t) { return t.size() >= 8 && folded(t.substr(0, 8)) == folded(unknown_prefix); };
+        for (int32_t c = d.nodes[d.root].first; c >= 0; c = d.nodes[c].next) {
+            W name = normalize_basic(d.member_name(c));
+            if (d.kind(c) == JKind::Array) {
+                std::vector<W> tags = string_array(d, c);
+                if (tags.empty()) continue;
+                FacetDef f;
+                f.name = name;
+                auto it = std::find_if(tags.begin(), tags.end(), is_unknown);
+                f.def = it != tags.end() ? *it : unknown_prefix + name;
+                for (auto& t : tags) if (!is_unknown(t)) f.rules.push_back(FacetR{t, {t}, {}});
+                list.push_back(f);
+            } else if (d.kind(c) == JKind::Object) {
+                FacetDef f;
+                f.name = name;
+                int32_t de = d.member(c, u"default");
+                f.def = de >= 0 ? normalize_basic(d.string_or_empty(de)) : unknown_prefix + name;
+                int32_t re = d.member(c, u"rules");
+                if (re >= 0 && d.kind(re) == JKind::Array) {
+                    for (int32_t r = d.nodes[re].first; r >= 0; r = d.nodes[r].next) {
+                        if (d.kind(r) != JKind::Object) continue;
+                        int32_t te = d.member(r, u"tag");
+                        W tag = te >= 0 ? normalize_basic(d.string_or_empty(te)) : W();
+                        if (blank(tag)) continue;
+                        f.rules.push_back(FacetR{tag, opt_array(d, r, u"match_any"), opt_array(d, r, u"match_all")});
+                    }
+                }
+                list.push_back(f);
+            }
+        }
+        if (!list.empty()) facets = list;
+    }
+};
+
+// Interned strings, unique under the ordinal-ignore-case comparison the reference's sets use.
+struct Interner {
+    std::vector<W> text;
+    std::unordered_map<W, uint32_t> exact;
+    std::unordered_map<W, uint32_t> by_fold;
+    uint32_t id(const W& s) {
+        auto it = exact.find(s);
+        if (it != exact.end()) return it->second;
+        W f = folded(s);
+        auto jt = by_fold.find(f);
+        if (jt != by_fold.end())
+            throw ConfigError("two table strings differ only by case mapping (\"" + to_utf8(text[jt->second]) + "\" / \"" + to_utf8(s) + "\"): not representable");
+        uint32_t n = (uint32_t)text.size();
+        text.push_back(s);
+        exact.emplace(s, n);
+        by_fold.emplace(f, n);
+        return n;
+    }
+};
+
+}  // namespace
+
+void compile_tables(const tp_config& cfg, HostTables& out) {
+    Loader ld;
+    try {
+        // ---- Main's load sequence, Program.cs:156-165 ----
+        std::string trig = cfg.trigger ? cfg.trigger : "sgrui";
+        ld.trigger = from_utf8((const uint8_t*)trig.data(), trig.size());
+        ld.strict_explicit = cfg.strict_known_explicit != 0;
+        ld.strict = cfg.strict_known != 0;
+        std::string ap = cfg.auto_prefix_tags ? cfg.auto_prefix_tags : "", ms = cfg.minimal_subject_tags ? cfg.minimal_subject_tags : "";
+        std::vector<W> hard_prefix = unique_fold(split_tags(from_utf8((const uint8_t*)ap.data(), ap.size())));   // :158
+        ld.allow = ld.load_tag_file(cfg.allowlist);                                                                // :159
+        ld.deny = ld.load_tag_file(cfg.denylist);
+        ld.load_vocabulary(cfg);                                                                                   // :160
+        if (!cfg.no_profile) ld.load_profile(cfg);                                                                 // :161
+        ld.force_allow = FoldSet();                                                                                // BuildForceAllowTags, :933-940
+        ld.force_allow.insert(ld.normalize(ld.trigger));
+        ld.force_allow.insert(widen("1girl"));
+        if (ld.has_profile) for (auto& t : ld.always_add) ld.force_allow.insert(ld.normalize(t));
+        ld.default_lexicon();                                                                                      // LoadRuleEngineConfigs, :1212-1226
+        ld.actions = Loader::builtin_actions();
+        ld.facets = Loader::builtin_facets();
+        ld.load_lexicon(cfg.lexicon);
+        ld.load_actions(cfg.actions);
+        ld.load_facets(cfg.required_facets);
+        for (auto& a : ld.actions) { ld.action_tags.insert(a.parent); for (auto& s : a.subs) ld.action_tags.insert(s.tag); }   // RebuildActionTagSet, :1417-1422
+        std::vector<W> mf = hard_prefix;                                                                           // :165
+        for (auto& t : split_tags(from_utf8((const uint8_t*)ms.data(), ms.size()))) mf.push_back(t);
+        mf = unique_fold(mf);
+        W fallback_line;
+        for (size_t i = 0; i < mf.size(); ++i) { if (i) fallback_line += widen(", "); fallback_line += mf[i]; }
+        std::string fl8 = to_utf8(fallback_line);
+        out.fallback_line.assign(fl8.begin(), fl8.end());
+    } catch (const JsonFail& e) {
+        throw ConfigError(std::string("Fatal error occurred. ") + e.what());
+    }
+
+    // ---- intern every string the pipeline can compare or emit; frequent ones first (low ids sit in the histogram's on-chip part) ----
+    Interner in;
+    in.id(W());                                                   // EMPTY_ID
+    const W trigger_n = ld.normalize(ld.trigger);
+    in.id(trigger_n);
+    in.id(widen("1girl"));
+    in.id(ld.normalize(widen("1girl")));
+    std::vector<W> always_final;
+    if (ld.has_profile) for (auto& t : ld.always_add) always_final.push_back(ld.normalize(ld.normalize(t)));   // Select(NormalizeTag) then AddOne's own NormalizeTag, Program.cs:667, 693
+    if (always_final.size() > (size_t)MAX_ALWAYS_ADD) throw ConfigError("profile lists more than 64 always-add tags");
+    for (auto& t : always_final) in.id(t);
+    for (auto& f : ld.facets) { in.id(f.def); for (auto& r : f.rules) in.id(r.tag); }
+    for (auto& a : ld.actions) { in.id(a.parent); for (auto& s : a.subs) in.id(s.tag); }
+    for (auto& t : ld.known.order) in.id(t);
+    for (auto& kv : ld.aliases.m) in.id(kv.second.first), in.id(kv.second.second);
+    for (auto& kv : ld.builtin_aliases.m) in.id(kv.second.first), in.id(kv.second.second);
+    for (auto& kv : ld.implied.m) { in.id(kv.second.first); for (auto& v : kv.second.second) in.id(ld.normalize(v)); }
+    for (auto& a : ld.actions) {
+        for (auto* l : {&a.all, &a.any, &a.forb}) for (auto& s : *l) in.id(s);
+        for (auto& s : a.subs) for (auto* l : {&s.any, &s.all}) for (auto& x : *l) in.id(x);
+    }
+    for (auto& f : ld.facets) for (auto& r : f.rules) for (auto* l : {&r.any, &r.all}) for (auto& x : *l) in.id(x);
+    for (auto* set : {&ld.subject, &ld.banned, &ld.builtin_deny, &ld.action_tags, &ld.safe_reject, &ld.allow, &ld.deny, &ld.force_allow})
+        for (auto& s : set->order) in.id(s);
+    const W feet_n = ld.normalize(widen("feet")), penis_n = ld.normalize(widen("penis")), footjob_n = ld.normalize(widen("footjob"));
+    in.id(feet_n); in.id(penis_n); in.id(footjob_n);
+    {
+        W fl = from_utf8(out.fallback_line.data(), out.fallback_line.size());
+        for (auto& tok : split_tags(fl)) in.id(normalize_basic(tok));
+    }
+    // close under NormalizeTagBasic, the alias lookup and NormalizeTag
+    for (size_t i = 0; i < in.text.size(); ++i) {
+        W s = in.text[i];
+        in.id(ld.alias_of(s));
+        W nb = normalize_basic(s);
+        in.id(nb);
+        in.id(ld.alias_of(nb));
+    }
+    const uint32_t N = (uint32_t)in.text.size();
+
+    // A force-allowed tag survives ShouldDropTag even when it holds ',' or white space, and the line ingest's join + re-split
+    // (Program.cs:604, 578) would then cut it in two; the kernels do not model that.
+    for (auto& s : ld.force_allow.order)
+        for (wc c : s) if (c == ',' || is_space(c)) throw ConfigError("a force-allowed tag (trigger / always-add) holds ',' or white space: not representable");
+
+    // ---- per-string attributes ----
+    out.strings.resize(N);
+    out.str_off.assign(N + 1, 0);
+    out.flags.assign(N, 0);
+    out.next.assign(N, 0);
+    out.alias1.assign(N, 0);
+    out.lit.assign(N, NO_ID);
+    out.str_bytes.clear();
+    auto id_of = [&](const W& s) -> uint32_t {
+        auto it = in.exact.find(s);
+        if (it != in.exact.end()) return it->second;
+        auto jt = in.by_fold.find(folded(s));
+        if (jt != in.by_fold.end()) return jt->second;
+        throw ConfigError("internal: string missing from the intern table: " + to_utf8(s));
+    };
+    for (uint32_t i = 0; i < N; ++i) {
+        const W& s = in.text[i];
+        out.strings[i] = to_utf8(s);
+        out.str_off[i] = (uint32_t)out.str_bytes.size();
+        out.str_bytes.insert(out.str_bytes.end(), out.strings[i].begin(), out.strings[i].end());
+        out.alias1[i] = id_of(ld.alias_of(s));
+        out.next[i] = id_of(ld.alias_of(normalize_basic(s)));
+        uint32_t mask = class_mask(ld.dfa_next, ld.dfa_out, lowered(s));
+        uint32_t f = 0;
+        if (blank(s)) f |= FL_BLANK;
+        if (Loader::valid_tag(s)) f |= FL_VALID;
+        if (ld.should_drop(s)) f |= FL_DROP;
+        if (s.size() >= 2) f |= FL_LEN2;
+        f |= ld.bucket_of(s, mask) << FL_BUCKET_SHIFT;
+        if (mask & CM_HAIR) f |= FL_HAIR;
+        if (mask & CM_EYES) f |= FL_EYES;
+        if (ld.banned.contains(s)) f |= FL_BANNED;
+        if (ld.safe_reject.contains(s)) {
+            f |= FL_SAFE;
+            W fs = folded(s);
+            for (uint32_t k = 0; k < 20; ++k) if (folded(widen(kSafeList[k])) == fs) f |= k << FL_SAFE_IDX_SHIFT;
+        }
+        if (ld.known.contains(s)) f |= FL_KNOWN;
+        out.flags[i] = f;
+    }
+    out.str_off[N] = (uint32_t)out.str_bytes.size();
+    out.str_bytes.resize(out.str_bytes.size() + 16, 0);   // slack so byte compares never touch the end of the allocation
+    const uint32_t feet_id = id_of(feet_n), penis_id = id_of(penis_n), footjob_id = id_of(footjob_n);
+    // implied lists (Program.cs:1171-1175): NormalizeTag of each entry, blanks removed
+    out.imp_off.assign(N + 1, 0);
+    out.imp_ids.clear();
+    for (uint32_t i = 0; i < N; ++i) {
+        out.imp_off[i] = (uint32_t)out.imp_ids.size();
+        if (const std::vector<W>* lst = ld.implied.get(in.text[i]))
+            for (auto& v : *lst) { W n = ld.normalize(v); if (!blank(n)) out.imp_ids.push_back(id_of(n)); }
+    }
+    out.imp_off[N] = (uint32_t)out.imp_ids.size();
+    for (uint32_t i = 0; i < N; ++i) {
+        if (out.next[i] != i || out.imp_off[i + 1] != out.imp_off[i]) out.flags[i] |= FL_EDGE;
+        if (out.next[i] == feet_id) out.flags[i] |= FL_NFEET;
+        if (out.next[i] == penis_id) out.flags[i] |= FL_NPENIS;
+        if (out.next[i] == footjob_id) out.flags[i] |= FL_NFOOTJOB;
+    }
+
+    // ---- rules -> literal indices ----
+    uint32_t n_lits = 0;
+    auto lit_list = [&](const std::vector<W>& v, uint32_t& off, uint32_t& cnt) {
+        off = (uint32_t)out.pool.size();
+        cnt = (uint32_t)v.size();
+        for (auto& s : v) {
+            uint32_t id = id_of(s);
+            if (out.lit[id] == NO_ID) out.lit[id] = n_lits++;
+            out.pool.push_back(out.lit[id]);
+        }
+    };
+    out.pool.clear(); out.rules.clear(); out.subs.clear(); out.facets.clear(); out.facet_rules.clear();
+    out.rule_names.clear(); out.sub_names.clear(); out.facet_names.clear(); out.facet_defaults.clear(); out.facet_rule_tags.clear();
+    for (auto& a : ld.actions) {
+        DRule r{};
+        r.parent_id = id_of(a.parent);
+        lit_list(a.all, r.all_off, r.all_cnt);
+        lit_list(a.any, r.any_off, r.any_cnt);
+        lit_list(a.forb, r.forb_off, r.forb_cnt);
+        r.sub_off = (uint32_t)out.subs.size();
+        r.sub_cnt = (uint32_t)a.subs.size();
+        for (auto& s : a.subs) {
+            DSub d{};
+            d.tag_id = id_of(s.tag);
+            lit_list(s.any, d.any_off, d.any_cnt);
+            lit_list(s.all, d.all_off, d.all_cnt);
+            out.subs.push_back(d);
+            out.sub_names.push_back(to_utf8(a.parent) + ":" + to_utf8(s.tag));
+        }
+        out.rules.push_back(r);
+        out.rule_names.push_back(to_utf8(a.parent));
+    }
+    for (auto& f : ld.facets) {
+        DFacet df{};
+        df.def_id = id_of(f.def);
+        df.rule_off = (uint32_t)out.facet_rules.size();
+        df.rule_cnt = (uint32_t)f.rules.size();
+        std::vector<std::string> tags;
+        for (auto& r : f.rules) {
+            DSub d{};
+            d.tag_id = id_of(r.tag);
+            lit_list(r.any, d.any_off, d.any_cnt);
+            lit_list(r.all, d.all_off, d.all_cnt);
+            out.facet_rules.push_back(d);
+            tags.push_back(to_utf8(r.tag));
+        }
+        if (df.rule_cnt > 0xFFFE) throw ConfigError("a facet has more than 65534 rules");
+        out.facets.push_back(df);
+        out.facet_names.push_back(to_utf8(f.name));
+        out.facet_defaults.push_back(to_utf8(f.def));
+        out.facet_rule_tags.push_back(tags);
+    }
+    if (out.pool.empty()) out.pool.push_back(0);
+    if (out.imp_ids.empty()) out.imp_ids.push_back(0);
+    if (out.subs.empty()) out.subs.push_back(DSub{});
+    if (out.rules.empty()) out.rules.push_back(DRule{});
+    if (out.facets.empty()) out.facets.push_back(DFacet{});
+    if (out.facet_rules.empty()) out.facet_rules.push_back(DSub{});
+
+    // ---- hash table over the strings' bytes ----
+    uint32_t slots = 16;
+    while (slots < N * 2u + 2u) slots <<= 1;
+    out.ht_hash.assign(slots, 0);
+    out.ht_id.assign(slots, NO_ID);
+    for (uint32_t i = 0; i < N; ++i) {
+        uint64_t h = HASH_SEED;
+        for (unsigned char c : out.strings[i]) h = hash_step(h, c);
+        h = hash_fin(h);
+        if (h == 0) h = 1;
+        uint32_t s = (uint32_t)h & (slots - 1);
+        while (out.ht_hash[s] != 0) s = (s + 1) & (slots - 1);
+        out.ht_hash[s] = h;
+        out.ht_id[s] = i;
+    }
+    out.dfa_next = ld.dfa_next;
+    out.dfa_out = ld.dfa_out;
+
+    // ---- scalars ----
+    DevTables& sc = out.scalars;
+    std::memset(&sc, 0, sizeof sc);
+    sc.n_strings = N;
+    sc.ht_mask = slots - 1;
+    sc.n_lits = n_lits;
+    sc.lit_words = (n_lits + 31) / 32;
+    sc.n_rules = (uint32_t)ld.actions.size();
+    sc.n_subs = (uint32_t)out.sub_names.size();
+    sc.n_facets = (uint32_t)ld.facets.size();
+    sc.fired_words = (sc.n_rules + sc.n_subs + 31) / 32;
+    sc.trigger_id = id_of(trigger_n);
+    sc.girl_add_id = id_of(ld.normalize(widen("1girl")));
+    sc.girl_lit_id = id_of(widen("1girl"));
+    sc.n_always = (uint32_t)always_final.size();
+    for (uint32_t k = 0; k < sc.n_always; ++k) sc.always_ids[k] = id_of(always_final[k]);
+    sc.n_fallback = 0;
+    sc.feet_n = feet_id; sc.penis_n = penis_id; sc.footjob_n = footjob_id;
+    sc.drop_unknown = (ld.known_found && ld.strict) ? 1 : 0;
+    sc.allow_nonempty = ld.allow.size() > 0 ? 1 : 0;
+    sc.known_active = (ld.known_found && ld.known.size() > 0) ? 1 : 0;
+    sc.safe_mode = cfg.safe_mode ? 1 : 0;
+    sc.line_weight = cfg.line_weight;
+    sc.line_source = (uint32_t)cfg.line_source;
+    std::string nl = cfg.newline ? cfg.newline : "\n";
+    if (nl.size() > 4) throw ConfigError("newline longer than 4 bytes");
+    sc.newline_len = (uint32_t)nl.size();
+    for (size_t k = 0; k < nl.size(); ++k) sc.newline[k] = (uint8_t)nl[k];
+    // Capacities of the per-file lists.  ExpandImpliedTags can add, per tag, everything reachable from it over the
+    // NormalizeTag and implied edges; the largest such reach bounds the growth.  A file that still outgrows a list is
+    // reported as unsupported rather than truncated.
+    uint32_t reach_max = 0;
+    {
+        std::vector<uint32_t> seen(N, NO_ID), stack;
+        for (uint32_t i = 0; i < N; ++i) {
+            if (!(out.flags[i] & FL_EDGE)) continue;
+            uint32_t reached = 0;
+            stack.assign(1, i);
+            seen[i] = i;
+            while (!stack.empty() && reached < 4096) {
+                uint32_t x = stack.back();
+                stack.pop_back();
+                auto visit = [&](uint32_t y) { if (seen[y] != i) { seen[y] = i; ++reached; stack.push_back(y); } };
+                visit(out.next[x]);
+                for (uint32_t m = out.imp_off[x]; m < out.imp_off[x + 1]; ++m) visit(out.imp_ids[m]);
+            }
+            reach_max = std::max(reach_max, reached);
+        }
+    }
+    sc.final_cap = MAX_TOTAL_TAGS + std::min<uint32_t>(MAX_TOTAL_TAGS * reach_max, 2048) + sc.n_rules + sc.n_subs + sc.n_facets + 16;
+    sc.evidence_grow = std::min<uint32_t>(73 * reach_max, 2048) + 16;   // at most 73 line-ingest candidates score >= 0.28
+    out.n_known = (uint32_t)ld.known.size();
+    out.strict = ld.strict;
+    out.known_found = ld.known_found;
+}
+
+DevTables bind_host_pointers(const HostTables& ht) {
+    DevTables t = ht.scalars;
+    t.str_bytes = ht.str_bytes.data();
+    t.str_off = ht.str_off.data();
+    t.flags = ht.flags.data();
+    t.next = ht.next.data();
+    t.alias1 = ht.alias1.data();
+    t.lit = ht.lit.data();
+    t.imp_off = ht.imp_off.data();
+    t.imp_ids = ht.imp_ids.data();
+    t.ht_hash = ht.ht_hash.data();
+    t.ht_id = ht.ht_id.data();
+    t.dfa_next = ht.dfa_next.data();
+    t.dfa_out = ht.dfa_out.data();
+    t.pool = ht.pool.data();
+    t.rules = ht.rules.data();
+    t.subs = ht.subs.data();
+    t.facets = ht.facets.data();
+    t.facet_rules = ht.facet_rules.data();
+    return t;
+}
+
+}  // namespace tp

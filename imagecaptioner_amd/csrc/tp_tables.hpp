@@ -1,0 +1,49 @@
+// Host-side table compiler: reads the reference's configuration files in the
+// reference's order (Program.cs:156-165) and compiles them into the flat table
+// image the kernels read (tp_common.h: DevTables).
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tagpipe.h"
+#include "tp_common.h"
+
+namespace tp {
+
+struct ConfigError : std::runtime_error {
+    explicit ConfigError(const std::string& m) : std::runtime_error(m) {}
+};
+
+struct HostTables {
+    // arrays of the device image
+    std::vector<uint8_t> str_bytes;
+    std::vector<uint32_t> str_off, flags, next, alias1, lit, imp_off, imp_ids;
+    std::vector<uint64_t> ht_hash;
+    std::vector<uint32_t> ht_id;
+    std::vector<uint16_t> dfa_next, dfa_out;
+    std::vector<uint32_t> pool;
+    std::vector<DRule> rules;
+    std::vector<DSub> subs;
+    std::vector<DFacet> facets;
+    std::vector<DSub> facet_rules;
+    DevTables scalars;                      // scalar members filled, pointer members null
+    // host-side facts
+    std::vector<std::string> strings;       // UTF-8 text per interned id
+    std::vector<std::string> rule_names;    // ActionRule.ParentTag per rule
+    std::vector<std::string> sub_names;     // "parent:tag" per subtype (global index)
+    std::vector<std::string> facet_names, facet_defaults;
+    std::vector<std::vector<std::string>> facet_rule_tags;
+    std::vector<uint8_t> fallback_line;     // the minimal fallback line (Program.cs:165), UTF-8
+    uint32_t n_known = 0;
+    bool strict = false, known_found = false;
+};
+
+// Throws ConfigError (malformed JSON or table content this build cannot represent).
+void compile_tables(const tp_config& cfg, HostTables& out);
+
+// A DevTables whose pointers address the HostTables vectors themselves (host-side logic checks).
+DevTables bind_host_pointers(const HostTables& ht);
+
+}  // namespace tp

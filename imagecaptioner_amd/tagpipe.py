@@ -1,0 +1,209 @@
+"""Host-side binding of libtagpipe_hip.so (the C ABI in include/tagpipe.h).
+
+The library runs the tag pipeline on the GPU only.  If the shared object is
+missing, or no HIP device is present, construction fails with an error: there is
+no CPU path in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (TP_E_CAPACITY, TP_OK, VERDICT_DTYPE, Config, tp_config, tp_counters, tp_device_io, tp_result, tp_table_info,
+                   tp_timing)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtagpipe_hip.so")
+_LIB = None
+
+EXPORTS = (
+    "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
+    "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_format_top_tags", "tp_get_last_timing",
+)
+
+
+class TagPipeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("tagpipe error %d: %s" % (code, message))
+        self.code = code
+
+
+def load_library():
+    """dlopen the in-tree library and declare its prototypes.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise TagPipeError(-3, "HIP extension not built: %s is missing (run `python -m imagecaptioner_amd.build`)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.tp_config_init.argtypes = [C.POINTER(tp_config)]
+    L.tp_config_init.restype = None
+    L.tp_create.argtypes = [C.POINTER(tp_config)]
+    L.tp_create.restype = C.c_void_p
+    L.tp_destroy.argtypes = [C.c_void_p]
+    L.tp_destroy.restype = None
+    L.tp_last_error.restype = C.c_char_p
+    L.tp_get_table_info.argtypes = [C.c_void_p, C.POINTER(tp_table_info)]
+    L.tp_get_string.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32)]
+    L.tp_get_name.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32)]
+    L.tp_run_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(tp_result)]
+    L.tp_run_scored.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(tp_result)]
+    L.tp_release.argtypes = [C.c_void_p, C.POINTER(tp_result)]
+    L.tp_release.restype = None
+    L.tp_run_lines_device.argtypes = [C.c_void_p, C.POINTER(tp_device_io), C.POINTER(C.c_uint64)]
+    L.tp_format_top_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.tp_get_last_timing.argtypes = [C.c_void_p, C.POINTER(tp_timing)]
+    _LIB = L
+    return L
+
+
+class BatchResult:
+    """Host copy of one batch's outputs."""
+
+    def __init__(self, captions, caption_offsets, verdicts, counters, histogram, histogram_other, fired, facet_choice):
+        self.captions = captions                # uint8[total]
+        self.caption_offsets = caption_offsets  # uint64[n+1]
+        self.verdicts = verdicts                # structured array, VERDICT_DTYPE
+        self.counters = counters                # dict
+        self.histogram = histogram              # uint64[n_strings]
+        self.histogram_other = histogram_other
+        self.fired = fired                      # uint32[n, fired_words]
+        self.facet_choice = facet_choice        # uint16[n, n_facets]
+
+    @property
+    def n_files(self):
+        return len(self.caption_offsets) - 1
+
+    def caption(self, i):
+        return bytes(self.captions[int(self.caption_offsets[i]):int(self.caption_offsets[i + 1])])
+
+
+class TagPipe:
+    """One GPU context: tables compiled from the reference's configuration files, resident on one device."""
+
+    def __init__(self, config: Config):
+        self._L = load_library()
+        self._cfg = config
+        self._h = self._L.tp_create(C.byref(config.struct))
+        if not self._h:
+            raise TagPipeError(-2, self._L.tp_last_error().decode("utf-8", "replace"))
+        info = tp_table_info()
+        self._check(self._L.tp_get_table_info(self._h, C.byref(info)))
+        self.info = info
+        self._strings = None
+
+    def _check(self, rc):
+        if rc != TP_OK:
+            raise TagPipeError(rc, self._L.tp_last_error().decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables -------------------------------------------------------------------------------
+    def string(self, i):
+        p, n = C.c_char_p(), C.c_uint32()
+        self._check(self._L.tp_get_string(self._h, i, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value).decode("utf-8", "replace")
+
+    def strings(self):
+        if self._strings is None:
+            self._strings = [self.string(i) for i in range(self.info.n_strings)]
+        return self._strings
+
+    def name(self, kind, index):
+        p, n = C.c_char_p(), C.c_uint32()
+        self._check(self._L.tp_get_name(self._h, kind, index, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value).decode("utf-8", "replace")
+
+    def rule_names(self):
+        i = self.info
+        return {
+            "actions": [self.name(0, r) for r in range(i.n_action_rules)],
+            "subtypes": [self.name(1, s) for s in range(i.n_action_subtypes)],
+            "facets": [{"name": self.name(2, f), "default": self.name(3, f)} for f in range(i.n_facets)],
+        }
+
+    def histogram_dict(self, histogram):
+        """{tag: count} for the non-zero entries of a histogram array."""
+        s = self.strings()
+        nz = np.nonzero(np.asarray(histogram)[:len(s)])[0]
+        return {s[int(i)]: int(histogram[int(i)]) for i in nz}
+
+    def format_top_tags(self, histogram):
+        hist = np.ascontiguousarray(histogram, dtype=np.uint64)
+        need = C.c_uint64()
+        rc = self._L.tp_format_top_tags(self._h, hist.ctypes.data, None, 0, C.byref(need))
+        if rc not in (TP_OK, TP_E_CAPACITY):
+            self._check(rc)
+        buf = np.zeros(max(need.value, 1), dtype=np.uint8)
+        if need.value:
+            self._check(self._L.tp_format_top_tags(self._h, hist.ctypes.data, buf.ctypes.data, need.value, C.byref(need)))
+        return bytes(buf[:need.value])
+
+    def last_timing(self):
+        t = tp_timing()
+        self._check(self._L.tp_get_last_timing(self._h, C.byref(t)))
+        return {"total_ms": t.total_ms, "select_ms": t.select_ms, "emit_ms": t.emit_ms, "other_ms": t.other_ms}
+
+    # ---- host-buffer runs -----------------------------------------------------------------------
+    def _collect(self, res):
+        n = int(res.n_files)
+        total = int(res.caption_offsets[n]) if n else 0
+        caps = np.ctypeslib.as_array(res.captions, shape=(max(total, 1),))[:total].copy()
+        offs = np.ctypeslib.as_array(res.caption_offsets, shape=(n + 1,)).copy()
+        ver = np.frombuffer(C.string_at(res.verdicts, 16 * n), dtype=VERDICT_DTYPE).copy() if n else np.zeros(0, VERDICT_DTYPE)
+        ns, fw, nf = self.info.n_strings, self.info.fired_words, self.info.n_facets
+        hist = np.ctypeslib.as_array(res.histogram, shape=(ns,)).copy()
+        fired = np.ctypeslib.as_array(res.fired, shape=(max(n * fw, 1),))[:n * fw].copy().reshape(n, fw)
+        fc = np.ctypeslib.as_array(res.facet_choice, shape=(max(n * nf, 1),))[:n * nf].copy().reshape(n, nf)
+        out = BatchResult(caps, offs, ver, res.counters.as_dict(), hist, int(res.histogram_other), fired, fc)
+        self._L.tp_release(self._h, C.byref(res))
+        return out
+
+    def run_lines(self, arena, offsets):
+        """tp_run_lines: host arena + offsets in, host results out (uploads and downloads included)."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = tp_result()
+        self._check(self._L.tp_run_lines(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, len(offsets) - 1, C.byref(res)))
+        return self._collect(res)
+
+    def run_texts(self, texts):
+        bs = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
+        offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        arena = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+        return self.run_lines(arena, offsets)
+
+    def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
+        tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        sources = np.ascontiguousarray(sources, dtype=np.uint8)
+        res = tp_result()
+        self._check(self._L.tp_run_scored(self._h, arena.ctypes.data if arena.size else None, tag_offsets.ctypes.data, tag_begin.ctypes.data,
+                                          scores.ctypes.data if scores.size else None, sources.ctypes.data if sources.size else None,
+                                          len(tag_begin) - 1, C.byref(res)))
+        return self._collect(res)
+
+    # ---- device-resident run ---------------------------------------------------------------------
+    def run_lines_device(self, io: tp_device_io):
+        """tp_run_lines_device: every pointer in `io` is a device pointer.  Returns the caption byte count;
+        raises TagPipeError(code TP_E_CAPACITY) when the caption buffer is too small."""
+        nbytes = C.c_uint64()
+        rc = self._L.tp_run_lines_device(self._h, C.byref(io), C.byref(nbytes))
+        if rc != TP_OK:
+            err = TagPipeError(rc, self._L.tp_last_error().decode("utf-8", "replace"))
+            err.required = nbytes.value
+            raise err
+        return nbytes.value

@@ -43,7 +43,7 @@ extern "C" {
 #define TP_F_FOOTJOB       0x04u  /* ... and the final tags have footjob, Program.cs:311 */
 #define TP_F_FALLBACK      0x08u  /* fewer than 3 selected tags: minimal fallback line used, Program.cs:297-298 */
 #define TP_F_LINE_REJECTED 0x10u  /* NormalizeRawTagLine returned "" (blank or LooksBad), Program.cs:590, 596 */
-#define TP_F_UNSUPPORTED   0x20u  /* input holds bytes this build does not process; caption is empty */
+#define TP_F_UNSUPPORTED   0x20u  /* input this build does not process (a byte >= 0x80, or a per-file list outgrew its workspace); nothing is written for the file */
 #define TP_F_SAFE_REJECT   0x40u  /* DetectSafeModeRejectReason hit, Program.cs:329, 942-945 */
 
 /* Candidate sources and their SourceRank (Program.cs:398, 712-717). */
@@ -146,6 +146,18 @@ int tp_get_table_info(const tp_ctx* ctx, tp_table_info* out);
 
 /* The interned string with the given id (histogram index -> tag).  Pointer valid until tp_destroy. */
 int tp_get_string(const tp_ctx* ctx, uint32_t id, const char** utf8, uint32_t* len);
+
+/*
+ * Names behind the detail arrays of tp_result, i.e. the strings the reference
+ * logs as "action:{parent}", "subtype:{parent}:{tag}", "facet:{name}:{tag}"
+ * and "facet:{name}:{default}:default" (Program.cs:741, 748, 764, 772).
+ */
+#define TP_NAME_ACTION_RULE    0  /* index = rule           -> ParentTag */
+#define TP_NAME_ACTION_SUBTYPE 1  /* index = global subtype -> "parent:tag" */
+#define TP_NAME_FACET          2  /* index = facet          -> Name */
+#define TP_NAME_FACET_DEFAULT  3  /* index = facet          -> DefaultTag */
+#define TP_NAME_FACET_RULE     4  /* index = facet << 16 | rule -> rule Tag */
+int tp_get_name(const tp_ctx* ctx, int kind, uint32_t index, const char** utf8, uint32_t* len);
 
 /*
  * Result of one batch, owned by the library until tp_release.

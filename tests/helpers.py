@@ -1,0 +1,208 @@
+"""Shared test utilities: oracle / hostsim bindings, result comparison, edge-case lines."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from imagecaptioner_amd._abi import VERDICT_DTYPE, Config, tp_config, tp_counters, tp_table_info, tp_verdict  # noqa: E402
+from oracle.oracle_py import Oracle, pack_lines  # noqa: E402,F401
+
+DATA = os.path.join(ROOT, "tests", "golden", "reference_data")
+
+
+def shipped_config(**kw):
+    """The reference's shipped tables (rules/*.json, profiles/sgrui.json, top_tags.txt)."""
+    base = dict(lexicon=os.path.join(DATA, "rules", "lexicon.json"), actions=os.path.join(DATA, "rules", "actions.json"),
+                required_facets=os.path.join(DATA, "rules", "required_facets.json"), profile=os.path.join(DATA, "profiles", "sgrui.json"),
+                vocabulary=os.path.join(DATA, "top_tags.txt"), minimal_subject_tags="1girl, solo")
+    base.update(kw)
+    return Config(**base)
+
+
+# ---- test-only host build of the kernels' per-file pipeline ---------------------------------------
+class sim_result(C.Structure):
+    _fields_ = [("n_files", C.c_uint64), ("captions", C.POINTER(C.c_uint8)), ("offsets", C.POINTER(C.c_uint64)),
+                ("verdicts", C.POINTER(tp_verdict)), ("counters", tp_counters), ("histogram", C.POINTER(C.c_uint64)),
+                ("fired", C.POINTER(C.c_uint32)), ("facets", C.POINTER(C.c_uint16)), ("opaque", C.c_void_p)]
+
+
+_SIM = None
+
+
+def sim_lib():
+    global _SIM
+    if _SIM is None:
+        d = os.path.join(ROOT, "tests", "hostsim")
+        subprocess.check_call(["make", "-C", d, "-s"])
+        L = C.CDLL(os.path.join(d, "libtp_hostsim.so"))
+        L.sim_last_error.restype = C.c_char_p
+        L.sim_create.restype = C.c_void_p
+        L.sim_create.argtypes = [C.POINTER(tp_config)]
+        L.sim_destroy.argtypes = [C.c_void_p]
+        L.sim_info.argtypes = [C.c_void_p, C.POINTER(tp_table_info)]
+        L.sim_string.restype = C.c_char_p
+        L.sim_string.argtypes = [C.c_void_p, C.c_uint32]
+        L.sim_run_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
+        L.sim_run_scored.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
+        L.sim_release.argtypes = [C.POINTER(sim_result)]
+        _SIM = L
+    return _SIM
+
+
+class SimResult:
+    def __init__(self, captions, offsets, verdicts, counters, histogram, histogram_other, fired, facet_choice):
+        self.captions, self.caption_offsets, self.verdicts, self.counters = captions, offsets, verdicts, counters
+        self.histogram, self.histogram_other, self.fired, self.facet_choice = histogram, histogram_other, fired, facet_choice
+
+    def caption(self, i):
+        return bytes(self.captions[int(self.caption_offsets[i]):int(self.caption_offsets[i + 1])])
+
+
+class HostSim:
+    """The kernel's per-file pipeline source compiled for the host (tests/hostsim) — logic checks only."""
+
+    def __init__(self, config):
+        self._cfg = config
+        self._L = sim_lib()
+        self._h = self._L.sim_create(C.byref(config.struct))
+        if not self._h:
+            raise RuntimeError(self._L.sim_last_error().decode("utf-8", "replace"))
+        self.info = tp_table_info()
+        self._L.sim_info(self._h, C.byref(self.info))
+        self._strings = None
+
+    def strings(self):
+        if self._strings is None:
+            self._strings = [self._L.sim_string(self._h, i).decode("utf-8", "replace") for i in range(self.info.n_strings)]
+        return self._strings
+
+    def histogram_dict(self, histogram):
+        s = self.strings()
+        nz = np.nonzero(np.asarray(histogram)[:len(s)])[0]
+        return {s[int(i)]: int(histogram[int(i)]) for i in nz}
+
+    def _collect(self, res, rc):
+        if rc != 0:
+            raise RuntimeError(self._L.sim_last_error().decode())
+        n = int(res.n_files)
+        total = int(res.offsets[n]) if n else 0
+        caps = np.ctypeslib.as_array(res.captions, shape=(max(total, 1),))[:total].copy()
+        offs = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
+        ver = np.frombuffer(C.string_at(res.verdicts, 16 * n), dtype=VERDICT_DTYPE).copy() if n else np.zeros(0, VERDICT_DTYPE)
+        ns, fw, nf = self.info.n_strings, self.info.fired_words, self.info.n_facets
+        hist = np.ctypeslib.as_array(res.histogram, shape=(ns + 1,)).copy()
+        fired = np.ctypeslib.as_array(res.fired, shape=(max(n * fw, 1),))[:n * fw].copy().reshape(n, fw)
+        fc = np.ctypeslib.as_array(res.facets, shape=(max(n * nf, 1),))[:n * nf].copy().reshape(n, nf)
+        out = SimResult(caps, offs, ver, res.counters.as_dict(), hist[:ns], int(hist[ns]), fired, fc)
+        self._L.sim_release(C.byref(res))
+        return out
+
+    def run_lines(self, arena, offsets):
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        pad = np.concatenate([arena, np.zeros(16, np.uint8)])
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = sim_result()
+        rc = self._L.sim_run_lines(self._h, pad.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(res))
+        return self._collect(res, rc)
+
+    def run_texts(self, texts):
+        a, o = pack_lines(texts)
+        return self.run_lines(a, o)
+
+    def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
+        arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
+        tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
+        tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        sources = np.ascontiguousarray(sources, dtype=np.uint8)
+        res = sim_result()
+        rc = self._L.sim_run_scored(self._h, arena.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data, scores.ctypes.data,
+                                    sources.ctypes.data, len(tag_begin) - 1, C.byref(res))
+        return self._collect(res, rc)
+
+
+# ---- comparison -------------------------------------------------------------------------------------
+def assert_same_results(got, want, hist_of_got, what="", check_hist=True):
+    """got: BatchResult/SimResult of the implementation under test; want: OracleResult.  Bit-exact on everything."""
+    n = len(want.caption_offsets) - 1
+    assert len(got.caption_offsets) - 1 == n, what
+    if not np.array_equal(got.caption_offsets, want.caption_offsets) or not np.array_equal(got.captions, want.captions):
+        for i in range(n):
+            assert got.caption(i) == want.caption(i), "%s file %d:\n got  %r\n want %r" % (what, i, got.caption(i), want.caption(i))
+    for name in got.verdicts.dtype.names:
+        if not np.array_equal(got.verdicts[name], want.verdicts[name]):
+            i = int(np.nonzero(got.verdicts[name] != want.verdicts[name])[0][0])
+            raise AssertionError("%s verdict.%s differs at file %d: got %r want %r (caption %r)" %
+                                 (what, name, i, got.verdicts[name][i], want.verdicts[name][i], want.caption(i)))
+    assert np.array_equal(got.fired, want.fired), what + " fired bitmap"
+    assert np.array_equal(got.facet_choice, want.facet_choice), what + " facet_choice"
+    for k, v in want.counters.items():
+        assert got.counters[k] == v, "%s counter %s: got %d want %d" % (what, k, got.counters[k], v)
+    if check_hist:
+        gh = dict(hist_of_got)
+        other = got.histogram_other
+        wh = dict(want.histogram)
+        if other:
+            # tags outside the tables are pooled in one counter; the oracle counts them by name
+            known = set(gh)
+            pooled = sum(c for t, c in wh.items() if t not in known)
+            assert pooled == other, "%s histogram_other: got %d want %d" % (what, other, pooled)
+            wh = {t: c for t, c in wh.items() if t in known}
+        assert gh == wh, "%s histogram differs: %r" % (what, sorted(set(gh.items()) ^ set(wh.items()))[:10])
+
+
+EDGE_LINES = [
+    "",
+    "   \t  ",
+    "1girl, solo, blue_hair, long_hair, blue_eyes, smile, school_uniform, standing, classroom, masterpiece, best_quality, highres, watermark",
+    "1girl",
+    "1girl, solo",
+    "a, b, c",
+    "solo, solo, Solo, SOLO , solo.",
+    "1girl, barefoot, penis, long hair, Blue Eyes., smile, dress, sitting, bedroom, toes",
+    "sorry, I can't help with that",
+    "this is one long sentence without any commas that goes past forty characters",
+    "short, line",
+    "POSITIVE: 1girl, smile, dress\nNEGATIVE: lowres, bad_hands",
+    "Here you go:\npositive:  1girl, long_hair, skirt  \nnegative: text",
+    "1girl, smile, dress NEGATIVE: watermark, text",
+    "```\n1girl, smile, dress, hat\n```",
+    "```json\n1girl, smile, dress, hat```",
+    "```1girl, smile, dress",
+    "1girl,\r\nsmile,\r\ndress,\r\nhat",
+    "1girl,,, ,smile,  ,dress,",
+    ",,,",
+    "'1girl', \"smile\", `dress`, 'hat'.",
+    "x'., y';, z\"., 1girl, smile, dress",
+    "' x', 'a b'  , \" q \" , 1girl, smile",
+    "long  hair , red__eyes, blue _ ribbon,  1girl",
+    "pedal stimulation, feet, penis, 1girl, between_feet",
+    "foot, soles, fingers, licking, penis, 1girl",
+    "fellatio, penis, 1girl, smile, dress",
+    "rating:safe, rating, watermark, signature, 1girl, smile, dress",
+    "1boy, male_focus, 1girl, smile, dress",
+    ":bad, -bad, _bad, ok_tag, (paren), a!b, a/b, a-b, a'b",
+    "nsfw, nude, 1girl, smile, dress",
+    "1girl, hand, penis, grip, vaginal_penetration",
+    "penis, vaginal, missionary, 1girl",
+    "1girl, looking_at_viewer, open_mouth, tongue_out, cum, ejaculation, panties_aside, male_pov",
+    "I'm not able to do that, 1girl, smile",
+    "as an AI, i cannot, 1girl",
+    "tag;, tag2..;, tag3;.;, 1girl",
+    "A, B",
+    "i\ncan't, 1girl, smile",
+    "1girl, " + ", ".join("tag_%d" % i for i in range(120)),
+    ", ".join(["blue_hair", "red_hair", "long_hair", "short_hair", "twintails", "ponytail", "braid", "ahoge", "bangs", "blush", "smile", "frown",
+               "dress", "skirt", "shirt", "jacket", "coat", "hat", "ribbon", "bow", "boots", "gloves", "standing", "sitting", "lying",
+               "kneeling", "walking", "running", "indoors", "outdoors", "bedroom", "street", "city", "park", "lighting", "shadow",
+               "bloom", "bokeh", "highres", "absurdres", "masterpiece", "detailed", "cat", "dog", "sword", "flower", "book", "cup", "star", "moon"]),
+    "masterpiece, best_quality, highres, absurdres, detailed, monochrome, 1girl",
+    "1girl, smile\n",
+    "\n\n1girl, smile, dress\n\n",
+]

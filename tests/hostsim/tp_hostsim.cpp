@@ -1,0 +1,153 @@
+// TEST-ONLY harness: compiles the kernels' per-file pipeline source (tp_pipeline.h) and the
+// table compiler for the HOST so that the pipeline LOGIC can be checked against the oracle
+// in this GPU-less container.  It is not part of the product: nothing under
+// imagecaptioner_amd/ loads it, the C ABI never routes here, and the GPU tests do not use it.
+// The lane-interleaved workspace layout is kept exactly as the kernel uses it (lane = file & 63).
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tagpipe.h"
+#include "../../imagecaptioner_amd/csrc/tp_pipeline.h"
+#include "../../imagecaptioner_amd/csrc/tp_tables.hpp"
+
+using namespace tp;
+
+namespace {
+thread_local std::string g_err;
+
+struct Sim {
+    HostTables ht;
+    DevTables dt;
+};
+
+struct SimOut {
+    std::vector<uint8_t> captions;
+    std::vector<uint64_t> offsets, hist;
+    std::vector<tp_verdict> verdicts;
+    std::vector<uint32_t> fired;
+    std::vector<uint16_t> facets;
+    tp_counters ctr{};
+};
+
+uint32_t commas(const uint8_t* p, uint64_t n) { uint32_t c = 0; for (uint64_t i = 0; i < n; ++i) c += p[i] == ','; return c; }
+
+// Runs files [0,n) wave by wave; `emit` receives each file's final handle list.
+void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const double* scores, const uint8_t* sources, uint64_t n,
+         int mode, SimOut& o, std::vector<std::vector<H>>* fin_lists) {
+    const DevTables& t = s.dt;
+    o.offsets.assign(n + 1, 0);
+    o.verdicts.assign(n, tp_verdict{});
+    o.fired.assign(n * t.fired_words, 0);
+    o.facets.assign(n * t.n_facets, 0xFFFF);
+    o.hist.assign((size_t)t.n_strings + 1, 0);
+    std::memset(&o.ctr, 0, sizeof o.ctr);
+    if (fin_lists) fin_lists->assign(n, {});
+    for (uint64_t w0 = 0; w0 < n; w0 += 64) {
+        uint64_t w1 = std::min<uint64_t>(n, w0 + 64);
+        uint32_t T = 1, LB = 0;
+        for (uint64_t f = w0; f < w1; ++f) {
+            uint32_t tf, lf;
+            if (tag_begin) { tf = (uint32_t)(tag_begin[f + 1] - tag_begin[f]); lf = (uint32_t)(offsets[tag_begin[f + 1]] - offsets[tag_begin[f]]); }
+            else { lf = (uint32_t)(offsets[f + 1] - offsets[f]); tf = commas(arena + offsets[f], lf) + 1; }
+            T = std::max(T, tf); LB = std::max(LB, lf);
+        }
+        WsLayout L = ws_layout(T, LB, t.final_cap, t.evidence_grow, t.lit_words);
+        std::vector<uint8_t> wsmem(L.total, 0xCD);
+        for (uint64_t f = w0; f < w1; ++f) {
+            FileWs ws = ws_bind(wsmem.data(), L, (uint32_t)(f & 63));
+            FileIn in{};
+            if (tag_begin) { in.arena = arena; in.tag_offsets = offsets; in.tag_lo = tag_begin[f]; in.tag_hi = tag_begin[f + 1]; in.scores = scores; in.sources = sources; }
+            else { in.text = arena + offsets[f]; in.len = (uint32_t)(offsets[f + 1] - offsets[f]); }
+            FileOut fo;
+            process_file(t, in, ws, fo, t.fired_words ? &o.fired[f * t.fired_words] : nullptr, t.n_facets ? &o.facets[f * t.n_facets] : nullptr, mode);
+            o.verdicts[f] = fo.verdict;
+            if (fin_lists) for (uint32_t k = 0; k < fo.n_final; ++k) (*fin_lists)[f].push_back(ws.fin[k]);
+            // caption bytes (what k_emit writes)
+            size_t before = o.captions.size();
+            if (mode == 0 && fo.caption_len) {
+                for (uint32_t k = 0; k < fo.n_final; ++k) {
+                    H h = ws.fin[k];
+                    if (k) { o.captions.push_back(','); o.captions.push_back(' '); }
+                    if (h_is_dyn(h)) { o.captions.insert(o.captions.end(), ws.norm + h_off(h), ws.norm + h_off(h) + h_len(h)); o.hist[t.n_strings]++; }
+                    else { const uint8_t* p = str_ptr(t, h_id(h)); o.captions.insert(o.captions.end(), p, p + str_len(t, h_id(h))); o.hist[h_id(h)]++; }
+                }
+                o.captions.insert(o.captions.end(), t.newline, t.newline + t.newline_len);
+                if (o.captions.size() - before != fo.caption_len) { g_err = "caption_len mismatch"; }
+            }
+            o.offsets[f + 1] = o.captions.size();
+            uint8_t fl = fo.verdict.flags;
+            o.ctr.files++;
+            o.ctr.low += (fl & TP_F_LOW) != 0; o.ctr.action_eligible += (fl & TP_F_ELIGIBLE) != 0; o.ctr.action_footjob += (fl & TP_F_FOOTJOB) != 0;
+            o.ctr.fallback += (fl & TP_F_FALLBACK) != 0; o.ctr.line_rejected += (fl & TP_F_LINE_REJECTED) != 0; o.ctr.unsupported += (fl & TP_F_UNSUPPORTED) != 0;
+            o.ctr.safe_rejected += (fl & TP_F_SAFE_REJECT) != 0;
+        }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* sim_last_error(void) { return g_err.c_str(); }
+
+void* sim_create(const tp_config* cfg) {
+    try {
+        std::unique_ptr<Sim> s(new Sim());
+        compile_tables(*cfg, s->ht);
+        s->dt = bind_host_pointers(s->ht);
+        // minimal fallback line, as tp_create evaluates it (mode 1, weight 1.0, source OpenAI)
+        DevTables saved = s->dt;
+        s->dt.line_weight = 1.0;
+        s->dt.line_source = TP_SRC_OPENAI;
+        uint64_t offs[2] = {0, s->ht.fallback_line.size()};
+        SimOut o;
+        std::vector<std::vector<H>> fin;
+        std::vector<uint8_t> line = s->ht.fallback_line;
+        line.resize(line.size() + 16);
+        run(*s, line.data(), offs, nullptr, nullptr, nullptr, 1, 1, o, &fin);
+        s->dt = saved;
+        s->dt.n_fallback = (uint32_t)fin[0].size();
+        for (size_t k = 0; k < fin[0].size(); ++k) s->dt.fallback_ids[k] = (uint32_t)fin[0][k];
+        return s.release();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void sim_destroy(void* h) { delete (Sim*)h; }
+
+int sim_info(void* h, tp_table_info* out) {
+    Sim* s = (Sim*)h;
+    std::memset(out, 0, sizeof *out);
+    out->n_strings = s->dt.n_strings; out->n_action_rules = s->dt.n_rules; out->n_action_subtypes = s->dt.n_subs; out->n_facets = s->dt.n_facets;
+    out->fired_words = s->dt.fired_words; out->n_known_tags = s->ht.n_known; out->strict_known = s->ht.strict; out->known_found = s->ht.known_found;
+    return 0;
+}
+const char* sim_string(void* h, uint32_t id) { return ((Sim*)h)->ht.strings[id].c_str(); }
+
+struct sim_result {
+    uint64_t n_files; const uint8_t* captions; const uint64_t* offsets; const tp_verdict* verdicts; tp_counters counters;
+    const uint64_t* histogram; const uint32_t* fired; const uint16_t* facets; void* opaque;
+};
+static int finish(SimOut* o, uint64_t n, sim_result* r) {
+    r->n_files = n; r->captions = o->captions.data(); r->offsets = o->offsets.data(); r->verdicts = o->verdicts.data(); r->counters = o->ctr;
+    r->histogram = o->hist.data(); r->fired = o->fired.data(); r->facets = o->facets.data(); r->opaque = o;
+    return g_err.empty() ? 0 : -1;
+}
+int sim_run_lines(void* h, const uint8_t* arena, const uint64_t* offsets, uint64_t n, sim_result* r) {
+    g_err.clear();
+    SimOut* o = new SimOut();
+    run(*(Sim*)h, arena, offsets, nullptr, nullptr, nullptr, n, 0, *o, nullptr);
+    return finish(o, n, r);
+}
+int sim_run_scored(void* h, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const double* scores, const uint8_t* sources, uint64_t n,
+                   sim_result* r) {
+    g_err.clear();
+    SimOut* o = new SimOut();
+    run(*(Sim*)h, arena, tag_offsets, tag_begin, scores, sources, n, 0, *o, nullptr);
+    return finish(o, n, r);
+}
+void sim_release(sim_result* r) { delete (SimOut*)r->opaque; r->opaque = nullptr; }
+
+}  // extern "C"
