@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the batch tag pipeline on MI355X.
+
+One "step" is one pass of the whole hot path (tp_run_lines_device: workspace sizing, the per-file pipeline
+kernel, caption-offset scan, caption/histogram emit) over one resident shard of synthetic tag files, plus —
+on more than one GPU — the RCCL all-reduce of the tag histogram and counters.  Inputs are in HBM before
+the timed region starts.  Weak scaling: every rank owns `--files` files (default 1,000,000: BASELINE
+config 2, "1M tag files, ~40 tags/file, 20k-entry lexicon, single MI355X").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--files", type=int, default=1_000_000, help="files per GPU")
+    ap.add_argument("--config", default="c2", help="corpus configuration: c1..c5")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cpu-sample", type=int, default=40_000, help="files of the same corpus timed on the host cores (rank 0, 1 GPU only); 0 = skip")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the tag pipeline has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from imagecaptioner_amd import Config, TagPipe
+    from imagecaptioner_amd._abi import tp_device_io
+    from imagecaptioner_amd.corpus import make_corpus
+
+    # ---- synthetic shard of this rank (seeded; every rank draws its own files from the same tables) ----
+    t0 = time.time()
+    corpus = make_corpus(args.config, args.files, seed=args.seed + 7919 * rank)
+    gen_s = time.time() - t0
+    cfg = Config(device=local_rank, **corpus.config_kwargs)
+    pipe = TagPipe(cfg)
+    n = corpus.n_files
+    in_bytes = int(corpus.offsets[-1])
+
+    arena = torch.from_numpy(corpus.arena).to(dev)
+    arena = torch.cat([arena, torch.zeros(64, dtype=torch.uint8, device=dev)])
+    offsets = torch.from_numpy(corpus.offsets.astype(np.int64)).to(dev)
+    cap_capacity = max(4 * in_bytes, 1 << 20)
+    captions = torch.empty(cap_capacity, dtype=torch.uint8, device=dev)
+    cap_offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    verdicts = torch.empty(n * 16, dtype=torch.uint8, device=dev)
+    hist = torch.zeros(pipe.info.n_strings + 1, dtype=torch.int64, device=dev)
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+
+    io = tp_device_io()
+    io.arena, io.offsets, io.n_files = arena.data_ptr(), offsets.data_ptr(), n
+    io.captions, io.caption_capacity, io.caption_offsets = captions.data_ptr(), cap_capacity, cap_offsets.data_ptr()
+    io.verdicts, io.histogram, io.counters = verdicts.data_ptr(), hist.data_ptr(), counters.data_ptr()
+    io.fired, io.facet_choice = None, None
+    io.stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        hist.zero_()
+        counters.zero_()
+        nbytes = pipe.run_lines_device(io)
+        if world > 1:
+            dist.all_reduce(hist)        # RCCL sum over xGMI: the corpus-wide tag histogram
+            dist.all_reduce(counters)
+        return nbytes
+
+    for _ in range(args.warmup):
+        step()
+    sel_ms, emit_ms, tot_ms = [], [], []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    cap_bytes = 0
+    for _ in range(args.steps):
+        cap_bytes = step()
+        tm = pipe.last_timing()        # HIP events recorded by the library on the stream its kernels run on
+        sel_ms.append(tm["select_ms"]); emit_ms.append(tm["emit_ms"]); tot_ms.append(tm["total_ms"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness spot check outside the timed region: device result == oracle on a prefix ----
+    check_n = min(n, 2000)
+    from oracle.oracle_py import Oracle
+    oracle = Oracle(Config(**corpus.config_kwargs))
+    want = oracle.run_lines(corpus.arena, corpus.offsets[:check_n + 1], threads=8)
+    got_off = cap_offsets[:check_n + 1].cpu().numpy().astype(np.uint64)
+    got_cap = captions[:int(got_off[-1])].cpu().numpy()
+    ok = bool(np.array_equal(got_off, want.caption_offsets) and np.array_equal(got_cap, want.captions) and
+              verdicts[:check_n * 16].cpu().numpy().tobytes() == want.verdicts.tobytes())
+    if not ok:
+        raise SystemExit("bench.py: device captions differ from the oracle on the first %d files" % check_n)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    files_total = n * world
+    value = files_total * args.steps / elapsed
+    # algorithmic bytes per file: input line + input offset + caption line + caption offset + verdict record
+    alg_bytes = in_bytes + 8 * n + int(cap_bytes) + 8 * n + 16 * n
+    sel_avg = float(np.mean(sel_ms))
+    achieved = alg_bytes / (sel_avg * 1e-3) / 1e9
+    traffic = None
+    try:
+        with open(args.traffic_json) as f:
+            tj = json.load(f)
+        if tj.get("workload") == "%s:%d" % (args.config, n):
+            traffic = tj.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+
+    out = {
+        "metric": "tag files captioned/sec (whole node)",
+        "value": value,
+        "unit": "files/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "%s: %d files/GPU, %.1f tags/file in, 20k-entry vocabulary + lexicon" % (args.config, n, float(np.mean(np.diff(corpus.offsets.astype(np.int64)))) / 14.2)
+                   if args.config in ("c2", "c4") else "%s: %d files/GPU" % (args.config, n),
+                   "files_per_gpu": n, "input_bytes_per_file": in_bytes / n, "caption_bytes_per_file": cap_bytes / n,
+                   "kernel_ms": {"pipeline": sel_avg, "emit": float(np.mean(emit_ms)), "all_kernels": float(np.mean(tot_ms))},
+                   "parallelism": "files sharded by rank; histogram all-reduce (RCCL)" if world > 1 else "single GPU",
+                   "corpus_gen_s": gen_s},
+        "roofline": {"bound": "hbm", "kernel": "k_pipeline", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sel_avg},
+    }
+
+    if world == 1 and args.cpu_sample > 0:
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        m = min(n, args.cpu_sample)
+        t1 = time.perf_counter()
+        oracle.run_lines(corpus.arena, corpus.offsets[:m + 1], threads=threads)
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": m / dt, "unit": "files/s", "cores": threads, "kind": "port",
+                               "sample": "first %d files of the same corpus, C++ restatement of Program.cs (not the .NET binary), %d threads, %.1f s" % (m, threads, dt)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

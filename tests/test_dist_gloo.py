@@ -1,0 +1,62 @@
+"""The multi-GPU layout on CPU: world_size-2 gloo ranks each own a contiguous shard of the files; the summed
+histograms / counters and the concatenated captions must equal the single-process result.  The per-shard work is
+done by the oracle here (no GPU in this container); on the GPU box the same sharding feeds tp_run_lines_device."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import Config, Oracle
+from imagecaptioner_amd.corpus import make_corpus
+from imagecaptioner_amd.dist import allreduce_sum_, shard_offsets, shard_range
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 64, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n_files, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = make_corpus("c1", n_files, seed=5)
+    o = Oracle(Config(**c.config_kwargs))
+    b, e = shard_range(n_files, rank, world)
+    offs, first = shard_offsets(c.offsets, b, e)
+    r = o.run_lines(c.arena[first:first + int(offs[-1])], offs)
+    vocab = sorted(Oracle(Config(**c.config_kwargs)).run_lines(c.arena, c.offsets).histogram)   # a common tag order for the dense vector
+    hist = torch.tensor([r.histogram.get(t, 0) for t in vocab], dtype=torch.int64)
+    ctr = torch.tensor([r.counters[k] for k in sorted(r.counters)], dtype=torch.int64)
+    allreduce_sum_([hist, ctr])
+    np.save(os.path.join(out_dir, "cap%d.npy" % rank), r.captions)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "hist.npy"), hist.numpy())
+        np.save(os.path.join(out_dir, "ctr.npy"), ctr.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_reproduce_single_process(tmp_path):
+    world, n_files = 2, 301
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(world, port, n_files, str(tmp_path)), nprocs=world, join=True)
+    c = make_corpus("c1", n_files, seed=5)
+    whole = Oracle(Config(**c.config_kwargs)).run_lines(c.arena, c.offsets)
+    caps = np.concatenate([np.load(tmp_path / ("cap%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(caps, whole.captions)
+    vocab = sorted(whole.histogram)
+    assert list(np.load(tmp_path / "hist.npy")) == [whole.histogram[t] for t in vocab]
+    assert list(np.load(tmp_path / "ctr.npy")) == [whole.counters[k] for k in sorted(whole.counters)]

@@ -1,0 +1,171 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle — bit-exact on caption bytes,
+caption offsets, verdict records, fired-rule bitmaps, facet choices, counters and the tag histogram."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import EDGE_LINES, Config, Oracle, assert_same_results, pack_lines, shipped_config
+from test_pipeline_logic_cpu import CONFIGS, fuzz_lines, scored_inputs
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def pipe_for(cfg):
+    from imagecaptioner_amd import TagPipe
+    return TagPipe(cfg)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_edge_and_fuzz_lines(name):
+    cfg = CONFIGS[name]()
+    lines = EDGE_LINES + fuzz_lines(11, 3000)
+    p = pipe_for(cfg)
+    got, want = p.run_texts(lines), Oracle(cfg).run_texts(lines)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name)
+
+
+def test_edge_lines_match_committed_golden():
+    with open(os.path.join(GOLDEN, "edge_lines.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    from golden.make_golden import CONFIGS as GC
+    for name in sorted(GC):
+        got = pipe_for(GC[name]()).run_texts(g["lines"])
+        for i, exp in enumerate(g["expected"][name]):
+            assert got.caption(i).decode("utf-8") == exp["caption"], (name, i)
+            assert [int(x) for x in got.verdicts[i]] == exp["verdict"], (name, i)
+
+
+@pytest.mark.parametrize("name,n", [("c1", 4000), ("c2", 6000), ("c3", 3000), ("c4", 3000), ("c5", 1500)])
+def test_benchmark_corpora(name, n):
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus(name, n, seed=4242)
+    cfg = Config(**c.config_kwargs)
+    p = pipe_for(cfg)
+    got, want = p.run_lines(c.arena, c.offsets), Oracle(cfg).run_lines(c.arena, c.offsets, threads=16)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
+def test_corpus_digests_match_committed_golden(name):
+    from imagecaptioner_amd.corpus import make_corpus
+    with open(os.path.join(GOLDEN, "corpus_digests.json")) as f:
+        g = json.load(f)[name]
+    c = make_corpus(name, g["n_files"])
+    p = pipe_for(Config(**c.config_kwargs))
+    r = p.run_lines(c.arena, c.offsets)
+    assert hashlib.sha256(r.captions.tobytes()).hexdigest() == g["captions_sha256"]
+    assert hashlib.sha256(r.verdicts.tobytes()).hexdigest() == g["verdicts_sha256"]
+    assert r.counters == g["counters"]
+    top = sorted(p.histogram_dict(r.histogram).items(), key=lambda kv: (-kv[1], kv[0]))[:20]
+    assert top == [tuple(x) for x in g["top_tags"]]
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict", "builtin"])
+def test_scored_ingest(name):
+    cfg = CONFIGS[name]()
+    args = scored_inputs(5, 1500)
+    p = pipe_for(cfg)
+    got, want = p.run_scored(*args), Oracle(cfg).run_scored(*args)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name + " scored")
+
+
+def test_empty_and_ragged_batches():
+    cfg = shipped_config()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    r = p.run_texts([])
+    assert r.n_files == 0 and len(r.captions) == 0 and r.counters["files"] == 0
+    for lines in (["1girl, smile"], [""] * 65, ["1girl, smile, dress"] * 64 + [""], [", ".join(["long_hair"] * 3000)], ["x" * 70000]):
+        got, want = p.run_texts(lines), o.run_texts(lines)
+        assert_same_results(got, want, p.histogram_dict(got.histogram), "ragged")
+
+
+def test_non_ascii_is_reported_not_guessed():
+    p = pipe_for(shipped_config())
+    r = p.run_texts(["1girl, smile, dress", "1girl, café, dress", "1girl, 青い髪"])
+    assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
+    assert r.caption(1) == b"" and r.caption(2) == b"" and r.counters["unsupported"] == 2
+
+
+def test_workspace_chunking_gives_identical_results(monkeypatch):
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus("c2", 5000, seed=31)
+    cfg = Config(**c.config_kwargs)
+    whole = pipe_for(cfg).run_lines(c.arena, c.offsets)
+    monkeypatch.setenv("TAGPIPE_WORKSPACE_BYTES", str(4 << 20))   # forces many chunks
+    p = pipe_for(cfg)
+    chunked = p.run_lines(c.arena, c.offsets)
+    assert np.array_equal(whole.captions, chunked.captions) and np.array_equal(whole.caption_offsets, chunked.caption_offsets)
+    assert whole.verdicts.tobytes() == chunked.verdicts.tobytes() and whole.counters == chunked.counters
+    assert np.array_equal(whole.histogram, chunked.histogram)
+
+
+def test_device_api_capacity_and_accumulation():
+    import torch
+    from imagecaptioner_amd._abi import TP_E_CAPACITY, tp_device_io
+    from imagecaptioner_amd import TagPipeError
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus("c1", 3000, seed=8)
+    cfg = Config(**c.config_kwargs)
+    p = pipe_for(cfg)
+    host = p.run_lines(c.arena, c.offsets)
+    dev = torch.device("cuda", 0)
+    arena = torch.cat([torch.from_numpy(c.arena).to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)])
+    offsets = torch.from_numpy(c.offsets.astype(np.int64)).to(dev)
+    n = c.n_files
+    caps = torch.empty(len(host.captions), dtype=torch.uint8, device=dev)
+    cap_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ver = torch.empty(n * 16, dtype=torch.uint8, device=dev)
+    hist = torch.zeros(p.info.n_strings + 1, dtype=torch.int64, device=dev)
+    ctr = torch.zeros(8, dtype=torch.int64, device=dev)
+    io = tp_device_io()
+    io.arena, io.offsets, io.n_files = arena.data_ptr(), offsets.data_ptr(), n
+    io.captions, io.caption_capacity, io.caption_offsets = caps.data_ptr(), len(host.captions) - 1, cap_off.data_ptr()
+    io.verdicts, io.histogram, io.counters = ver.data_ptr(), hist.data_ptr(), ctr.data_ptr()
+    io.stream = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(TagPipeError) as e:
+        p.run_lines_device(io)
+    assert e.value.code == TP_E_CAPACITY and e.value.required == len(host.captions)
+    io.caption_capacity = len(host.captions)
+    hist.zero_(); ctr.zero_()
+    assert p.run_lines_device(io) == len(host.captions)
+    p.run_lines_device(io)            # histogram and counters accumulate across calls
+    torch.cuda.synchronize()
+    assert np.array_equal(caps.cpu().numpy(), host.captions)
+    assert np.array_equal(cap_off.cpu().numpy().astype(np.uint64), host.caption_offsets)
+    assert ver.cpu().numpy().tobytes() == host.verdicts.tobytes()
+    assert np.array_equal(hist.cpu().numpy()[:-1].astype(np.uint64), 2 * host.histogram)
+    assert int(ctr[0]) == 2 * n
+
+
+def test_full_size_properties():
+    """BASELINE config 2 at full size (1M files): properties that need no oracle run — shard concatenation equals the
+    whole batch, the histogram sums to the number of caption tags, reruns are deterministic — plus oracle parity on a prefix."""
+    from imagecaptioner_amd.corpus import make_corpus
+    n = 1_000_000
+    c = make_corpus("c2", n, seed=1234)
+    cfg = Config(**c.config_kwargs)
+    p = pipe_for(cfg)
+    whole = p.run_lines(c.arena, c.offsets)
+    assert whole.counters["files"] == n and whole.counters["unsupported"] == 0
+    assert int(whole.histogram.sum()) + whole.histogram_other == int(whole.verdicts["n_tags"].astype(np.int64).sum())
+    again = p.run_lines(c.arena, c.offsets)
+    assert hashlib.sha256(again.captions.tobytes()).digest() == hashlib.sha256(whole.captions.tobytes()).digest()
+    # two shards, concatenated
+    half = n // 2
+    first = int(c.offsets[half])
+    a = p.run_lines(c.arena[:first], c.offsets[:half + 1])
+    b = p.run_lines(c.arena[first:], c.offsets[half:] - c.offsets[half])
+    assert np.array_equal(np.concatenate([a.captions, b.captions]), whole.captions)
+    assert np.array_equal(a.histogram + b.histogram, whole.histogram)
+    m = 20000
+    want = Oracle(cfg).run_lines(c.arena, c.offsets[:m + 1], threads=16)
+    assert np.array_equal(whole.captions[:int(whole.caption_offsets[m])], want.captions)
+    assert whole.verdicts[:m].tobytes() == want.verdicts.tobytes()

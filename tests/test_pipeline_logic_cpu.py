@@ -1,0 +1,114 @@
+"""Logic check of the kernels' per-file pipeline source without a GPU.
+
+tests/hostsim compiles imagecaptioner_amd/csrc/tp_pipeline.h and the table compiler for the host (test-only;
+the product library never does) and runs files through the same lane-interleaved workspace layout the kernel
+uses.  Results must be bit-identical to the oracle's.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import DATA, EDGE_LINES, Config, HostSim, Oracle, assert_same_results, shipped_config
+from imagecaptioner_amd.corpus import make_corpus
+
+CONFIGS = {
+    "shipped": lambda: shipped_config(),
+    "shipped_nonstrict": lambda: shipped_config(strict_known=False, strict_known_explicit=True),
+    "builtin": lambda: Config(trigger="trigger_token", minimal_subject_tags="1girl", no_profile=True),
+    "novocab_w07_crlf": lambda: shipped_config(vocabulary=None, profile=None, trigger="My Trigger", auto_prefix_tags="1girl, solo",
+                                               minimal_subject_tags="smile", safe_mode=False, newline="\r\n", line_weight=0.7),
+    "allow_deny": lambda: shipped_config(allowlist=b"# comment\n1girl\nsmile\n", denylist=b"dress\nlong hair\n"),
+}
+
+
+def fuzz_lines(seed, n):
+    rng = random.Random(seed)
+    vocab = [l.strip() for l in open(DATA + "/top_tags.txt") if l.strip()][:600]
+    pool = vocab + ["pedal stimulation", "foot", "soles", "fingers", "licking", "fellatio", "sexual_intercourse", "barefoot", "toes", "penis", "feet",
+                    "hand", "grip", "between_feet", "cum", "ejaculation", "male_pov", "no_panties", "1boy", "text", "unknown_thing", "zzz_not_in_vocab",
+                    "my_oc_name", "some random words", "watermark_big", "rating_x"]
+    junk = ["'", '"', "`", ".", ";", " ", "  ", "_", "__", "\t", "\n", "\r\n", ":", "!", "(", ")", "/", "-", ",", "A", "Z", "x", "9", "sorry",
+            "POSITIVE:", "NEGATIVE:", "```", "i can't", "watermark", "rating"]
+    out = []
+    for _ in range(n):
+        k = rng.choice([0, 1, 2, 3, 5, 8, 13, 30, 60, 100])
+        toks = []
+        for _ in range(k):
+            r = rng.random()
+            t = rng.choice(pool)
+            if r < 0.15:
+                t = t.upper()
+            elif r < 0.25:
+                t = t.replace("_", " ")
+            elif r < 0.35:
+                t = rng.choice(junk) + t + rng.choice(junk)
+            elif r < 0.40:
+                t = t + rng.choice(["'", "'.", "\".", "';.", "`..", ".'.'"])
+            elif r < 0.45:
+                t = "".join(rng.choice("abcxyz_09 '.-") for _ in range(rng.randint(0, 12)))
+            elif r < 0.47:
+                t = rng.choice(junk)
+            toks.append(t)
+        line = rng.choice([", ", ",", " , ", ",  "]).join(toks)
+        if rng.random() < 0.1:
+            line = rng.choice(junk) + line + rng.choice(junk)
+        out.append(line)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_edge_and_fuzz_lines(name):
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    lines = EDGE_LINES + fuzz_lines(11, 1200)
+    want, got = o.run_texts(lines), s.run_texts(lines)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name)
+
+
+@pytest.mark.parametrize("name,n", [("c1", 600), ("c2", 800), ("c3", 500), ("c4", 500), ("c5", 200)])
+def test_benchmark_corpora(name, n):
+    c = make_corpus(name, n, seed=77)
+    cfg = Config(**c.config_kwargs)
+    o, s = Oracle(cfg), HostSim(cfg)
+    want, got = o.run_lines(c.arena, c.offsets, threads=8), s.run_lines(c.arena, c.offsets)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name)
+
+
+def scored_inputs(seed, n_files):
+    rng = random.Random(seed)
+    vocab = [l.strip() for l in open(DATA + "/top_tags.txt") if l.strip()][:400] + ["foot", "fingers", "Pedal Stimulation", "zz_unknown", "x'.", "", " ", "a"]
+    tags, begin, scores, sources = [], [0], [], []
+    for _ in range(n_files):
+        k = rng.choice([0, 1, 3, 10, 40, 90])
+        for _ in range(k):
+            tags.append(rng.choice(vocab))
+            scores.append(round(rng.random(), 2) if rng.random() < 0.8 else rng.choice([0.28, 0.6, 0.5, 0.53, 0.47]))
+            sources.append(rng.choice([0, 0, 1, 2]))
+        begin.append(len(tags))
+    enc = [t.encode() for t in tags]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs[1:] = np.cumsum([len(b) for b in enc])
+    arena = np.frombuffer(b"".join(enc), dtype=np.uint8).copy() if enc else np.zeros(0, np.uint8)
+    return arena, offs, np.array(begin, dtype=np.uint64), np.array(scores, dtype=np.float64), np.array(sources, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict", "builtin"])
+def test_scored_ingest(name):
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    args = scored_inputs(5, 400)
+    want, got = o.run_scored(*args), s.run_scored(*args)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name + " scored")
+
+
+def test_non_ascii_is_reported_not_guessed():
+    cfg = shipped_config()
+    s = HostSim(cfg)
+    r = s.run_texts(["1girl, smile, dress", "1girl, café, dress", "1girl, 青い髪"])
+    assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
+    assert r.caption(1) == b"" and r.caption(2) == b""
+    assert r.counters["unsupported"] == 2
