@@ -93,7 +93,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sel_ms, emit_ms, tot_ms = [], [], []
+    sel_ms, gen_ms, emit_ms, tot_ms, gen_files = [], [], [], [], 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -102,7 +102,8 @@ def main():
     for _ in range(args.steps):
         cap_bytes = step()
         tm = pipe.last_timing()        # HIP events recorded by the library on the stream its kernels run on
-        sel_ms.append(tm["select_ms"]); emit_ms.append(tm["emit_ms"]); tot_ms.append(tm["total_ms"])
+        sel_ms.append(tm["select_ms"]); gen_ms.append(tm["general_ms"]); emit_ms.append(tm["emit_ms"]); tot_ms.append(tm["total_ms"])
+        gen_files = tm["general_files"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -133,7 +134,10 @@ def main():
     value = files_total * args.steps / elapsed
     # algorithmic bytes per file: input line + input offset + caption line + caption offset + verdict record
     alg_bytes = in_bytes + 8 * n + int(cap_bytes) + 8 * n + 16 * n
-    sel_avg = float(np.mean(sel_ms))
+    # the dominant kernel: the wave-per-file pipeline kernel, or the general thread-per-file one when it took longer
+    fast_avg, gen_avg = float(np.mean(sel_ms)), float(np.mean(gen_ms))
+    dominant = "k_fast" if fast_avg >= gen_avg else "k_pipeline"
+    sel_avg = max(fast_avg, gen_avg)
     achieved = alg_bytes / (sel_avg * 1e-3) / 1e9
     traffic = None
     try:
@@ -157,13 +161,13 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "%s: %d files/GPU, %.1f tags/file in, 20k-entry vocabulary + lexicon" % (args.config, n, float(np.mean(np.diff(corpus.offsets.astype(np.int64)))) / 14.2)
-                   if args.config in ("c2", "c4") else "%s: %d files/GPU" % (args.config, n),
+        "config": {"workload": "%s: %d tag files per GPU, %.0f input bytes/file" % (args.config, n, in_bytes / n),
                    "files_per_gpu": n, "input_bytes_per_file": in_bytes / n, "caption_bytes_per_file": cap_bytes / n,
-                   "kernel_ms": {"pipeline": sel_avg, "emit": float(np.mean(emit_ms)), "all_kernels": float(np.mean(tot_ms))},
+                   "kernel_ms": {"k_fast": fast_avg, "k_pipeline": gen_avg, "k_emit": float(np.mean(emit_ms)), "first_to_last_kernel": float(np.mean(tot_ms))},
+                   "files_in_general_kernel": int(gen_files),
                    "parallelism": "files sharded by rank; histogram all-reduce (RCCL)" if world > 1 else "single GPU",
                    "corpus_gen_s": gen_s},
-        "roofline": {"bound": "hbm", "kernel": "k_pipeline", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sel_avg},
     }
 

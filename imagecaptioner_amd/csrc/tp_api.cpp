@@ -71,17 +71,19 @@ struct tp_ctx {
     HostTables ht;
     DevTables dt;
     std::vector<void*> table_mem;
-    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, scalars, workspace;
+    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, scalars, workspace;
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
     std::vector<hipEvent_t> events;
     tp_timing timing{};
-    size_t ws_budget = (size_t)8 << 30;
+    size_t ws_budget = (size_t)64 << 30;
+    bool no_fast = false;            // TAGPIPE_NO_FAST=1: every file takes the general kernel (testing aid)
+    uint64_t last_slow = 0;
 
     ~tp_ctx() {
         (void)hipSetDevice(device);
         for (void* p : table_mem) (void)hipFree(p);
-        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
+        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -102,16 +104,119 @@ struct RunIo {
     hipStream_t stream; int mode;
 };
 
-// The device-side run: sizes -> workspace offsets -> per chunk {pipeline, caption offsets, emit}.
+// One range of files [f0, f1): wave-per-file kernel, general kernel for what it declined, caption offsets, emit.
+// When the general kernel's workspace would exceed the budget the range is halved and each half runs on its own.
+struct RunState {
+    uint64_t total = 0;          // caption bytes so far (host copy of the device running total)
+    int chunk = 0;               // parity of the device running-total slot
+    bool over_capacity = false;
+    size_t ev = 2;               // next free event
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> fast_ev, pipe_ev, emit_ev;
+};
+
+int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
+    hipStream_t s = io.stream;
+    const uint64_t n = f1 - f0;
+    uint64_t* d_total = c->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
+    uint32_t* d_status = (uint32_t*)(d_total + 2);
+    uint32_t* d_slow_count = d_status + 1;
+    const bool use_fast = c->dt.fast_ok && !io.tag_begin && io.mode == 0 && !c->no_fast;
+
+    c->cap_len.need(n * 4); c->n_final.need(n * 4); c->slot_of.need(n * 4);
+    uint32_t* cap_len = c->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
+    uint32_t* n_final = c->n_final.as<uint32_t>() - f0;
+    uint32_t* slot_of = c->slot_of.as<uint32_t>() - f0;
+    uint32_t n_slow = (uint32_t)n;
+    const uint32_t* item_list = nullptr;
+    if (use_fast) {
+        c->fin32.need(n * fast_fin_stride() * 4);
+        c->slow_list.need(n * 4);
+        HIP_OK(hipMemsetAsync(d_slow_count, 0, 4, s));
+        FastArgs fa{};
+        fa.arena = io.arena; fa.offsets = io.offsets; fa.file0 = f0; fa.file_end = f1;
+        fa.verdicts = io.verdicts; fa.n_final = n_final; fa.cap_len = cap_len; fa.fin32 = c->fin32.as<uint32_t>(); fa.slot_of = slot_of;
+        fa.slow_list = c->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.fired = io.fired; fa.facet_choice = io.facet_choice;
+        hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
+        HIP_OK(hipEventRecord(p0, s));
+        HIP_OK(launch_fast(c->dt, fa, s));
+        HIP_OK(hipEventRecord(p1, s));
+        st.fast_ev.emplace_back(p0, p1);
+        HIP_OK(hipMemcpyAsync(&n_slow, d_slow_count, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        item_list = c->slow_list.as<uint32_t>();
+    }
+    c->last_slow += n_slow;
+    if (n_slow) {
+        const uint64_t n_waves = ((uint64_t)n_slow + 63) / 64;
+        c->wave_T.need(n_waves * 4); c->wave_LB.need(n_waves * 4); c->wave_bytes.need(n_waves * 8); c->wave_off.need((n_waves + 1) * 8);
+        c->tile_sums.need(scan_tiles_needed(std::max<uint64_t>(n, n_waves)) * 8);
+        HIP_OK(launch_wave_sizes(c->dt, io.arena, io.offsets, io.tag_begin, item_list, f0, n_slow, c->wave_T.as<uint32_t>(), c->wave_LB.as<uint32_t>(),
+                                 c->wave_bytes.as<uint64_t>(), d_status, s));
+        HIP_OK(launch_scan_u64(c->wave_bytes.as<uint64_t>(), n_waves, c->wave_off.as<uint64_t>(), c->tile_sums.as<uint64_t>(), nullptr, nullptr, s));
+        uint64_t ws_bytes = 0;
+        uint32_t status = 0;
+        HIP_OK(hipMemcpyAsync(&ws_bytes, c->wave_off.as<uint64_t>() + n_waves, 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (status) return fail(TP_E_INVALID_ARG, "a file is longer than 2 GiB");
+        if (ws_bytes > c->ws_budget && n > 64) {
+            uint64_t mid = f0 + n / 2;
+            c->last_slow -= n_slow;
+            int rc = run_range(c, io, f0, mid, st);
+            if (rc != TP_OK && rc != TP_E_CAPACITY) return rc;
+            return run_range(c, io, mid, f1, st);
+        }
+        c->workspace.need(ws_bytes);
+        PipelineArgs pa{};
+        pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
+        pa.item_list = item_list; pa.file0 = f0; pa.n_items = n_slow;
+        pa.wave_T = c->wave_T.as<uint32_t>(); pa.wave_LB = c->wave_LB.as<uint32_t>(); pa.wave_off = c->wave_off.as<uint64_t>();
+        pa.workspace = c->workspace.as<uint8_t>();
+        pa.verdicts = io.verdicts; pa.n_final = n_final; pa.cap_len = cap_len; pa.slot_of = slot_of;
+        pa.fired = io.fired; pa.facet_choice = io.facet_choice; pa.mode = io.mode;
+        hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
+        HIP_OK(hipEventRecord(p0, s));
+        HIP_OK(launch_pipeline(c->dt, pa, s));
+        HIP_OK(hipEventRecord(p1, s));
+        st.pipe_ev.emplace_back(p0, p1);
+    } else {
+        c->tile_sums.need(scan_tiles_needed(n) * 8);
+    }
+    // caption offsets of the range, continuing the running total
+    HIP_OK(launch_scan_u32(c->cap_len.as<uint32_t>(), n, io.caption_offsets + f0, c->tile_sums.as<uint64_t>(), d_total + (st.chunk & 1),
+                           d_total + ((st.chunk + 1) & 1), s));
+    HIP_OK(hipMemcpyAsync(&st.total, d_total + ((st.chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    ++st.chunk;
+    if (io.mode != 0) return TP_OK;
+    if (io.grow_captions) {
+        c->out_captions.need(std::max<uint64_t>(st.total, 16), true, s);
+        io.captions = c->out_captions.as<uint8_t>();
+        io.caption_capacity = c->out_captions.cap;
+    }
+    if (st.total > io.caption_capacity) st.over_capacity = true;
+    if (st.over_capacity) return TP_E_CAPACITY;
+    EmitArgs ea{};
+    ea.file0 = f0; ea.file_end = f1;
+    ea.wave_T = c->wave_T.as<uint32_t>(); ea.wave_LB = c->wave_LB.as<uint32_t>(); ea.wave_off = c->wave_off.as<uint64_t>(); ea.workspace = c->workspace.as<uint8_t>();
+    ea.fin32 = c->fin32.as<uint32_t>(); ea.slot_of = slot_of; ea.n_final = n_final;
+    ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
+    ea.histogram = io.histogram; ea.counters = io.counters;
+    hipEvent_t q0 = c->event(st.ev++), q1 = c->event(st.ev++);
+    HIP_OK(hipEventRecord(q0, s));
+    HIP_OK(launch_emit(c->dt, ea, s));
+    HIP_OK(hipEventRecord(q1, s));
+    st.emit_ev.emplace_back(q0, q1);
+    return TP_OK;
+}
+
 int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes) {
     HIP_OK(hipSetDevice(c->device));
     hipStream_t s = io.stream;
     const uint64_t n = io.n_files;
-    const uint64_t n_waves = (n + 63) / 64;
     c->timing = tp_timing{};
+    c->last_slow = 0;
     c->scalars.need(64);
-    uint64_t* d_total = c->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
-    uint32_t* d_status = (uint32_t*)(d_total + 2);
     HIP_OK(hipMemsetAsync(c->scalars.p, 0, 64, s));
     if (n == 0) {
         HIP_OK(hipMemsetAsync(io.caption_offsets, 0, 8, s));
@@ -119,81 +224,29 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes) {
         if (caption_bytes) *caption_bytes = 0;
         return TP_OK;
     }
-    c->wave_T.need(n_waves * 4); c->wave_LB.need(n_waves * 4); c->wave_bytes.need(n_waves * 8); c->wave_off.need((n_waves + 1) * 8);
-    c->tile_sums.need(scan_tiles_needed(std::max(n, n_waves)) * 8);
-    c->cap_len.need(n * 4); c->n_final.need(n * 4);
-
-    size_t ev = 0;
-    hipEvent_t e_begin = c->event(ev++), e_end = c->event(ev++);
+    RunState st;
+    hipEvent_t e_begin = c->event(0), e_end = c->event(1);
     HIP_OK(hipEventRecord(e_begin, s));
-    HIP_OK(launch_wave_sizes(c->dt, io.arena, io.offsets, io.tag_begin, n, c->wave_T.as<uint32_t>(), c->wave_LB.as<uint32_t>(), c->wave_bytes.as<uint64_t>(), d_status, s));
-    HIP_OK(launch_scan_u64(c->wave_bytes.as<uint64_t>(), n_waves, c->wave_off.as<uint64_t>(), c->tile_sums.as<uint64_t>(), nullptr, nullptr, s));
-    std::vector<uint64_t> wave_off(n_waves + 1);
-    uint32_t status = 0;
-    HIP_OK(hipMemcpyAsync(wave_off.data(), c->wave_off.p, (n_waves + 1) * 8, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    if (status) return fail(TP_E_INVALID_ARG, "a file is longer than 2 GiB");
-
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pipe_ev, emit_ev;
-    uint64_t total = 0;
-    bool over_capacity = false;
-    int chunk = 0;
-    for (uint64_t w0 = 0; w0 < n_waves;) {
-        uint64_t w1 = w0 + 1;
-        while (w1 < n_waves && wave_off[w1 + 1] - wave_off[w0] <= c->ws_budget) ++w1;
-        c->workspace.need(wave_off[w1] - wave_off[w0]);
-        uint64_t f0 = w0 * 64, f1 = std::min(n, w1 * 64);
-        PipelineArgs pa{};
-        pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
-        pa.file0 = f0; pa.file_end = f1;
-        pa.wave_T = c->wave_T.as<uint32_t>(); pa.wave_LB = c->wave_LB.as<uint32_t>(); pa.wave_off = c->wave_off.as<uint64_t>();
-        pa.workspace = c->workspace.as<uint8_t>();
-        pa.verdicts = io.verdicts; pa.n_final = c->n_final.as<uint32_t>(); pa.cap_len = c->cap_len.as<uint32_t>();
-        pa.fired = io.fired; pa.facet_choice = io.facet_choice; pa.mode = io.mode;
-        hipEvent_t p0 = c->event(ev++), p1 = c->event(ev++);
-        HIP_OK(hipEventRecord(p0, s));
-        HIP_OK(launch_pipeline(c->dt, pa, s));
-        HIP_OK(hipEventRecord(p1, s));
-        pipe_ev.emplace_back(p0, p1);
-        // caption offsets of the chunk, continuing the running total
-        HIP_OK(launch_scan_u32(c->cap_len.as<uint32_t>() + f0, f1 - f0, io.caption_offsets + f0, c->tile_sums.as<uint64_t>(), d_total + (chunk & 1),
-                               d_total + ((chunk + 1) & 1), s));
-        HIP_OK(hipMemcpyAsync(&total, d_total + ((chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        if (io.mode == 0) {
-            if (io.grow_captions) {
-                c->out_captions.need(std::max<uint64_t>(total, 16), true, s);
-                io.captions = c->out_captions.as<uint8_t>();
-                io.caption_capacity = c->out_captions.cap;
-            }
-            if (total > io.caption_capacity) over_capacity = true;
-            if (!over_capacity) {
-                EmitArgs ea{};
-                ea.file0 = f0; ea.file_end = f1;
-                ea.wave_T = pa.wave_T; ea.wave_LB = pa.wave_LB; ea.wave_off = pa.wave_off; ea.workspace = pa.workspace;
-                ea.n_final = pa.n_final; ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
-                ea.histogram = io.histogram; ea.counters = io.counters;
-                hipEvent_t q0 = c->event(ev++), q1 = c->event(ev++);
-                HIP_OK(hipEventRecord(q0, s));
-                HIP_OK(launch_emit(c->dt, ea, s));
-                HIP_OK(hipEventRecord(q1, s));
-                emit_ev.emplace_back(q0, q1);
-            }
-        }
-        w0 = w1;
-        ++chunk;
+    int rc = TP_OK;
+    const uint64_t range_max = (uint64_t)1 << 24;              // files per range: bounds the per-range index buffers
+    for (uint64_t f0 = 0; f0 < n; f0 += range_max) {
+        int r = run_range(c, io, f0, std::min(n, f0 + range_max), st);
+        if (r != TP_OK) rc = r;
+        if (r != TP_OK && r != TP_E_CAPACITY) break;
     }
     HIP_OK(hipEventRecord(e_end, s));
     HIP_OK(hipStreamSynchronize(s));
+    if (rc != TP_OK && rc != TP_E_CAPACITY) return rc;
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, e_begin, e_end));
     c->timing.total_ms = ms;
-    for (auto& p : pipe_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.select_ms += ms; }
-    for (auto& p : emit_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.emit_ms += ms; }
-    c->timing.other_ms = c->timing.total_ms - c->timing.select_ms - c->timing.emit_ms;
-    if (caption_bytes) *caption_bytes = total;
-    if (over_capacity) return fail(TP_E_CAPACITY, "caption buffer too small: " + std::to_string(total) + " bytes needed");
+    for (auto& p : st.fast_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.select_ms += ms; }
+    for (auto& p : st.pipe_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.general_ms += ms; }
+    for (auto& p : st.emit_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.emit_ms += ms; }
+    c->timing.other_ms = c->timing.total_ms - c->timing.select_ms - c->timing.general_ms - c->timing.emit_ms;
+    c->timing.general_files = c->last_slow;
+    if (caption_bytes) *caption_bytes = st.total;
+    if (st.over_capacity) return fail(TP_E_CAPACITY, "caption buffer too small: " + std::to_string(st.total) + " bytes needed");
     return TP_OK;
 }
 
@@ -316,13 +369,14 @@ void compute_fallback(tp_ctx* c) {
     HIP_OK(hipMemcpy(&T, c->wave_T.p, 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(&LB, c->wave_LB.p, 4, hipMemcpyDeviceToHost));
     WsLayout lay = ws_layout(T, LB, c->dt.final_cap, c->dt.evidence_grow, c->dt.lit_words);
-    c->dt.n_fallback = nfin;
+    std::vector<uint32_t> ids(nfin);
     for (uint32_t k = 0; k < nfin; ++k) {
         uint64_t h = 0;
         HIP_OK(hipMemcpy(&h, c->workspace.as<uint8_t>() + lay.o_fin + (size_t)k * 64 * 8, 8, hipMemcpyDeviceToHost));
         if (h >> 32) throw ConfigError("internal: fallback tag outside the tables");
-        c->dt.fallback_ids[k] = (uint32_t)h;
+        ids[k] = (uint32_t)h;
     }
+    set_fallback(c->ht, c->dt, ids.data(), nfin);
 }
 
 }  // namespace
@@ -356,6 +410,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         c->device = cfg->device;
         HIP_OK(hipSetDevice(c->device));
         if (const char* b = std::getenv("TAGPIPE_WORKSPACE_BYTES")) { unsigned long long v = std::strtoull(b, nullptr, 10); if (v >= (1ull << 20)) c->ws_budget = (size_t)v; }
+        if (const char* b = std::getenv("TAGPIPE_NO_FAST")) c->no_fast = b[0] == '1';
         compile_tables(*cfg, c->ht);
         const HostTables& h = c->ht;
         DevTables& d = c->dt;
@@ -377,6 +432,12 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.subs = upload(c->table_mem, h.subs);
         d.facets = upload(c->table_mem, h.facets);
         d.facet_rules = upload(c->table_mem, h.facet_rules);
+        d.rec = upload(c->table_mem, h.rec);
+        d.ht_info = upload(c->table_mem, h.ht_info);
+        d.step_off = upload(c->table_mem, h.step_off);
+        d.step_ids = upload(c->table_mem, h.step_ids);
+        d.reach_off = upload(c->table_mem, h.reach_off);
+        d.reach_ent = upload(c->table_mem, h.reach_ent);
         compute_fallback(c.get());
         return TP_OK;
     });

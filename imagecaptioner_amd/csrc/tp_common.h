@@ -52,6 +52,8 @@ enum : uint32_t {
     FL_NFEET = 1u << 18,       // NormalizeTag(it) == NormalizeTag("feet"), Program.cs:309, 719
     FL_NPENIS = 1u << 19,
     FL_NFOOTJOB = 1u << 20,
+    FL_NEXT_BLANK = 1u << 21,  // NormalizeTag(it) is blank
+    FL_PREFIX = 1u << 22,      // it is one of the tags SelectTags adds before the candidates (trigger, 1girl, always-add)
 };
 enum Bucket : uint32_t { B_IDENTITY = 0, B_FACE = 1, B_OUTFIT = 2, B_POSE = 3, B_BACKGROUND = 4, B_STYLE = 5, B_OTHER = 6 };
 TP_HD uint32_t fl_bucket(uint32_t f) { return (f & FL_BUCKET_MASK) >> FL_BUCKET_SHIFT; }
@@ -96,6 +98,11 @@ TP_HD uint64_t hash_fin(uint64_t h) {
 struct DRule { uint32_t parent_id, all_off, all_cnt, any_off, any_cnt, forb_off, forb_cnt, sub_off, sub_cnt; };  // ActionRule, Program.cs:129
 struct DSub { uint32_t tag_id, any_off, any_cnt, all_off, all_cnt; };                                            // ActionSubtypeRule / FacetRule, :130-131
 struct DFacet { uint32_t def_id, rule_off, rule_cnt; };                                                          // RequiredFacet, :132
+
+// Per-string record for the wave-per-file kernel: everything one NormalizeTag hop needs, in one 16-byte load.
+struct Rec { uint32_t flags, next, lit, len; };
+// Hash-table payload: what the alias lookup makes of the string in this slot, and where its bytes are (to verify a probe).
+struct HtInfo { uint32_t val, soff, slen, pad; };
 
 constexpr uint32_t NO_ID = 0xFFFFFFFFu;
 constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
@@ -145,6 +152,17 @@ struct DevTables {
     double line_weight;
     uint32_t line_source;
     uint32_t newline_len; uint8_t newline[4];
+    // extra tables of the wave-per-file kernel
+    const Rec* rec;              // n_strings
+    const HtInfo* ht_info;       // per hash slot
+    const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:
+    const uint32_t* step_ids;    //   NormalizeTag(it), then the implied tags of that (Program.cs:1164-1175); empty when nothing can change
+    const uint32_t* reach_off;   // n_strings + 1: every other string the closure of {it} holds, as pairs
+    const uint32_t* reach_ent;   //   {id, literal index (24 bits, 0xFFFFFF = none) | FL_NFEET-ness << 24 | FL_NPENIS-ness << 25}
+    uint32_t closure_tables;     // 0 when the reach table would be too large: files that need a closure take the general kernel
+    uint32_t fast_ok;            // the configuration fits the wave-per-file kernel at all
+    uint32_t n_prefix; uint32_t prefix_ids[MAX_TOTAL_TAGS];      // result list after the AddOne calls of Program.cs:664-668
+    uint32_t n_fb_final; uint32_t fb_final[MAX_FALLBACK];        // normalizedFinalSet of the fallback selection (Program.cs:298, 303)
     uint32_t final_cap;          // capacity of the per-file final-tag list
     uint32_t evidence_grow;      // evidence list capacity = candidates + this
 };

@@ -1,0 +1,654 @@
+// Wave-per-file form of the tag pipeline: the 64 lanes of one wavefront cooperate on one file whose state lives in
+// LDS and registers.  Lanes own bytes of the line, then tokens, then candidates, then final tags; set operations are
+// ballots or a small LDS hash set; sequential parts of the reference (the bucket fills of SelectTags, the ordered
+// growth of the final set) are turned into prefix-popcount arithmetic or short wave-uniform loops.
+//
+// It takes the COMMON shape of a file and hands anything else to the general one-thread-per-file kernel
+// (tp_pipeline.h) by returning false (whatever it wrote by then is overwritten by that kernel):
+//   * ASCII line of at most FAST_LINE_MAX bytes, no ':' or '`' (so no POSITIVE:/NEGATIVE:/code-fence handling,
+//     Program.cs:592-595), no line break inside the trimmed text;
+//   * at most FAST_TOK_MAX tokens, at most 64 candidates, every kept token an interned string;
+//   * no two different candidates that NormalizeTag maps to one selected tag (their AddOne order would matter);
+//   * lists that fit their LDS capacities.
+// Both kernels restate the same reference span (Program.cs:223-229, 292-329, 574-605) and are tested against the
+// same oracle; citations below name the reference lines each step stands for.
+//
+// All wave collectives (ballot / shfl / sync) are executed in wave-uniform control flow: every branch around one
+// depends only on ballot results or kernel arguments.  `W` supplies the collectives: hardware intrinsics on the GPU,
+// a lock-step emulation in the host-side logic test.
+#pragma once
+#include <math.h>
+
+#include "../../include/tagpipe.h"
+#include "tp_common.h"
+
+namespace tp {
+
+constexpr uint32_t FAST_LINE_MAX = 2048;   // bytes of one line held in LDS
+constexpr uint32_t FAST_TOK_MAX = 128;     // tokens per line (two per lane)
+constexpr uint32_t FAST_FIN_MAX = 128;     // final tags (two per lane)
+constexpr uint32_t FAST_SET_SLOTS = 256;   // LDS hash set
+constexpr uint32_t FAST_LIT_WORDS = 128;   // evidence bitset words (4096 rule literals)
+constexpr uint32_t FAST_FIRED_WORDS = 64;  // fired-rule bitmap words (2048 rules + subtypes)
+
+struct alignas(16) FastLds {
+    uint8_t line[FAST_LINE_MAX + 48];
+    uint16_t cpos[FAST_TOK_MAX];
+    uint32_t cand[64];
+    uint32_t fin[FAST_FIN_MAX];
+    uint32_t set_key[FAST_SET_SLOTS];
+    uint32_t set_min[FAST_SET_SLOTS];
+    uint32_t ebits[FAST_LIT_WORDS];
+    uint32_t firedw[FAST_FIRED_WORDS];
+};
+
+struct FastOut {
+    tp_verdict verdict;
+    uint32_t n_final;
+    uint32_t caption_len;
+};
+
+TP_HD uint32_t popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(x);
+#else
+    return (uint32_t)__builtin_popcountll(x);
+#endif
+}
+TP_HD uint32_t ctz64(uint64_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(__ffsll((long long)x) - 1);
+#else
+    return (uint32_t)__builtin_ctzll(x);
+#endif
+}
+TP_HD uint32_t clz64(uint64_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clzll((long long)x);
+#else
+    return (uint32_t)__builtin_clzll(x);
+#endif
+}
+
+template <class W>
+TP_HD uint32_t wave_sum(W& w, uint32_t v) {
+    for (uint32_t d = 32; d >= 1; d >>= 1) v += w.shfl(v, w.lane() ^ d);
+    return v;
+}
+
+// ---- LDS hash set: key -> smallest order value seen ---------------------------------------------------------------
+template <class W>
+TP_HD void set_clear(W& w, FastLds& L) {
+    for (uint32_t k = w.lane(); k < FAST_SET_SLOTS; k += 64) { L.set_key[k] = NO_ID; L.set_min[k] = 0xFFFFFFFFu; }
+    w.sync();
+}
+// Returns the slot, or NO_ID when the table is full.  `created` is true for exactly one caller per key.
+template <class W>
+TP_HD uint32_t set_put(W& w, FastLds& L, uint32_t key, uint32_t order, bool& created) {
+    uint32_t s = (key * 2654435761u) >> 24;
+    created = false;
+    for (uint32_t probe = 0; probe < FAST_SET_SLOTS; ++probe) {
+        uint32_t old = w.lds_cas(&L.set_key[s], NO_ID, key);
+        if (old == NO_ID || old == key) {
+            created = old == NO_ID;
+            w.lds_min(&L.set_min[s], order);
+            return s;
+        }
+        s = (s + 1) & (FAST_SET_SLOTS - 1);
+    }
+    return NO_ID;
+}
+
+// First-occurrence filter over up to 128 (key, valid) pairs held two per lane (element index = blk * 64 + lane).
+// On return first[blk] marks the elements that are the first with their key; returns false if the set overflowed.
+template <class W>
+TP_HD bool dedupe_first(W& w, FastLds& L, const uint32_t key[2], const bool valid[2], bool first[2]) {
+    set_clear(w, L);
+    uint32_t slot[2];
+    bool full = false;
+    for (int blk = 0; blk < 2; ++blk) {
+        slot[blk] = NO_ID;
+        if (valid[blk]) {
+            bool created;
+            slot[blk] = set_put(w, L, key[blk], (uint32_t)blk * 64 + w.lane(), created);
+            if (slot[blk] == NO_ID) full = true;
+        }
+    }
+    w.sync();
+    for (int blk = 0; blk < 2; ++blk) first[blk] = valid[blk] && slot[blk] != NO_ID && L.set_min[slot[blk]] == (uint32_t)blk * 64 + w.lane();
+    bool any_full = w.ballot(full) != 0;
+    w.sync();
+    return !any_full;
+}
+
+TP_HD bool lds_match(const uint8_t* s, uint32_t pos, uint32_t end, const char* pat, uint32_t plen) {
+    if (pos + plen > end) return false;
+    for (uint32_t k = 0; k < plen; ++k) if (lower8(s[pos + k]) != (uint8_t)pat[k]) return false;
+    return true;
+}
+
+// One token of the line (LDS bytes [i, j)) -> what NormalizeTag makes of it (Program.cs:1149-1158).
+//   returns 0: empty after trimming, skipped (Program.cs:1183-1185)
+//           1: interned, id in `out`
+//           2: not in any table
+template <class Tbl>
+TP_HD int fast_token(const Tbl& t, const uint8_t* s, uint32_t i, uint32_t j, uint32_t& out, bool& valid_dyn, uint32_t& dyn_len) {
+    while (i < j && is_ws8(s[i])) ++i;
+    while (j > i && is_ws8(s[j - 1])) --j;
+    if (i == j) return 0;
+    while (i < j && is_quote8(s[i])) ++i;
+    while (j > i && is_quote8(s[j - 1])) --j;
+    while (j > i && is_punct8(s[j - 1])) --j;
+    uint64_t hsh = HASH_SEED;
+    uint32_t n = 0;
+    bool last_us = false, valid = true;
+    for (uint32_t p = i; p < j; ++p) {                       // \s+ -> "_", _+ -> "_", lower case (Program.cs:1152-1154)
+        uint8_t c = s[p];
+        if (is_ws8(c) || c == '_') { if (last_us) continue; last_us = true; c = '_'; }
+        else { last_us = false; c = lower8(c); }
+        if (!(n == 0 ? is_tag_first8(c) : is_tag_rest8(c))) valid = false;
+        hsh = hash_step(hsh, c);
+        ++n;
+    }
+    hsh = hash_fin(hsh);
+    if (hsh == 0) hsh = 1;
+    uint32_t slot = (uint32_t)hsh & t.ht_mask;
+    for (;;) {
+        uint64_t hh = t.ht_hash[slot];
+        if (hh == 0) break;
+        if (hh == hsh) {
+            HtInfo info = t.ht_info[slot];
+            if (info.slen == n) {
+                const uint8_t* q = t.str_bytes + info.soff;
+                uint32_t k = 0;
+                bool lu = false;
+                bool same = true;
+                for (uint32_t p = i; p < j && same; ++p) {
+                    uint8_t c = s[p];
+                    if (is_ws8(c) || c == '_') { if (lu) continue; lu = true; c = '_'; }
+                    else { lu = false; c = lower8(c); }
+                    if (q[k] != c) same = false;
+                    ++k;
+                }
+                if (same) { out = info.val; return 1; }
+            }
+        }
+        slot = (slot + 1) & t.ht_mask;
+    }
+    valid_dyn = valid && n > 0;
+    dyn_len = n;
+    return 2;
+}
+
+// MatchesActionRule / MatchesSubtypeRule / MatchesFacetRule on the LDS evidence bitset (Program.cs:777-794).
+TP_HD bool fbit(const FastLds& L, uint32_t idx) { return (L.ebits[idx >> 5] >> (idx & 31)) & 1u; }
+TP_HD bool f_all(const DevTables& t, const FastLds& L, uint32_t off, uint32_t cnt) {
+    for (uint32_t k = 0; k < cnt; ++k) if (!fbit(L, t.pool[off + k])) return false;
+    return true;
+}
+TP_HD bool f_any(const DevTables& t, const FastLds& L, uint32_t off, uint32_t cnt) {
+    for (uint32_t k = 0; k < cnt; ++k) if (fbit(L, t.pool[off + k])) return true;
+    return false;
+}
+TP_HD bool f_match_sub(const DevTables& t, const FastLds& L, const DSub& r) {
+    if (r.any_cnt && !f_any(t, L, r.any_off, r.any_cnt)) return false;
+    if (r.all_cnt && !f_all(t, L, r.all_off, r.all_cnt)) return false;
+    return true;
+}
+
+// Appends `id` to the final list unless present.  own0/own1 mirror L.fin[lane], L.fin[lane + 64] in registers.
+// Wave-uniform: `id`, `nf` and the return value are the same in every lane.  Returns false on overflow.
+template <class W>
+TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id) {
+    if (w.ballot(own0 == id || own1 == id) != 0) return true;
+    if (nf >= FAST_FIN_MAX) return false;
+    if (w.lane() == (nf & 63)) { if (nf < 64) own0 = id; else own1 = id; }
+    if (w.lane() == 0) L.fin[nf] = id;
+    ++nf;
+    return true;
+}
+
+// The pipeline for one file.  Returns false when the file needs the general kernel.
+// fin32: where the caption's tag ids go (FAST_FIN_MAX entries); fired / facet_choice may be null.
+template <class W>
+TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32, uint32_t* fired,
+                     uint16_t* facet_choice) {
+    const uint32_t lane = w.lane();
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (len > FAST_LINE_MAX) return false;
+
+    // ---- S1: line -> LDS in aligned 16-byte pieces -------------------------------------------------------------------
+    const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
+    {
+        const uint8_t* abase = text - shift;
+        uint32_t pieces = (shift + len + 15) >> 4;
+        for (uint32_t c = lane; c < pieces; c += 64) w.copy16(L.line + 16 * c, abase + 16 * c);
+    }
+    w.sync();
+    const uint8_t* s = L.line + shift;
+
+    // ---- S2: character classes, trim (NormalizeRawTagLine, Program.cs:589-596) ------------------------------------------
+    uint32_t first_nonws = 0xFFFFFFFFu, end_nonws = 0, first_nl = 0xFFFFFFFFu, last_nl = 0;
+    bool odd = false;
+    for (uint32_t base = 0; base < len; base += 64) {
+        uint32_t p = base + lane;
+        uint8_t c = p < len ? s[p] : (uint8_t)' ';
+        uint64_t m_nonws = w.ballot(!is_ws8(c));
+        uint64_t m_odd = w.ballot(c >= 0x80 || c == ':' || c == '`');
+        uint64_t m_nl = w.ballot(p < len && (c == '\r' || c == '\n'));
+        if (m_odd) odd = true;
+        if (m_nonws) { if (first_nonws == 0xFFFFFFFFu) first_nonws = base + ctz64(m_nonws); end_nonws = base + 64 - clz64(m_nonws); }
+        if (m_nl) { if (first_nl == 0xFFFFFFFFu) first_nl = base + ctz64(m_nl); last_nl = base + 63 - clz64(m_nl); }
+    }
+    if (odd) return false;
+    const bool blank_line = first_nonws == 0xFFFFFFFFu;
+    const uint32_t a = blank_line ? 0 : first_nonws, b = blank_line ? 0 : end_nonws;
+    if (!blank_line && first_nl != 0xFFFFFFFFu && first_nl < b && last_nl > a) return false;   // a line break may sit inside the text
+
+    // commas and LooksBad (Program.cs:1141-1147)
+    uint32_t ncomma = 0;
+    bool refusal = false;
+    for (uint32_t base = a; base < b; base += 64) {
+        uint32_t p = base + lane;
+        bool inb = p < b;
+        uint8_t c = inb ? s[p] : 0;
+        uint64_t m_c = w.ballot(inb && c == ',');
+        if (inb && c == ',') { uint32_t k = ncomma + popc64(m_c & lt); if (k < FAST_TOK_MAX) L.cpos[k] = (uint16_t)p; }
+        ncomma += popc64(m_c);
+        bool hit = false;
+        if (inb) {
+            switch (lower8(c)) {                                  // DropTagsContains without the two entries that hold ':' (Program.cs:56-58)
+                case 's': hit = lds_match(s, p, b, "sorry", 5); break;
+                case 'i': hit = lds_match(s, p, b, "i can't", 7) || lds_match(s, p, b, "i cannot", 8) || lds_match(s, p, b, "i'm not able", 12) || lds_match(s, p, b, "i won't", 7); break;
+                case 'c': hit = lds_match(s, p, b, "cannot provide", 14); break;
+                case 'u': hit = lds_match(s, p, b, "unable to", 9); break;
+                case 'a': hit = lds_match(s, p, b, "as an ai", 8); break;
+                default: break;
+            }
+        }
+        if (w.ballot(hit)) refusal = true;
+    }
+    const uint32_t T = ncomma + 1;
+    if (T > FAST_TOK_MAX) return false;
+    const bool rejected = blank_line || refusal || (ncomma < 2 && (b - a) > 40);
+    w.sync();
+
+    // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
+    uint32_t n = 0;   // candidates
+    {
+        uint32_t tid[2] = {NO_ID, NO_ID};
+        bool keep[2] = {false, false};
+        bool dyn_survivor = false;
+        if (!rejected) {
+            for (int blk = 0; blk < 2; ++blk) {
+                uint32_t tix = (uint32_t)blk * 64 + lane;
+                if (tix < T) {
+                    uint32_t i = tix == 0 ? a : (uint32_t)L.cpos[tix - 1] + 1;
+                    uint32_t j = tix == T - 1 ? b : (uint32_t)L.cpos[tix];
+                    uint32_t id = NO_ID, dlen = 0;
+                    bool vdyn = false;
+                    int kind = fast_token(t, s, i, j, id, vdyn, dlen);
+                    if (kind == 1) {
+                        uint32_t f = t.rec[id].flags;
+                        if ((f & FL_LEN2) && !(f & FL_DROP)) { tid[blk] = id; keep[blk] = true; }
+                    } else if (kind == 2) {
+                        // a string outside the tables: gone under strict vocabulary, too short, or invalid; anything else may survive
+                        if (!t.drop_unknown && dlen >= 2 && vdyn) dyn_survivor = true;
+                    }
+                }
+            }
+        }
+        if (w.ballot(dyn_survivor)) return false;
+        bool first[2];
+        if (!dedupe_first(w, L, tid, keep, first)) return false;
+        uint64_t m0 = w.ballot(first[0]), m1 = w.ballot(first[1]);
+        n = popc64(m0) + popc64(m1);
+        if (n > 64) return false;
+        if (first[0]) L.cand[popc64(m0 & lt)] = tid[0];
+        if (first[1]) L.cand[popc64(m0) + popc64(m1 & lt)] = tid[1];
+        w.sync();
+    }
+
+    // ---- S5: SelectTags first half on lanes = candidates (Program.cs:625-655), evidence seeds (Program.cs:721-729) ----------
+    const bool act = lane < n;
+    const uint32_t h1 = act ? L.cand[lane] : EMPTY_ID;
+    Rec r1 = t.rec[h1];
+    const uint32_t t2 = r1.next;
+    const uint64_t m_hop2 = w.ballot(act && t2 != h1);
+    Rec r2 = r1;
+    if (m_hop2 && act && t2 != h1) r2 = t.rec[t2];
+    const double score = fmax(0.05, 1.0 - (double)(int)lane * 0.01) * t.line_weight;     // Program.cs:581
+    const uint32_t style_n = popc64(w.ballot(act && fl_bucket(r1.flags) == B_STYLE && score >= 0.60));   // DetermineStyleQualityCap, Program.cs:702-710
+    const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
+    const bool nonblank2 = act && !(r2.flags & FL_BLANK);
+    bool first2 = nonblank2;
+    if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences (the lower index carries the higher score)
+        uint32_t key[2] = {t2, NO_ID};
+        bool valid[2] = {nonblank2, false};
+        bool fst[2];
+        if (!dedupe_first(w, L, key, valid, fst)) return false;
+        first2 = fst[0];
+    }
+    const bool bad2 = nonblank2 && (!(r2.flags & FL_VALID) || (r2.flags & FL_DROP));
+    const bool uniq = first2 && !bad2;
+    const uint32_t n_dropped = popc64(w.ballot(first2 && bad2));                            // distinct "{n}:invalid_tag" / "{n}:policy_drop"
+    const bool ev_seed = first2 && !(score < 0.28);
+
+    // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
+    const uint32_t t3 = r2.next;
+    const uint64_t m_hop3 = w.ballot(uniq && t3 != t2);
+    uint32_t f3 = r2.flags;
+    if (m_hop3 && uniq && t3 != t2) f3 = t.rec[t3].flags;
+    const bool ok3 = uniq && !(f3 & FL_BLANK) && (f3 & FL_VALID) && !(f3 & FL_DROP) && !(f3 & FL_PREFIX);   // AddOne's tests; prefix tags are already in
+    if (m_hop3) {
+        uint32_t key[2] = {t3, NO_ID};
+        bool valid[2] = {ok3, false};
+        bool fst[2];
+        if (!dedupe_first(w, L, key, valid, fst)) return false;
+        if (w.ballot(ok3 && !fst[0])) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
+    }
+    uint32_t nr = t.n_prefix;
+    {
+        const uint32_t bucket2 = fl_bucket(r2.flags);
+        const int caps[6] = {3, 10, 8, 6, 4, style_cap};
+        bool taken = false;
+        uint32_t pos = 0;
+        for (uint32_t bk = 0; bk < 6; ++bk) {                     // FillBucket in order: the first `cap` eligible tags, while the list is short of 42
+            bool el = ok3 && bucket2 == bk;
+            uint64_t m = w.ballot(el);
+            uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
+            uint32_t take = popc64(m);
+            if (take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
+            if (take > room) take = room;
+            uint32_t rank = popc64(m & lt);
+            if (el && rank < take) { taken = true; pos = nr + rank; }
+            nr += take;
+        }
+        {                                                         // final sweep over the sorted list (Program.cs:677-680)
+            bool el = ok3 && !taken;
+            uint64_t m = w.ballot(el);
+            uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
+            uint32_t take = popc64(m);
+            if (take > room) take = room;
+            uint32_t rank = popc64(m & lt);
+            if (el && rank < take) { taken = true; pos = nr + rank; }
+            nr += take;
+        }
+        if (lane < t.n_prefix) L.fin[lane] = t.prefix_ids[lane];
+        if (taken) L.fin[pos] = t3;
+        w.sync();
+    }
+    const uint32_t n_selected = nr;
+
+    // ---- S7: EvaluateCoverage (Program.cs:1056-1095) and normalizedFinalSet (Program.cs:303) -------------------------------
+    uint32_t own0 = NO_ID, own1 = NO_ID;   // the final list, entry k in lane k & 63
+    uint32_t nf = 0;
+    uint32_t coverage = 0;
+    {
+        const bool in = lane < nr;
+        const uint32_t r = in ? L.fin[lane] : EMPTY_ID;
+        Rec rr = t.rec[r];
+        const uint32_t t4 = rr.next;
+        const uint64_t m_hop4 = w.ballot(in && t4 != r);
+        uint32_t f4 = rr.flags;
+        if (m_hop4 && in && t4 != r) f4 = t.rec[t4].flags;
+        const bool nb4 = in && !(f4 & FL_BLANK);
+        const bool has_trigger = w.ballot(nb4 && t4 == t.trigger_id) != 0, has_girl = w.ballot(nb4 && t4 == t.girl_lit_id) != 0;
+        coverage = ((has_trigger && has_girl) ? TP_COV_IDENTITY : 0) | (w.ballot(nb4 && (f4 & FL_HAIR)) ? TP_COV_HAIR : 0) |
+                   (w.ballot(nb4 && (f4 & FL_EYES)) ? TP_COV_EYES : 0) | (w.ballot(nb4 && fl_bucket(f4) == B_OUTFIT) ? TP_COV_OUTFIT : 0) |
+                   (w.ballot(nb4 && fl_bucket(f4) == B_POSE) ? TP_COV_POSE_ACTION : 0) | (w.ballot(nb4 && fl_bucket(f4) == B_BACKGROUND) ? TP_COV_BACKGROUND : 0);
+        if (nr >= 3) {
+            bool keep4 = nb4;
+            if (m_hop4) {
+                uint32_t key[2] = {t4, NO_ID};
+                bool valid[2] = {nb4, false};
+                bool fst[2];
+                if (!dedupe_first(w, L, key, valid, fst)) return false;
+                keep4 = fst[0];
+            }
+            uint64_t m = w.ballot(keep4);
+            nf = popc64(m);
+            w.sync();
+            if (keep4) L.fin[popc64(m & lt)] = t4;
+        } else {                                                   // fewer than 3 tags: the minimal fallback selection (Program.cs:297-298)
+            nf = t.n_fb_final;
+            w.sync();
+            if (lane < nf) L.fin[lane] = t.fb_final[lane];
+        }
+        w.sync();
+        own0 = lane < nf ? L.fin[lane] : NO_ID;
+    }
+    uint32_t flags = (rejected ? TP_F_LINE_REJECTED : 0u) | (nr < 3 ? TP_F_FALLBACK : 0u);
+
+    // ---- S8: evidence closure (Program.cs:301-302) -> literal bitset, count, feet/penis ---------------------------------------
+    for (uint32_t k = lane; k < t.lit_words; k += 64) L.ebits[k] = 0;
+    w.sync();
+    uint32_t n_evidence = 0;
+    bool ev_feet = false, ev_penis = false;
+    {
+        const uint64_t m_edge = w.ballot(ev_seed && (r2.flags & FL_EDGE));
+        if (ev_seed) {
+            if (r2.lit != NO_ID) w.lds_or(&L.ebits[r2.lit >> 5], 1u << (r2.lit & 31));
+            ev_feet = (r2.flags & FL_NFEET) != 0;                  // HasTag(evidenceTags, ...), Program.cs:309, 719
+            ev_penis = (r2.flags & FL_NPENIS) != 0;
+        }
+        if (!m_edge) {
+            n_evidence = popc64(w.ballot(ev_seed));
+        } else {
+            if (!t.closure_tables) return false;
+            set_clear(w, L);
+            uint32_t made = 0;
+            bool full = false;
+            if (ev_seed) {
+                bool created;
+                if (set_put(w, L, t2, 0, created) == NO_ID) full = true;
+                made += created;
+            }
+            w.sync();
+            if (ev_seed && (r2.flags & FL_EDGE)) {
+                for (uint32_t m = t.reach_off[t2]; m < t.reach_off[t2 + 1] && !full; ++m) {
+                    uint32_t id = t.reach_ent[2 * m], info = t.reach_ent[2 * m + 1];
+                    bool created;
+                    if (set_put(w, L, id, 0, created) == NO_ID) { full = true; break; }
+                    if (created) {
+                        ++made;
+                        uint32_t li = info & 0xFFFFFFu;
+                        if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                    }
+                    ev_feet |= (info >> 24) & 1u;
+                    ev_penis |= (info >> 25) & 1u;
+                }
+            }
+            if (w.ballot(full)) return false;
+            n_evidence = wave_sum(w, made);
+            if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
+        }
+        ev_feet = w.ballot(ev_feet) != 0;
+        ev_penis = w.ballot(ev_penis) != 0;
+        w.sync();
+    }
+
+    // ---- S9: final-set closure, in the reference's insertion order (ExpandImpliedTags, Program.cs:304, 1160-1179) ------------
+    // The set grows breadth-first: a round visits every element in order and appends NormalizeTag(it) and its implied tags.
+    {
+        uint32_t lo = 0, hi = nf;
+        while (lo < hi) {
+            for (int blk = 0; blk < 2; ++blk) {
+                uint32_t idx = (uint32_t)blk * 64 + lane;
+                bool in = idx >= lo && idx < hi;
+                uint32_t id = blk == 0 ? own0 : own1;
+                uint32_t fl = in ? t.rec[id].flags : 0;
+                bool edge = in && (fl & FL_EDGE);
+                uint32_t so = 0, sc = 0, s0 = NO_ID, s1 = NO_ID;
+                if (edge) {
+                    so = t.step_off[id];
+                    sc = t.step_off[id + 1] - so;
+                    s0 = t.step_ids[so];
+                    if (sc > 1) s1 = t.step_ids[so + 1];
+                }
+                uint64_t m = w.ballot(edge);
+                while (m) {
+                    uint32_t q = ctz64(m);
+                    m &= m - 1;
+                    uint32_t cnt = w.shfl(sc, q), off = w.shfl(so, q), a0 = w.shfl(s0, q), a1 = w.shfl(s1, q);
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        uint32_t sid = k == 0 ? a0 : (k == 1 ? a1 : t.step_ids[off + k]);
+                        if (!fin_append(w, L, own0, own1, nf, sid)) return false;
+                    }
+                }
+            }
+            lo = hi;
+            hi = nf;
+        }
+        w.sync();
+    }
+
+    // ---- S10: InferActionTags (Program.cs:731-753) ---------------------------------------------------------------------------
+    {
+        // inferred = Select(NormalizeTag).Where(non-blank).Distinct()
+        uint32_t g[2];
+        bool nb[2];
+        bool changed = false;
+        for (int blk = 0; blk < 2; ++blk) {
+            uint32_t idx = (uint32_t)blk * 64 + lane;
+            uint32_t id = blk == 0 ? own0 : own1;
+            bool in = idx < nf;
+            Rec rr = t.rec[in ? id : EMPTY_ID];
+            g[blk] = rr.next;
+            nb[blk] = in && !(rr.flags & FL_NEXT_BLANK);
+            if (in && (g[blk] != id || !nb[blk])) changed = true;
+        }
+        if (w.ballot(changed)) {
+            bool fst[2];
+            if (!dedupe_first(w, L, g, nb, fst)) return false;
+            uint64_t m0 = w.ballot(fst[0]), m1 = w.ballot(fst[1]);
+            nf = popc64(m0) + popc64(m1);
+            if (fst[0]) L.fin[popc64(m0 & lt)] = g[0];
+            if (fst[1]) L.fin[popc64(m0) + popc64(m1 & lt)] = g[1];
+            w.sync();
+            own0 = lane < nf ? L.fin[lane] : NO_ID;
+            own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
+        }
+        if (lane < t.fired_words) L.firedw[lane] = 0;
+        w.sync();
+        for (uint32_t r0 = 0; r0 < t.n_rules; r0 += 64) {
+            uint32_t r = r0 + lane;
+            bool hit = false;
+            DRule rule = t.rules[r < t.n_rules ? r : 0];
+            if (r < t.n_rules) {                                   // MatchesActionRule, Program.cs:777-782
+                hit = !(rule.all_cnt && !f_all(t, L, rule.all_off, rule.all_cnt)) && !(rule.any_cnt && !f_any(t, L, rule.any_off, rule.any_cnt)) &&
+                      !f_any(t, L, rule.forb_off, rule.forb_cnt);
+            }
+            uint64_t m = w.ballot(hit);
+            if (hit) w.lds_or(&L.firedw[r >> 5], 1u << (r & 31));      // "action:{parent}" (Program.cs:741)
+            while (m) {
+                uint32_t q = ctz64(m);
+                m &= m - 1;
+                uint32_t parent = w.shfl(rule.parent_id, q), sub_off = w.shfl(rule.sub_off, q), sub_cnt = w.shfl(rule.sub_cnt, q);
+                if (!fin_append(w, L, own0, own1, nf, parent)) return false;
+                for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
+                    uint32_t si = s0 + lane;
+                    bool shit = false;
+                    DSub sub = t.subs[sub_off + (si < sub_cnt ? si : 0)];
+                    if (si < sub_cnt) shit = f_match_sub(t, L, sub);
+                    uint64_t ms = w.ballot(shit);
+                    if (shit) {                                    // "subtype:{parent}:{tag}" (Program.cs:748)
+                        uint32_t bit = t.n_rules + sub_off + si;
+                        w.lds_or(&L.firedw[bit >> 5], 1u << (bit & 31));
+                    }
+                    while (ms) {
+                        uint32_t qs = ctz64(ms);
+                        ms &= ms - 1;
+                        if (!fin_append(w, L, own0, own1, nf, w.shfl(sub.tag_id, qs))) return false;
+                    }
+                }
+            }
+        }
+    }
+    // ---- S11: EnsureRequiredFacets (Program.cs:755-775) -----------------------------------------------------------------------
+    for (uint32_t f0 = 0; f0 < t.n_facets; f0 += 64) {
+        uint32_t f = f0 + lane;
+        uint32_t selected = NO_ID;
+        if (f < t.n_facets) {
+            DFacet facet = t.facets[f];
+            selected = facet.def_id;
+            uint16_t choice = 0xFFFF;
+            for (uint32_t r = 0; r < facet.rule_cnt; ++r) {
+                DSub fr = t.facet_rules[facet.rule_off + r];
+                if (f_match_sub(t, L, fr)) { selected = fr.tag_id; choice = (uint16_t)r; break; }
+            }
+            if (facet_choice) facet_choice[f] = choice;
+        }
+        uint32_t cnt = t.n_facets - f0 < 64 ? t.n_facets - f0 : 64;
+        for (uint32_t q = 0; q < cnt; ++q)
+            if (!fin_append(w, L, own0, own1, nf, w.shfl(selected, q))) return false;
+    }
+    w.sync();
+
+    // ---- S12: verdicts on the final list (Program.cs:319, 329), GetUnknownTags (:817-824), FormatCaptionSingleLine (:971-974) ---
+    uint32_t c[2], clen[2];
+    bool cnb[2], cknown[2];
+    bool face = false, outfit = false, changed = false;
+    uint32_t safe_idx[2] = {0, 0};
+    bool safe[2] = {false, false};
+    for (int blk = 0; blk < 2; ++blk) {
+        uint32_t idx = (uint32_t)blk * 64 + lane;
+        uint32_t id = blk == 0 ? own0 : own1;
+        bool in = idx < nf;
+        Rec rr = t.rec[in ? id : EMPTY_ID];
+        if (in) {
+            uint32_t bk = fl_bucket(rr.flags);
+            face |= bk == B_FACE;                                  // MissingCoreBuckets, Program.cs:1097-1101
+            outfit |= bk == B_OUTFIT;
+            if (rr.flags & FL_SAFE) { safe[blk] = true; safe_idx[blk] = (rr.flags >> FL_SAFE_IDX_SHIFT) & 31; }
+        }
+        c[blk] = rr.next;
+        Rec rc = rr;
+        if (in && c[blk] != id) { rc = t.rec[c[blk]]; changed = true; }
+        cnb[blk] = in && !(rc.flags & FL_BLANK);
+        if (in && !cnb[blk]) changed = true;
+        clen[blk] = rc.len;
+        cknown[blk] = (rc.flags & FL_KNOWN) != 0;
+    }
+    if (!(w.ballot(face) && w.ballot(outfit))) flags |= TP_F_LOW;
+    int safe_hit = -1;
+    {
+        uint64_t ms0 = w.ballot(safe[0]), ms1 = w.ballot(safe[1]);
+        if (t.safe_mode && (ms0 | ms1)) {                          // first final tag in SafeModeRejectTags (Program.cs:942-945)
+            uint32_t v = ms0 ? w.shfl(safe_idx[0], ctz64(ms0)) : w.shfl(safe_idx[1], ctz64(ms1));
+            safe_hit = (int)v;
+            flags |= TP_F_SAFE_REJECT;
+        }
+    }
+    bool keepc[2] = {cnb[0], cnb[1]};
+    if (w.ballot(changed)) {
+        if (!dedupe_first(w, L, c, cnb, keepc)) return false;
+    }
+    const uint64_t mc0 = w.ballot(keepc[0]), mc1 = w.ballot(keepc[1]);
+    const uint32_t nc = popc64(mc0) + popc64(mc1);
+    uint32_t bytes = (keepc[0] ? clen[0] : 0) + (keepc[1] ? clen[1] : 0);
+    bytes = wave_sum(w, bytes);
+    const uint32_t unknown = t.known_active ? popc64(w.ballot(keepc[0] && !cknown[0])) + popc64(w.ballot(keepc[1] && !cknown[1])) : 0;
+    const bool footjob = w.ballot((keepc[0] && c[0] == t.footjob_n) || (keepc[1] && c[1] == t.footjob_n)) != 0;   // HasTag(finalTags, "footjob"), Program.cs:311
+    w.sync();
+    if (fired && lane < t.fired_words) fired[lane] = L.firedw[lane];
+    if (keepc[0]) fin32[popc64(mc0 & lt)] = c[0];
+    if (keepc[1]) fin32[popc64(mc0) + popc64(mc1 & lt)] = c[1];
+    if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (footjob) flags |= TP_F_FOOTJOB; }
+
+    tp_verdict& v = out.verdict;
+    v.coverage = (uint8_t)coverage;
+    v.flags = (uint8_t)flags;
+    v.n_tags = (uint16_t)nc;
+    v.n_candidates = (uint16_t)n;
+    v.n_selected = (uint16_t)n_selected;
+    v.safe_hit = (int16_t)safe_hit;
+    v.n_evidence = (uint16_t)n_evidence;
+    v.n_unknown = (uint16_t)unknown;
+    v.n_dropped = (uint16_t)n_dropped;
+    out.n_final = nc;
+    out.caption_len = bytes + (nc ? 2 * (nc - 1) : 0) + t.newline_len;
+    return true;
+}
+
+}  // namespace tp

@@ -1,20 +1,77 @@
 // HIP kernels of the batch tag pipeline for gfx950 (MI355X) and their launchers.
 //
 // Kernel map (all integer/byte work, HBM- and latency-bound; no MFMA):
-//   k_wave_sizes   one thread per file: token upper bound (comma count, 8 bytes per step) and line length; a wavefront
-//                  reduces both to its maximum and records the byte size of its interleaved workspace.
+//   k_fast         one WAVEFRONT per file (tp_fast.h): line staged in LDS, lanes = bytes / tokens / candidates / tags,
+//                  set operations by ballot and an LDS hash set.  Takes the common shape of a file; files it declines
+//                  are appended to a list for k_pipeline.
+//   k_pipeline     one THREAD per file (tp_pipeline.h): the general form of the same pipeline; lane-private arrays are
+//                  interleaved across the wavefront's 64 lanes so equal element indices share 512-byte rows.
+//   k_wave_sizes   sizes k_pipeline's workspace: per item the token upper bound (comma count, 8 bytes per step) and the
+//                  line length, reduced to per-wavefront maxima.
 //   k_scan_*       three-pass exclusive scan (u32/u64 -> u64) for workspace offsets and caption offsets.
-//   k_pipeline     one thread per file: the whole per-file pipeline (tp_pipeline.h); lane-private arrays are interleaved
-//                  across the wavefront's 64 lanes so equal element indices share 512-byte rows.
-//   k_emit         one wavefront per file: caption bytes from the final handle list (wave prefix sum of tag lengths),
+//   k_emit         one wavefront per file: caption bytes from the final tag list (wave prefix sum of tag lengths),
 //                  tag histogram (block-private LDS counters for the low, frequent ids; global atomics for the tail),
 //                  batch counters.
 #include <hip/hip_runtime.h>
 
+#include "tp_fast.h"
 #include "tp_launch.h"
 #include "tp_pipeline.h"
 
 namespace tp {
+
+// ------------------------------------------------------------------------------------------------
+// k_fast
+// ------------------------------------------------------------------------------------------------
+// Wave collectives for tp_fast.h.  LDS traffic between lanes of one wavefront needs no barrier in hardware (the lanes
+// run in lock step and LDS operations of a wave complete in order); the fence keeps the compiler from moving LDS
+// accesses across the exchange point.
+struct DevWave {
+    __device__ uint32_t lane() const { return threadIdx.x & 63u; }
+    __device__ uint64_t ballot(bool p) const { return __ballot(p ? 1 : 0); }
+    __device__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)(src & 63u), 64); }
+    __device__ void sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __device__ uint32_t lds_cas(uint32_t* p, uint32_t cmp, uint32_t val) const { return atomicCAS(p, cmp, val); }
+    __device__ void lds_min(uint32_t* p, uint32_t v) const { atomicMin(p, v); }
+    __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
+    __device__ void copy16(uint8_t* lds_dst, const uint8_t* src) const { *(uint4*)lds_dst = *(const uint4*)src; }
+};
+
+constexpr int FAST_WAVES_PER_BLOCK = 4;
+
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast(DevTables t, FastArgs a) {
+    __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
+    FastLds& L = lds[threadIdx.x >> 6];
+    DevWave w;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t f = a.file0 + wave_global; f < a.file_end; f += n_waves) {
+        uint64_t o = a.offsets[f];
+        uint64_t len64 = a.offsets[f + 1] - o;
+        bool done = false;
+        FastOut out;
+        if (len64 <= FAST_LINE_MAX) {
+            done = fast_file(w, t, L, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
+                             a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+        }
+        if (w.lane() == 0) {
+            if (done) {
+                a.verdicts[f] = out.verdict;
+                a.n_final[f] = out.n_final;
+                a.cap_len[f] = out.caption_len;
+                a.slot_of[f] = SLOT_FAST;
+            } else {
+                uint32_t k = atomicAdd(a.slow_count, 1u);
+                a.slow_list[k] = (uint32_t)(f - a.file0);
+            }
+        }
+        w.sync();
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_wave_sizes
@@ -33,10 +90,12 @@ __device__ inline uint32_t count_commas(const uint8_t* p, uint32_t n) {
 }
 
 __global__ __launch_bounds__(256) void k_wave_sizes(DevTables t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin,
-                                                    uint64_t n_files, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status) {
-    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                    const uint32_t* item_list, uint64_t file0, uint64_t n_items, uint32_t* wave_T, uint32_t* wave_LB,
+                                                    uint64_t* wave_bytes, uint32_t* status) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t T = 1, LB = 0;
-    if (f < n_files) {
+    if (i < n_items) {
+        uint64_t f = file0 + (item_list ? (uint64_t)item_list[i] : i);
         if (tag_begin) {   // scored ingest: tag count and total text length are read off the offset arrays
             uint64_t lo = tag_begin[f], hi = tag_begin[f + 1];
             uint64_t ntag = hi - lo, bytes = offsets[hi] - offsets[lo];
@@ -55,8 +114,8 @@ __global__ __launch_bounds__(256) void k_wave_sizes(DevTables t, const uint8_t* 
         T = T > oT ? T : oT;
         LB = LB > oL ? LB : oL;
     }
-    if ((threadIdx.x & 63) == 0 && (f < n_files)) {
-        uint64_t w = f >> 6;
+    if ((threadIdx.x & 63) == 0 && i < n_items) {
+        uint64_t w = i >> 6;
         WsLayout L = ws_layout(T, LB, t.final_cap, t.evidence_grow, t.lit_words);
         wave_T[w] = T;
         wave_LB[w] = LB;
@@ -128,14 +187,13 @@ uint64_t scan_tiles_needed(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE 
 // k_pipeline
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
-    uint64_t local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // file index inside the chunk
-    uint64_t f = a.file0 + local;
-    if (f >= a.file_end) return;
-    uint64_t w = f >> 6;
-    uint32_t lane = (uint32_t)(f & 63);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // item index
+    if (i >= a.n_items) return;
+    uint64_t f = a.file0 + (a.item_list ? (uint64_t)a.item_list[i] : i);
+    uint64_t w = i >> 6;
+    uint32_t lane = (uint32_t)(i & 63);
     WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
-    uint8_t* wave_base = a.workspace + (a.wave_off[w] - a.wave_off[a.file0 >> 6]);
-    FileWs ws = ws_bind(wave_base, L, lane);
+    FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, lane);
     FileIn in;
     if (a.tag_begin) {
         in.text = nullptr; in.len = 0;
@@ -151,6 +209,7 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
     a.verdicts[f] = out.verdict;
     a.n_final[f] = out.n_final;
     a.cap_len[f] = out.caption_len;
+    a.slot_of[f] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -169,10 +228,6 @@ __global__ __launch_bounds__(256) void k_emit(DevTables t, EmitArgs a) {
     uint64_t c_files = 0, c_low = 0, c_elig = 0, c_foot = 0, c_fb = 0, c_rej = 0, c_uns = 0, c_safe = 0, c_other = 0;
 
     for (uint64_t f = a.file0 + wave_global; f < a.file_end; f += n_waves) {
-        uint64_t w = f >> 6;
-        WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
-        uint8_t* wave_base = a.workspace + (a.wave_off[w] - a.wave_off[a.file0 >> 6]);
-        FileWs ws = ws_bind(wave_base, L, (uint32_t)(f & 63));
         uint32_t nfin = a.n_final[f];
         uint64_t out0 = a.caption_offsets[f];
         uint32_t total = (uint32_t)(a.caption_offsets[f + 1] - out0);
@@ -183,11 +238,21 @@ __global__ __launch_bounds__(256) void k_emit(DevTables t, EmitArgs a) {
             c_rej += (fl & TP_F_LINE_REJECTED) != 0; c_uns += (fl & TP_F_UNSUPPORTED) != 0; c_safe += (fl & TP_F_SAFE_REJECT) != 0;
         }
         if (total == 0) continue;   // unsupported file: nothing is written
+        const uint32_t slot = a.slot_of[f];
+        const bool fast = slot == SLOT_FAST;
+        const uint32_t* ids = a.fin32 + (f - a.file0) * FAST_FIN_MAX;
+        FileWs ws;
+        if (!fast) {
+            uint64_t w = slot >> 6;
+            WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
+            ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63);
+        }
         uint32_t running = 0;
         for (uint32_t k0 = 0; k0 < nfin; k0 += 64) {
             uint32_t k = k0 + lane;
             bool live = k < nfin;
-            H h = live ? ws.fin[k] : 0;
+            H h = 0;
+            if (live) h = fast ? (H)ids[k] : ws.fin[k];
             const uint8_t* src = nullptr;
             uint32_t len = 0;
             if (live) {
@@ -235,11 +300,21 @@ __global__ __launch_bounds__(256) void k_emit(DevTables t, EmitArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, uint64_t n_files,
-                             uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s) {
-    if (n_files == 0) return hipSuccess;
-    unsigned blocks = (unsigned)((n_files + 255) / 256);
-    hipLaunchKernelGGL(k_wave_sizes, dim3(blocks), dim3(256), 0, s, t, arena, offsets, tag_begin, n_files, wave_T, wave_LB, wave_bytes, status);
+uint32_t fast_fin_stride() { return FAST_FIN_MAX; }
+
+hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
+    uint64_t n = a.file_end - a.file0;
+    if (n == 0) return hipSuccess;
+    uint64_t want = (n + FAST_WAVES_PER_BLOCK - 1) / FAST_WAVES_PER_BLOCK;
+    unsigned blocks = (unsigned)(want < 256 * 8 ? want : 256 * 8);    // up to 8 blocks per CU, wavefronts stride over the files
+    hipLaunchKernelGGL(k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), 0, s, t, a);
+    return hipGetLastError();
+}
+hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,
+                             uint64_t file0, uint64_t n_items, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s) {
+    if (n_items == 0) return hipSuccess;
+    unsigned blocks = (unsigned)((n_items + 255) / 256);
+    hipLaunchKernelGGL(k_wave_sizes, dim3(blocks), dim3(256), 0, s, t, arena, offsets, tag_begin, item_list, file0, n_items, wave_T, wave_LB, wave_bytes, status);
     return hipGetLastError();
 }
 hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s) {
@@ -249,9 +324,8 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64
     return scan_exclusive<uint32_t>(in, n, out, tile_sums, base_ptr, total_out, s);
 }
 hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_t s) {
-    uint64_t n = a.file_end - a.file0;
-    if (n == 0) return hipSuccess;
-    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (a.n_items == 0) return hipSuccess;
+    unsigned blocks = (unsigned)((a.n_items + 255) / 256);
     hipLaunchKernelGGL(k_pipeline, dim3(blocks), dim3(256), 0, s, t, a);
     return hipGetLastError();
 }

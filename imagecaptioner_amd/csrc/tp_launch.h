@@ -8,21 +8,43 @@
 
 namespace tp {
 
-// One chunk of files [file0, file_end); file0 is a multiple of 64 so that a wavefront's lanes are 64 consecutive files.
+constexpr uint32_t SLOT_FAST = 0xFFFFFFFFu;   // slot_of[file]: the file was finished by the wave-per-file kernel
+
+// Wave-per-file kernel over files [file0, file_end) (line ingest only).
+struct FastArgs {
+    const uint8_t* arena;
+    const uint64_t* offsets;
+    uint64_t file0, file_end;
+    tp_verdict* verdicts;
+    uint32_t* n_final;
+    uint32_t* cap_len;
+    uint32_t* fin32;              // FAST_FIN_MAX ids per file, indexed by file - file0
+    uint32_t* slot_of;            // per file: SLOT_FAST, or (set later) its position in the general kernel's item list
+    uint32_t* slow_list;          // files (absolute index) left to the general kernel, in no particular order
+    uint32_t* slow_count;
+    uint32_t* fired;
+    uint16_t* facet_choice;
+};
+
+// General kernel: items are files file0 + i, or slow_list[i] when a list is given.  Item i uses lane i & 63 of
+// workspace wave i >> 6.
 struct PipelineArgs {
     const uint8_t* arena;
     const uint64_t* offsets;      // line ingest: file offsets; scored ingest: tag offsets
     const uint64_t* tag_begin;    // scored ingest only
     const double* scores;
     const uint8_t* sources;
-    uint64_t file0, file_end;
-    const uint32_t* wave_T;       // per wavefront: token capacity and line-length capacity of its workspace
+    const uint32_t* item_list;    // may be null
+    uint64_t file0;
+    uint64_t n_items;
+    const uint32_t* wave_T;       // per workspace wave: token capacity and line-length capacity
     const uint32_t* wave_LB;
-    const uint64_t* wave_off;     // per wavefront: byte offset of its workspace (global scan; the chunk's first wave is subtracted)
+    const uint64_t* wave_off;     // per workspace wave: byte offset of its workspace
     uint8_t* workspace;
     tp_verdict* verdicts;
     uint32_t* n_final;
     uint32_t* cap_len;
+    uint32_t* slot_of;
     uint32_t* fired;
     uint16_t* facet_choice;
     int mode;
@@ -34,6 +56,8 @@ struct EmitArgs {
     const uint32_t* wave_LB;
     const uint64_t* wave_off;
     uint8_t* workspace;
+    const uint32_t* fin32;        // indexed by file - file0
+    const uint32_t* slot_of;
     const uint32_t* n_final;
     const uint64_t* caption_offsets;
     const tp_verdict* verdicts;
@@ -42,12 +66,14 @@ struct EmitArgs {
     tp_counters* counters;        // accumulated; may be null
 };
 
-hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, uint64_t n_files,
-                             uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s);
+hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s);
+hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,
+                             uint64_t file0, uint64_t n_items, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s);
 hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s);
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s);
 uint64_t scan_tiles_needed(uint64_t n);
 hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_t s);
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s);
+uint32_t fast_fin_stride();
 
 }  // namespace tp

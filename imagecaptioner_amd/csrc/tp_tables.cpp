@@ -944,9 +944,97 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     }
     sc.final_cap = MAX_TOTAL_TAGS + std::min<uint32_t>(MAX_TOTAL_TAGS * reach_max, 2048) + sc.n_rules + sc.n_subs + sc.n_facets + 16;
     sc.evidence_grow = std::min<uint32_t>(73 * reach_max, 2048) + 16;   // at most 73 line-ingest candidates score >= 0.28
+    // ---- tables of the wave-per-file kernel ----
+    // prefix: the result list after AddOne(trigger), AddOne("1girl"), AddOne(always-add...) (Program.cs:664-668, 692-699)
+    sc.n_prefix = 0;
+    {
+        std::vector<uint32_t> pre = {sc.trigger_id, sc.girl_add_id};
+        for (uint32_t k = 0; k < sc.n_always; ++k) pre.push_back(sc.always_ids[k]);
+        for (uint32_t id : pre) {
+            uint32_t f = out.flags[id];
+            if ((f & FL_BLANK) || sc.n_prefix >= (uint32_t)MAX_TOTAL_TAGS || !(f & FL_VALID) || (f & FL_DROP)) continue;
+            if (std::find(sc.prefix_ids, sc.prefix_ids + sc.n_prefix, id) != sc.prefix_ids + sc.n_prefix) continue;
+            sc.prefix_ids[sc.n_prefix++] = id;
+            out.flags[id] |= FL_PREFIX;
+        }
+    }
+    for (uint32_t i = 0; i < N; ++i) if (out.flags[out.next[i]] & FL_BLANK) out.flags[i] |= FL_NEXT_BLANK;
+    // step lists: one ExpandImpliedTags visit of a string appends NormalizeTag(it), then that string's implied tags
+    out.step_off.assign(N + 1, 0);
+    out.step_ids.clear();
+    for (uint32_t i = 0; i < N; ++i) {
+        out.step_off[i] = (uint32_t)out.step_ids.size();
+        if (!(out.flags[i] & FL_EDGE)) continue;
+        uint32_t s = out.next[i];
+        if (out.flags[s] & FL_BLANK) continue;                     // snapshot drops blank forms (Program.cs:1164)
+        out.step_ids.push_back(s);
+        for (uint32_t m = out.imp_off[s]; m < out.imp_off[s + 1]; ++m) out.step_ids.push_back(out.imp_ids[m]);
+    }
+    out.step_off[N] = (uint32_t)out.step_ids.size();
+    for (uint32_t i = 0; i < N; ++i) {                              // FL_EDGE now means exactly "a visit can append something"
+        bool trivial = true;
+        for (uint32_t m = out.step_off[i]; m < out.step_off[i + 1]; ++m) if (out.step_ids[m] != i) trivial = false;
+        if (trivial) { out.flags[i] &= ~(uint32_t)FL_EDGE; }
+    }
+    // reach lists: closure of {it} under the visits, without it
+    out.reach_off.assign(N + 1, 0);
+    out.reach_ent.clear();
+    sc.closure_tables = 1;
+    {
+        std::vector<uint32_t> seen(N, NO_ID), stack;
+        for (uint32_t i = 0; i < N && sc.closure_tables; ++i) {
+            out.reach_off[i] = (uint32_t)(out.reach_ent.size() / 2);
+            if (!(out.flags[i] & FL_EDGE)) continue;
+            stack.assign(1, i);
+            seen[i] = i;
+            while (!stack.empty()) {
+                uint32_t x = stack.back();
+                stack.pop_back();
+                if (!(out.flags[x] & FL_EDGE)) continue;
+                for (uint32_t m = out.step_off[x]; m < out.step_off[x + 1]; ++m) {
+                    uint32_t y = out.step_ids[m];
+                    if (seen[y] == i) continue;
+                    seen[y] = i;
+                    stack.push_back(y);
+                    uint32_t li = out.lit[y] == NO_ID ? 0xFFFFFFu : out.lit[y];
+                    out.reach_ent.push_back(y);
+                    out.reach_ent.push_back(li | ((out.flags[y] & FL_NFEET) ? 1u << 24 : 0) | ((out.flags[y] & FL_NPENIS) ? 1u << 25 : 0));
+                }
+            }
+            if (out.reach_ent.size() > (size_t)(64u << 20)) sc.closure_tables = 0;
+        }
+        if (!sc.closure_tables) { out.reach_ent.clear(); std::fill(out.reach_off.begin(), out.reach_off.end(), 0u); }
+        out.reach_off[N] = (uint32_t)(out.reach_ent.size() / 2);
+    }
+    if (out.step_ids.empty()) out.step_ids.push_back(0);
+    if (out.reach_ent.empty()) { out.reach_ent.push_back(0); out.reach_ent.push_back(0); }
+    out.rec.resize(N);
+    for (uint32_t i = 0; i < N; ++i) out.rec[i] = Rec{out.flags[i], out.next[i], out.lit[i], out.str_off[i + 1] - out.str_off[i]};
+    out.ht_info.assign(slots, HtInfo{0, 0, 0, 0});
+    for (uint32_t s = 0; s < slots; ++s) {
+        if (!out.ht_hash[s]) continue;
+        uint32_t id = out.ht_id[s];
+        out.ht_info[s] = HtInfo{out.alias1[id], out.str_off[id], out.str_off[id + 1] - out.str_off[id], 0};
+    }
+    // the wave-per-file kernel keeps its literal bitset in 128 LDS words and assumes scores fall with the token index
+    sc.fast_ok = (sc.lit_words <= 128 && sc.fired_words <= 64 && n_lits < 0xFFFFFFu && cfg.line_weight > 0.0) ? 1 : 0;
+    sc.n_fb_final = 0;
     out.n_known = (uint32_t)ld.known.size();
     out.strict = ld.strict;
     out.known_found = ld.known_found;
+}
+
+void set_fallback(const HostTables& ht, DevTables& dt, const uint32_t* ids, uint32_t n) {
+    if (n > (uint32_t)MAX_FALLBACK) throw ConfigError("internal: fallback selection too long");
+    dt.n_fallback = n;
+    dt.n_fb_final = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        dt.fallback_ids[i] = ids[i];
+        uint32_t h = ht.next[ids[i]];                               // finalTags.Select(NormalizeTag).Where(non-blank).ToHashSet(), Program.cs:303
+        if (ht.flags[h] & FL_BLANK) continue;
+        if (std::find(dt.fb_final, dt.fb_final + dt.n_fb_final, h) != dt.fb_final + dt.n_fb_final) continue;
+        dt.fb_final[dt.n_fb_final++] = h;
+    }
 }
 
 DevTables bind_host_pointers(const HostTables& ht) {
@@ -968,6 +1056,12 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.subs = ht.subs.data();
     t.facets = ht.facets.data();
     t.facet_rules = ht.facet_rules.data();
+    t.rec = ht.rec.data();
+    t.ht_info = ht.ht_info.data();
+    t.step_off = ht.step_off.data();
+    t.step_ids = ht.step_ids.data();
+    t.reach_off = ht.reach_off.data();
+    t.reach_ent = ht.reach_ent.data();
     return t;
 }
 

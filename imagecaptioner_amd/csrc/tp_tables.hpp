@@ -28,6 +28,9 @@ struct HostTables {
     std::vector<DSub> subs;
     std::vector<DFacet> facets;
     std::vector<DSub> facet_rules;
+    std::vector<Rec> rec;
+    std::vector<HtInfo> ht_info;
+    std::vector<uint32_t> step_off, step_ids, reach_off, reach_ent;
     DevTables scalars;                      // scalar members filled, pointer members null
     // host-side facts
     std::vector<std::string> strings;       // UTF-8 text per interned id
@@ -42,6 +45,10 @@ struct HostTables {
 
 // Throws ConfigError (malformed JSON or table content this build cannot represent).
 void compile_tables(const tp_config& cfg, HostTables& out);
+
+// Stores the SelectTags result of the minimal fallback line (ids, evaluated by the pipeline kernel at load time) and
+// derives the final-set form the wave-per-file kernel starts from.
+void set_fallback(const HostTables& ht, DevTables& dt, const uint32_t* ids, uint32_t n);
 
 // A DevTables whose pointers address the HostTables vectors themselves (host-side logic checks).
 DevTables bind_host_pointers(const HostTables& ht);

@@ -151,7 +151,8 @@ class TagPipe:
     def last_timing(self):
         t = tp_timing()
         self._check(self._L.tp_get_last_timing(self._h, C.byref(t)))
-        return {"total_ms": t.total_ms, "select_ms": t.select_ms, "emit_ms": t.emit_ms, "other_ms": t.other_ms}
+        return {"total_ms": t.total_ms, "select_ms": t.select_ms, "general_ms": t.general_ms, "emit_ms": t.emit_ms, "other_ms": t.other_ms,
+                "general_files": int(t.general_files)}
 
     # ---- host-buffer runs -----------------------------------------------------------------------
     def _collect(self, res):

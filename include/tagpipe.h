@@ -239,9 +239,11 @@ int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* ou
 /* Timing of the most recent run on this context (milliseconds, from HIP events on the run's stream). */
 typedef struct tp_timing {
     float total_ms;     /* first kernel start to last kernel end */
-    float select_ms;    /* the per-file pipeline kernel (dominant) */
-    float emit_ms;      /* caption byte emission */
-    float other_ms;     /* scans, counters, histogram */
+    float select_ms;    /* wave-per-file pipeline kernel (k_fast) */
+    float general_ms;   /* thread-per-file pipeline kernel (k_pipeline) over the files k_fast declined */
+    float emit_ms;      /* caption bytes, histogram, counters (k_emit) */
+    float other_ms;     /* sizing, scans, host round trips between kernels */
+    uint64_t general_files; /* how many files took the thread-per-file kernel */
 } tp_timing;
 int tp_get_last_timing(const tp_ctx* ctx, tp_timing* out);
 

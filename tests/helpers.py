@@ -50,6 +50,7 @@ def sim_lib():
         L.sim_string.argtypes = [C.c_void_p, C.c_uint32]
         L.sim_run_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
         L.sim_run_scored.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
+        L.sim_run_lines_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result), C.POINTER(C.c_uint64)]
         L.sim_release.argtypes = [C.POINTER(sim_result)]
         _SIM = L
     return _SIM
@@ -114,6 +115,23 @@ class HostSim:
     def run_texts(self, texts):
         a, o = pack_lines(texts)
         return self.run_lines(a, o)
+
+    def run_lines_fast(self, arena, offsets):
+        """The GPU flow: wave-per-file kernel body on an emulated wavefront, general pipeline for declined files."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        if arena.size == 0:
+            arena = np.zeros(1, np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = sim_result()
+        ng = C.c_uint64()
+        rc = self._L.sim_run_lines_fast(self._h, arena.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(res), C.byref(ng))
+        out = self._collect(res, rc)
+        out.n_general = ng.value
+        return out
+
+    def run_texts_fast(self, texts):
+        a, o = pack_lines(texts)
+        return self.run_lines_fast(a, o)
 
     def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
         arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])

@@ -9,7 +9,9 @@
 #include <vector>
 
 #include "../../include/tagpipe.h"
+#include "../../imagecaptioner_amd/csrc/tp_fast.h"
 #include "../../imagecaptioner_amd/csrc/tp_pipeline.h"
+#include "wave_emu.h"
 #include "../../imagecaptioner_amd/csrc/tp_tables.hpp"
 
 using namespace tp;
@@ -107,8 +109,9 @@ void* sim_create(const tp_config* cfg) {
         line.resize(line.size() + 16);
         run(*s, line.data(), offs, nullptr, nullptr, nullptr, 1, 1, o, &fin);
         s->dt = saved;
-        s->dt.n_fallback = (uint32_t)fin[0].size();
-        for (size_t k = 0; k < fin[0].size(); ++k) s->dt.fallback_ids[k] = (uint32_t)fin[0][k];
+        std::vector<uint32_t> ids;
+        for (H h : fin[0]) ids.push_back((uint32_t)h);
+        set_fallback(s->ht, s->dt, ids.data(), (uint32_t)ids.size());
         return s.release();
     } catch (const std::exception& e) {
         g_err = e.what();
@@ -148,6 +151,79 @@ int sim_run_scored(void* h, const uint8_t* arena, const uint64_t* tag_offsets, c
     run(*(Sim*)h, arena, tag_offsets, tag_begin, scores, sources, n, 0, *o, nullptr);
     return finish(o, n, r);
 }
+// The GPU flow: every file first goes through the wave-per-file kernel body (tp_fast.h) on an emulated wavefront;
+// files it declines take the general pipeline.  *n_general receives how many did.
+int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, sim_result* r, uint64_t* n_general) {
+    g_err.clear();
+    Sim& s = *(Sim*)h;
+    const DevTables& t = s.dt;
+    SimOut* o = new SimOut();
+    // the kernel reads whole aligned 16-byte pieces around a line: give the arena slack on both sides
+    std::vector<uint8_t> padded((size_t)offsets[n] + 128, 0);
+    uint8_t* arena = padded.data() + 64;
+    std::memcpy(arena, arena_in, (size_t)offsets[n]);
+    SimOut general;
+    std::vector<std::vector<H>> unused;
+    o->offsets.assign(n + 1, 0);
+    o->verdicts.assign(n, tp_verdict{});
+    o->fired.assign(n * t.fired_words, 0);
+    o->facets.assign(n * t.n_facets, 0xFFFF);
+    o->hist.assign((size_t)t.n_strings + 1, 0);
+    uint64_t slow = 0;
+    emu::Shared sh;
+    for (uint64_t f = 0; f < n; ++f) {
+        static FastLds lds;
+        std::memset(&lds, 0xCD, sizeof lds);
+        std::vector<uint32_t> fin32(FAST_FIN_MAX, 0xDEADBEEF);
+        bool done[64];
+        FastOut outs[64];
+        const uint8_t* text = arena + offsets[f];
+        uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
+        bool ok = t.fast_ok && len <= FAST_LINE_MAX;
+        if (ok) {
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                done[lane] = fast_file(w, t, lds, text, len, outs[lane], fin32.data(), t.fired_words ? &o->fired[f * t.fired_words] : nullptr,
+                                       t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
+            });
+            for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the fast-path verdict"; }
+            ok = done[0];
+        }
+        size_t before = o->captions.size();
+        if (ok) {
+            const FastOut& fo = outs[0];
+            o->verdicts[f] = fo.verdict;
+            for (uint32_t k = 0; k < fo.n_final; ++k) {
+                uint32_t id = fin32[k];
+                if (k) { o->captions.push_back(','); o->captions.push_back(' '); }
+                const uint8_t* p = str_ptr(t, id);
+                o->captions.insert(o->captions.end(), p, p + str_len(t, id));
+                o->hist[id]++;
+            }
+            o->captions.insert(o->captions.end(), t.newline, t.newline + t.newline_len);
+            if (o->captions.size() - before != fo.caption_len) g_err = "fast caption_len mismatch";
+        } else {
+            ++slow;
+            uint64_t offs2[2] = {0, len};
+            SimOut one;
+            run(s, text, offs2, nullptr, nullptr, nullptr, 1, 0, one, nullptr);
+            o->verdicts[f] = one.verdicts[0];
+            for (uint32_t k = 0; k < t.fired_words; ++k) o->fired[f * t.fired_words + k] = one.fired[k];
+            for (uint32_t k = 0; k < t.n_facets; ++k) o->facets[f * t.n_facets + k] = one.facets[k];
+            o->captions.insert(o->captions.end(), one.captions.begin(), one.captions.end());
+            for (size_t k = 0; k < one.hist.size(); ++k) o->hist[k] += one.hist[k];
+        }
+        o->offsets[f + 1] = o->captions.size();
+        uint8_t fl = o->verdicts[f].flags;
+        o->ctr.files++;
+        o->ctr.low += (fl & TP_F_LOW) != 0; o->ctr.action_eligible += (fl & TP_F_ELIGIBLE) != 0; o->ctr.action_footjob += (fl & TP_F_FOOTJOB) != 0;
+        o->ctr.fallback += (fl & TP_F_FALLBACK) != 0; o->ctr.line_rejected += (fl & TP_F_LINE_REJECTED) != 0; o->ctr.unsupported += (fl & TP_F_UNSUPPORTED) != 0;
+        o->ctr.safe_rejected += (fl & TP_F_SAFE_REJECT) != 0;
+    }
+    if (n_general) *n_general = slow;
+    return finish(o, n, r);
+}
+
 void sim_release(sim_result* r) { delete (SimOut*)r->opaque; r->opaque = nullptr; }
 
 }  // extern "C"
