@@ -10,8 +10,8 @@
 //   * at most FAST_TOK_MAX tokens, at most 64 candidates, every kept token an interned string;
 //   * no two different candidates that NormalizeTag maps to one selected tag (their AddOne order would matter);
 //   * lists that fit their LDS capacities.
-// Both kernels restate the same reference span (Program.cs:223-229, 292-329, 574-605) and are tested against the
-// same oracle; citations below name the reference lines each step stands for.
+// Both kernels restate the same reference span (Program.cs:223-229, 292-329, 574-605) and must give identical
+// results; citations below name the reference lines each step stands for.
 //
 // All wave collectives (ballot / shfl / sync) are executed in wave-uniform control flow: every branch around one
 // depends only on ballot results or kernel arguments.  `W` supplies the collectives: hardware intrinsics on the GPU,

@@ -112,3 +112,24 @@ def test_non_ascii_is_reported_not_guessed():
     assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
     assert r.caption(1) == b"" and r.caption(2) == b""
     assert r.counters["unsupported"] == 2
+
+
+# ---- the wave-per-file kernel body (tp_fast.h) on an emulated wavefront ---------------------------------------------
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_wave_kernel_edge_and_fuzz_lines(name):
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    lines = EDGE_LINES + fuzz_lines(23, 300)
+    want, got = o.run_texts(lines), s.run_texts_fast(lines)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name + " wave kernel")
+
+
+@pytest.mark.parametrize("name,n", [("c1", 250), ("c2", 250), ("c3", 250), ("c4", 250), ("c5", 120)])
+def test_wave_kernel_benchmark_corpora(name, n):
+    c = make_corpus(name, n, seed=91)
+    cfg = Config(**c.config_kwargs)
+    o, s = Oracle(cfg), HostSim(cfg)
+    want, got = o.run_lines(c.arena, c.offsets, threads=8), s.run_lines_fast(c.arena, c.offsets)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name + " wave kernel")
+    if name in ("c2", "c3", "c4"):
+        assert got.n_general <= n // 20, "the wave-per-file kernel should take nearly every file of %s (declined %d)" % (name, got.n_general)
