@@ -434,6 +434,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.facet_rules = upload(c->table_mem, h.facet_rules);
         d.rec = upload(c->table_mem, h.rec);
         d.ht_info = upload(c->table_mem, h.ht_info);
+        d.str_words = upload(c->table_mem, h.str_words);
         d.step_off = upload(c->table_mem, h.step_off);
         d.step_ids = upload(c->table_mem, h.step_ids);
         d.reach_off = upload(c->table_mem, h.reach_off);

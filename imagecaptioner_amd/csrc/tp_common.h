@@ -84,14 +84,26 @@ TP_HD bool is_tag_rest8(uint8_t c) {
 }
 
 // ---- hashing (FNV-1a 64 with a final avalanche; equality is always verified on bytes) ------------------
+// The string is taken as little-endian 8-byte words (the last one zero-padded): one multiply per word, not per byte.
 constexpr uint64_t HASH_SEED = 0xcbf29ce484222325ull;
-TP_HD uint64_t hash_step(uint64_t h, uint8_t c) { return (h ^ c) * 0x100000001b3ull; }
-TP_HD uint64_t hash_fin(uint64_t h) {
-    h ^= h >> 32;
-    h *= 0x9E3779B97F4A7C15ull;
-    h ^= h >> 29;
-    return h;
+TP_HD uint64_t hash_word(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 32);
 }
+TP_HD uint64_t hash_finish(uint64_t h, uint32_t n_bytes) {
+    h = (h ^ n_bytes) * 0xD6E8FEB86659FD93ull;
+    h ^= h >> 29;
+    return h ? h : 1;          // 0 marks an empty slot
+}
+struct Hasher {
+    uint64_t h = HASH_SEED, w = 0;
+    uint32_t n = 0;
+    TP_HD void add(uint8_t c) {
+        w |= (uint64_t)c << (8 * (n & 7));
+        if ((++n & 7) == 0) { h = hash_word(h, w); w = 0; }
+    }
+    TP_HD uint64_t done() const { return hash_finish((n & 7) ? hash_word(h, w) : h, n); }
+};
 
 // ---- compiled rules --------------------------------------------------------------------------------------
 // Literal lists are [off, off+cnt) ranges of DevTables::pool holding indices into the per-file evidence bitset.
@@ -100,9 +112,12 @@ struct DSub { uint32_t tag_id, any_off, any_cnt, all_off, all_cnt; };           
 struct DFacet { uint32_t def_id, rule_off, rule_cnt; };                                                          // RequiredFacet, :132
 
 // Per-string record for the wave-per-file kernel: everything one NormalizeTag hop needs, in one 16-byte load.
-struct Rec { uint32_t flags, next, lit, len; };
+struct Rec {
+    uint32_t flags, next, lit, len;
+    uint32_t step_off, step_cnt, step0, step1;   // its ExpandImpliedTags step list (DevTables::step_ids), the first two entries inline
+};
 // Hash-table payload: what the alias lookup makes of the string in this slot, and where its bytes are (to verify a probe).
-struct HtInfo { uint32_t val, soff, slen, pad; };
+struct HtInfo { uint32_t val, woff, slen, pad; };   // woff: first 8-byte word of the string in DevTables::str_words
 
 constexpr uint32_t NO_ID = 0xFFFFFFFFu;
 constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
@@ -155,6 +170,7 @@ struct DevTables {
     // extra tables of the wave-per-file kernel
     const Rec* rec;              // n_strings
     const HtInfo* ht_info;       // per hash slot
+    const uint64_t* str_words;   // every string again as zero-padded little-endian 8-byte words, for word-wise probe verification
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:
     const uint32_t* step_ids;    //   NormalizeTag(it), then the implied tags of that (Program.cs:1164-1175); empty when nothing can change
     const uint32_t* reach_off;   // n_strings + 1: every other string the closure of {it} holds, as pairs

@@ -7,7 +7,7 @@
 // (tp_pipeline.h) by returning false (whatever it wrote by then is overwritten by that kernel):
 //   * ASCII line of at most FAST_LINE_MAX bytes, no ':' or '`' (so no POSITIVE:/NEGATIVE:/code-fence handling,
 //     Program.cs:592-595), no line break inside the trimmed text;
-//   * at most FAST_TOK_MAX tokens, at most 64 candidates, every kept token an interned string;
+//   * at most FAST_TOK_MAX tokens, every kept token an interned string;
 //   * no two different candidates that NormalizeTag maps to one selected tag (their AddOne order would matter);
 //   * lists that fit their LDS capacities.
 // Both kernels restate the same reference span (Program.cs:223-229, 292-329, 574-605) and must give identical
@@ -34,7 +34,7 @@ constexpr uint32_t FAST_FIRED_WORDS = 64;  // fired-rule bitmap words (2048 rule
 struct alignas(16) FastLds {
     uint8_t line[FAST_LINE_MAX + 48];
     uint16_t cpos[FAST_TOK_MAX];
-    uint32_t cand[64];
+    uint32_t cand[FAST_TOK_MAX];
     uint32_t fin[FAST_FIN_MAX];
     uint32_t set_key[FAST_SET_SLOTS];
     uint32_t set_min[FAST_SET_SLOTS];
@@ -131,15 +131,16 @@ TP_HD bool lds_match(const uint8_t* s, uint32_t pos, uint32_t end, const char* p
 //   returns 0: empty after trimming, skipped (Program.cs:1183-1185)
 //           1: interned, id in `out`
 //           2: not in any table
-template <class Tbl>
-TP_HD int fast_token(const Tbl& t, const uint8_t* s, uint32_t i, uint32_t j, uint32_t& out, bool& valid_dyn, uint32_t& dyn_len) {
+// The normalised bytes are packed into 8-byte words as they are produced (the first 32 bytes stay in registers), so
+// hashing costs one multiply per word and a probe hit is verified word by word against DevTables::str_words.
+TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, uint32_t& out, bool& valid_dyn, uint32_t& dyn_len) {
     while (i < j && is_ws8(s[i])) ++i;
     while (j > i && is_ws8(s[j - 1])) --j;
     if (i == j) return 0;
     while (i < j && is_quote8(s[i])) ++i;
     while (j > i && is_quote8(s[j - 1])) --j;
     while (j > i && is_punct8(s[j - 1])) --j;
-    uint64_t hsh = HASH_SEED;
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, cur = 0, h = HASH_SEED;
     uint32_t n = 0;
     bool last_us = false, valid = true;
     for (uint32_t p = i; p < j; ++p) {                       // \s+ -> "_", _+ -> "_", lower case (Program.cs:1152-1154)
@@ -147,11 +148,21 @@ TP_HD int fast_token(const Tbl& t, const uint8_t* s, uint32_t i, uint32_t j, uin
         if (is_ws8(c) || c == '_') { if (last_us) continue; last_us = true; c = '_'; }
         else { last_us = false; c = lower8(c); }
         if (!(n == 0 ? is_tag_first8(c) : is_tag_rest8(c))) valid = false;
-        hsh = hash_step(hsh, c);
-        ++n;
+        cur |= (uint64_t)c << (8 * (n & 7));
+        if ((++n & 7) == 0) {
+            h = hash_word(h, cur);
+            uint32_t wi = (n >> 3) - 1;
+            if (wi == 0) w0 = cur; else if (wi == 1) w1 = cur; else if (wi == 2) w2 = cur; else if (wi == 3) w3 = cur;
+            cur = 0;
+        }
     }
-    hsh = hash_fin(hsh);
-    if (hsh == 0) hsh = 1;
+    if (n & 7) {
+        h = hash_word(h, cur);
+        uint32_t wi = n >> 3;
+        if (wi == 0) w0 = cur; else if (wi == 1) w1 = cur; else if (wi == 2) w2 = cur; else if (wi == 3) w3 = cur;
+    }
+    const uint64_t hsh = hash_finish(h, n);
+    const uint32_t nwords = (n + 7) >> 3;
     uint32_t slot = (uint32_t)hsh & t.ht_mask;
     for (;;) {
         uint64_t hh = t.ht_hash[slot];
@@ -159,16 +170,24 @@ TP_HD int fast_token(const Tbl& t, const uint8_t* s, uint32_t i, uint32_t j, uin
         if (hh == hsh) {
             HtInfo info = t.ht_info[slot];
             if (info.slen == n) {
-                const uint8_t* q = t.str_bytes + info.soff;
-                uint32_t k = 0;
-                bool lu = false;
+                const uint64_t* q = t.str_words + info.woff;
                 bool same = true;
-                for (uint32_t p = i; p < j && same; ++p) {
-                    uint8_t c = s[p];
-                    if (is_ws8(c) || c == '_') { if (lu) continue; lu = true; c = '_'; }
-                    else { lu = false; c = lower8(c); }
-                    if (q[k] != c) same = false;
-                    ++k;
+                if (nwords > 0 && q[0] != w0) same = false;
+                if (nwords > 1 && q[1] != w1) same = false;
+                if (nwords > 2 && q[2] != w2) same = false;
+                if (nwords > 3 && q[3] != w3) same = false;
+                if (same && nwords > 4) {                        // a long token: re-normalise the tail against the stored words
+                    uint32_t k = 0;
+                    bool lu = false;
+                    uint64_t acc = 0;
+                    for (uint32_t p = i; p < j && same; ++p) {
+                        uint8_t c = s[p];
+                        if (is_ws8(c) || c == '_') { if (lu) continue; lu = true; c = '_'; }
+                        else { lu = false; c = lower8(c); }
+                        acc |= (uint64_t)c << (8 * (k & 7));
+                        if ((++k & 7) == 0) { if (k > 32 && q[(k >> 3) - 1] != acc) same = false; acc = 0; }
+                    }
+                    if (same && (k & 7) && q[k >> 3] != acc) same = false;
                 }
                 if (same) { out = info.val; return 1; }
             }
@@ -234,9 +253,14 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         uint32_t p = base + lane;
         uint8_t c = p < len ? s[p] : (uint8_t)' ';
         uint64_t m_nonws = w.ballot(!is_ws8(c));
-        uint64_t m_odd = w.ballot(c >= 0x80 || c == ':' || c == '`');
+        uint64_t m_odd = w.ballot(c >= 0x80 || c == '`');
+        uint64_t m_colon = w.ballot(c == ':');
         uint64_t m_nl = w.ballot(p < len && (c == '\r' || c == '\n'));
         if (m_odd) odd = true;
+        if (m_colon) {   // only "positive:" / "negative:" matter (Program.cs:57, 592-594); other colons are ordinary tag text
+            bool key = c == ':' && p >= 8 && (lds_match(s, p - 8, len, "positive", 8) || lds_match(s, p - 8, len, "negative", 8));
+            if (w.ballot(key)) odd = true;
+        }
         if (m_nonws) { if (first_nonws == 0xFFFFFFFFu) first_nonws = base + ctz64(m_nonws); end_nonws = base + 64 - clz64(m_nonws); }
         if (m_nl) { if (first_nl == 0xFFFFFFFFu) first_nl = base + ctz64(m_nl); last_nl = base + 63 - clz64(m_nl); }
     }
@@ -274,7 +298,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     w.sync();
 
     // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
-    uint32_t n = 0;   // candidates
+    uint32_t n = 0;   // candidates, two per lane: candidate index = blk * 64 + lane
     {
         uint32_t tid[2] = {NO_ID, NO_ID};
         bool keep[2] = {false, false};
@@ -303,79 +327,87 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         if (!dedupe_first(w, L, tid, keep, first)) return false;
         uint64_t m0 = w.ballot(first[0]), m1 = w.ballot(first[1]);
         n = popc64(m0) + popc64(m1);
-        if (n > 64) return false;
         if (first[0]) L.cand[popc64(m0 & lt)] = tid[0];
         if (first[1]) L.cand[popc64(m0) + popc64(m1 & lt)] = tid[1];
         w.sync();
     }
 
-    // ---- S5: SelectTags first half on lanes = candidates (Program.cs:625-655), evidence seeds (Program.cs:721-729) ----------
-    const bool act = lane < n;
-    const uint32_t h1 = act ? L.cand[lane] : EMPTY_ID;
-    Rec r1 = t.rec[h1];
-    const uint32_t t2 = r1.next;
-    const uint64_t m_hop2 = w.ballot(act && t2 != h1);
-    Rec r2 = r1;
-    if (m_hop2 && act && t2 != h1) r2 = t.rec[t2];
-    const double score = fmax(0.05, 1.0 - (double)(int)lane * 0.01) * t.line_weight;     // Program.cs:581
-    const uint32_t style_n = popc64(w.ballot(act && fl_bucket(r1.flags) == B_STYLE && score >= 0.60));   // DetermineStyleQualityCap, Program.cs:702-710
-    const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
-    const bool nonblank2 = act && !(r2.flags & FL_BLANK);
-    bool first2 = nonblank2;
-    if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences (the lower index carries the higher score)
-        uint32_t key[2] = {t2, NO_ID};
-        bool valid[2] = {nonblank2, false};
-        bool fst[2];
-        if (!dedupe_first(w, L, key, valid, fst)) return false;
-        first2 = fst[0];
+    // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
+    // In line ingest the scores fall with the candidate index, so "sorted" order is candidate order and the first of
+    // two candidates that NormalizeTag merges carries the merged score, order and source.
+    bool act[2], nonblank2[2], first2[2], bad2[2], uniq[2], ev_seed[2];
+    uint32_t h1[2], t2[2];
+    Rec r2[2];
+    uint32_t style_n = 0;
+    uint64_t m_hop2 = 0;
+    for (int blk = 0; blk < 2; ++blk) {
+        uint32_t ci = (uint32_t)blk * 64 + lane;
+        act[blk] = ci < n;
+        h1[blk] = act[blk] ? L.cand[ci] : EMPTY_ID;
+        Rec r1 = t.rec[h1[blk]];
+        t2[blk] = r1.next;
+        bool hop = act[blk] && t2[blk] != h1[blk];
+        uint64_t mh = w.ballot(hop);
+        m_hop2 |= mh;
+        r2[blk] = r1;
+        if (mh && hop) r2[blk] = t.rec[t2[blk]];
+        double score = fmax(0.05, 1.0 - (double)(int)ci * 0.01) * t.line_weight;          // Program.cs:581
+        style_n += popc64(w.ballot(act[blk] && fl_bucket(r1.flags) == B_STYLE && score >= 0.60));   // DetermineStyleQualityCap, Program.cs:702-710
+        nonblank2[blk] = act[blk] && !(r2[blk].flags & FL_BLANK);
+        first2[blk] = nonblank2[blk];
+        bad2[blk] = nonblank2[blk] && (!(r2[blk].flags & FL_VALID) || (r2[blk].flags & FL_DROP));
+        ev_seed[blk] = !(score < 0.28);
     }
-    const bool bad2 = nonblank2 && (!(r2.flags & FL_VALID) || (r2.flags & FL_DROP));
-    const bool uniq = first2 && !bad2;
-    const uint32_t n_dropped = popc64(w.ballot(first2 && bad2));                            // distinct "{n}:invalid_tag" / "{n}:policy_drop"
-    const bool ev_seed = first2 && !(score < 0.28);
+    const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
+    if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences
+        if (!dedupe_first(w, L, t2, nonblank2, first2)) return false;
+    }
+    uint32_t n_dropped = 0;
+    for (int blk = 0; blk < 2; ++blk) {
+        uniq[blk] = first2[blk] && !bad2[blk];
+        n_dropped += popc64(w.ballot(first2[blk] && bad2[blk]));                            // distinct "{n}:invalid_tag" / "{n}:policy_drop"
+        ev_seed[blk] = ev_seed[blk] && first2[blk];
+    }
 
     // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
-    const uint32_t t3 = r2.next;
-    const uint64_t m_hop3 = w.ballot(uniq && t3 != t2);
-    uint32_t f3 = r2.flags;
-    if (m_hop3 && uniq && t3 != t2) f3 = t.rec[t3].flags;
-    const bool ok3 = uniq && !(f3 & FL_BLANK) && (f3 & FL_VALID) && !(f3 & FL_DROP) && !(f3 & FL_PREFIX);   // AddOne's tests; prefix tags are already in
+    uint32_t t3[2];
+    bool ok3[2];
+    uint64_t m_hop3 = 0;
+    for (int blk = 0; blk < 2; ++blk) {
+        t3[blk] = r2[blk].next;
+        bool hop = uniq[blk] && t3[blk] != t2[blk];
+        uint64_t mh = w.ballot(hop);
+        m_hop3 |= mh;
+        uint32_t f3 = r2[blk].flags;
+        if (mh && hop) f3 = t.rec[t3[blk]].flags;
+        ok3[blk] = uniq[blk] && !(f3 & FL_BLANK) && (f3 & FL_VALID) && !(f3 & FL_DROP) && !(f3 & FL_PREFIX);   // AddOne's tests; prefix tags are already in
+    }
     if (m_hop3) {
-        uint32_t key[2] = {t3, NO_ID};
-        bool valid[2] = {ok3, false};
         bool fst[2];
-        if (!dedupe_first(w, L, key, valid, fst)) return false;
-        if (w.ballot(ok3 && !fst[0])) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
+        if (!dedupe_first(w, L, t3, ok3, fst)) return false;
+        if (w.ballot((ok3[0] && !fst[0]) || (ok3[1] && !fst[1]))) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
     }
     uint32_t nr = t.n_prefix;
     {
-        const uint32_t bucket2 = fl_bucket(r2.flags);
         const int caps[6] = {3, 10, 8, 6, 4, style_cap};
-        bool taken = false;
-        uint32_t pos = 0;
-        for (uint32_t bk = 0; bk < 6; ++bk) {                     // FillBucket in order: the first `cap` eligible tags, while the list is short of 42
-            bool el = ok3 && bucket2 == bk;
-            uint64_t m = w.ballot(el);
+        bool taken[2] = {false, false};
+        uint32_t pos[2] = {0, 0};
+        for (uint32_t bk = 0; bk <= 6; ++bk) {                    // FillBucket for the six capped buckets in order, then (bk == 6) the final sweep (Program.cs:670-680)
+            bool el0 = ok3[0] && !taken[0] && (bk == 6 || fl_bucket(r2[0].flags) == bk);
+            bool el1 = ok3[1] && !taken[1] && (bk == 6 || fl_bucket(r2[1].flags) == bk);
+            uint64_t m0 = w.ballot(el0), m1 = w.ballot(el1);
             uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
-            uint32_t take = popc64(m);
-            if (take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
+            uint32_t take = popc64(m0) + popc64(m1);
+            if (bk < 6 && take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
             if (take > room) take = room;
-            uint32_t rank = popc64(m & lt);
-            if (el && rank < take) { taken = true; pos = nr + rank; }
-            nr += take;
-        }
-        {                                                         // final sweep over the sorted list (Program.cs:677-680)
-            bool el = ok3 && !taken;
-            uint64_t m = w.ballot(el);
-            uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
-            uint32_t take = popc64(m);
-            if (take > room) take = room;
-            uint32_t rank = popc64(m & lt);
-            if (el && rank < take) { taken = true; pos = nr + rank; }
+            uint32_t rank0 = popc64(m0 & lt), rank1 = popc64(m0) + popc64(m1 & lt);
+            if (el0 && rank0 < take) { taken[0] = true; pos[0] = nr + rank0; }
+            if (el1 && rank1 < take) { taken[1] = true; pos[1] = nr + rank1; }
             nr += take;
         }
         if (lane < t.n_prefix) L.fin[lane] = t.prefix_ids[lane];
-        if (taken) L.fin[pos] = t3;
+        if (taken[0]) L.fin[pos[0]] = t3[0];
+        if (taken[1]) L.fin[pos[1]] = t3[1];
         w.sync();
     }
     const uint32_t n_selected = nr;
@@ -426,37 +458,45 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     uint32_t n_evidence = 0;
     bool ev_feet = false, ev_penis = false;
     {
-        const uint64_t m_edge = w.ballot(ev_seed && (r2.flags & FL_EDGE));
-        if (ev_seed) {
-            if (r2.lit != NO_ID) w.lds_or(&L.ebits[r2.lit >> 5], 1u << (r2.lit & 31));
-            ev_feet = (r2.flags & FL_NFEET) != 0;                  // HasTag(evidenceTags, ...), Program.cs:309, 719
-            ev_penis = (r2.flags & FL_NPENIS) != 0;
+        uint64_t m_edge = 0;
+        for (int blk = 0; blk < 2; ++blk) {
+            m_edge |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE));
+            if (ev_seed[blk]) {
+                uint32_t li = r2[blk].lit;
+                if (li != NO_ID) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                ev_feet |= (r2[blk].flags & FL_NFEET) != 0;         // HasTag(evidenceTags, ...), Program.cs:309, 719
+                ev_penis |= (r2[blk].flags & FL_NPENIS) != 0;
+            }
         }
         if (!m_edge) {
-            n_evidence = popc64(w.ballot(ev_seed));
+            n_evidence = popc64(w.ballot(ev_seed[0])) + popc64(w.ballot(ev_seed[1]));
         } else {
             if (!t.closure_tables) return false;
             set_clear(w, L);
             uint32_t made = 0;
             bool full = false;
-            if (ev_seed) {
-                bool created;
-                if (set_put(w, L, t2, 0, created) == NO_ID) full = true;
-                made += created;
+            for (int blk = 0; blk < 2; ++blk) {
+                if (ev_seed[blk]) {
+                    bool created;
+                    if (set_put(w, L, t2[blk], 0, created) == NO_ID) full = true;
+                    made += created;
+                }
             }
             w.sync();
-            if (ev_seed && (r2.flags & FL_EDGE)) {
-                for (uint32_t m = t.reach_off[t2]; m < t.reach_off[t2 + 1] && !full; ++m) {
-                    uint32_t id = t.reach_ent[2 * m], info = t.reach_ent[2 * m + 1];
-                    bool created;
-                    if (set_put(w, L, id, 0, created) == NO_ID) { full = true; break; }
-                    if (created) {
-                        ++made;
-                        uint32_t li = info & 0xFFFFFFu;
-                        if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+            for (int blk = 0; blk < 2; ++blk) {
+                if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
+                    for (uint32_t m = t.reach_off[t2[blk]]; m < t.reach_off[t2[blk] + 1] && !full; ++m) {
+                        uint32_t id = t.reach_ent[2 * m], info = t.reach_ent[2 * m + 1];
+                        bool created;
+                        if (set_put(w, L, id, 0, created) == NO_ID) { full = true; break; }
+                        if (created) {
+                            ++made;
+                            uint32_t li = info & 0xFFFFFFu;
+                            if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                        }
+                        ev_feet |= (info >> 24) & 1u;
+                        ev_penis |= (info >> 25) & 1u;
                     }
-                    ev_feet |= (info >> 24) & 1u;
-                    ev_penis |= (info >> 25) & 1u;
                 }
             }
             if (w.ballot(full)) return false;
@@ -470,6 +510,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
 
     // ---- S9: final-set closure, in the reference's insertion order (ExpandImpliedTags, Program.cs:304, 1160-1179) ------------
     // The set grows breadth-first: a round visits every element in order and appends NormalizeTag(it) and its implied tags.
+    uint32_t gnext[2] = {EMPTY_ID, EMPTY_ID}, gflags[2] = {0, 0};   // NormalizeTag and flags of the entries this lane owns, read once here
     {
         uint32_t lo = 0, hi = nf;
         while (lo < hi) {
@@ -477,14 +518,14 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                 uint32_t idx = (uint32_t)blk * 64 + lane;
                 bool in = idx >= lo && idx < hi;
                 uint32_t id = blk == 0 ? own0 : own1;
-                uint32_t fl = in ? t.rec[id].flags : 0;
-                bool edge = in && (fl & FL_EDGE);
                 uint32_t so = 0, sc = 0, s0 = NO_ID, s1 = NO_ID;
-                if (edge) {
-                    so = t.step_off[id];
-                    sc = t.step_off[id + 1] - so;
-                    s0 = t.step_ids[so];
-                    if (sc > 1) s1 = t.step_ids[so + 1];
+                bool edge = false;
+                if (in) {
+                    Rec rr = t.rec[id];
+                    gnext[blk] = rr.next;
+                    gflags[blk] = rr.flags;
+                    edge = (rr.flags & FL_EDGE) != 0;
+                    so = rr.step_off; sc = rr.step_cnt; s0 = rr.step0; s1 = rr.step1;
                 }
                 uint64_t m = w.ballot(edge);
                 while (m) {
@@ -513,9 +554,8 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             uint32_t idx = (uint32_t)blk * 64 + lane;
             uint32_t id = blk == 0 ? own0 : own1;
             bool in = idx < nf;
-            Rec rr = t.rec[in ? id : EMPTY_ID];
-            g[blk] = rr.next;
-            nb[blk] = in && !(rr.flags & FL_NEXT_BLANK);
+            g[blk] = gnext[blk];
+            nb[blk] = in && !(gflags[blk] & FL_NEXT_BLANK);
             if (in && (g[blk] != id || !nb[blk])) changed = true;
         }
         if (w.ballot(changed)) {

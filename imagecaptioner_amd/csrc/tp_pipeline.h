@@ -153,7 +153,6 @@ TP_HD uint32_t classify_dyn(const DevTables& t, const uint8_t* p, uint32_t n) {
 
 // Hash-table probe with the candidate bytes given as plain memory.
 TP_HD uint32_t probe_bytes(const DevTables& t, const uint8_t* p, uint32_t n, uint64_t hash) {
-    if (hash == 0) hash = 1;
     uint32_t slot = (uint32_t)hash & t.ht_mask;
     for (;;) {
         uint64_t hh = t.ht_hash[slot];
@@ -215,18 +214,18 @@ TP_HD bool make_token(const DevTables& t, FileWs& ws, uint32_t& norm_used, const
             tail = j;
         }
         // pass 1: hash + length
-        uint64_t hsh = HASH_SEED;
-        uint32_t n = 0;
+        Hasher hs;
         bool last_us = false;
         {
             NormIt it(s, i, tail);
-            for (int c; (c = it.next()) >= 0;) { hsh = hash_step(hsh, (uint8_t)c); ++n; }
+            for (int c; (c = it.next()) >= 0;) hs.add((uint8_t)c);
             last_us = it.last_us;
         }
         bool add_us = (tail < j) && !last_us;          // the kept '\n' -> '_' unless it merges with a preceding '_'
         if (tail == j) add_us = false;                 // newline already inside [i,tail)
-        if (add_us) { hsh = hash_step(hsh, '_'); ++n; }
-        hsh = hash_fin(hsh);
+        if (add_us) hs.add('_');
+        const uint32_t n = hs.n;
+        const uint64_t hsh = hs.done();
         // materialise (rare path) and look it up
         if (n > MAX_DYN_LEN || norm_used + n > ws.cap_norm) { unsupported = true; return false; }
         uint8_t* dst = ws.norm + norm_used;
@@ -245,14 +244,13 @@ TP_HD bool make_token(const DevTables& t, FileWs& ws, uint32_t& norm_used, const
     while (tail > i && is_punct8(s[tail - 1])) --tail;
     j = tail;
     // pass 1: hash and length of the normalised form
-    uint64_t hsh = HASH_SEED;
-    uint32_t n = 0;
+    Hasher hs;
     {
         NormIt it(s, i, j);
-        for (int c; (c = it.next()) >= 0;) { hsh = hash_step(hsh, (uint8_t)c); ++n; }
+        for (int c; (c = it.next()) >= 0;) hs.add((uint8_t)c);
     }
-    hsh = hash_fin(hsh);
-    if (hsh == 0) hsh = 1;
+    const uint32_t n = hs.n;
+    const uint64_t hsh = hs.done();
     // probe, verifying the bytes against the stream
     uint32_t slot = (uint32_t)hsh & t.ht_mask;
     for (;;) {
@@ -293,9 +291,9 @@ TP_HD H norm_hop(const DevTables& t, const FileWs& ws, H h) {
     while (n > 0 && is_quote8(p[n - 1])) --n;
     while (n > 0 && is_punct8(p[n - 1])) --n;
     if (n == 0) return t.alias1[EMPTY_ID];
-    uint64_t hsh = HASH_SEED;
-    for (uint32_t k = 0; k < n; ++k) hsh = hash_step(hsh, p[k]);
-    uint32_t id = probe_bytes(t, p, n, hash_fin(hsh));
+    Hasher hs;
+    for (uint32_t k = 0; k < n; ++k) hs.add(p[k]);
+    uint32_t id = probe_bytes(t, p, n, hs.done());
     if (id != NO_ID) return t.alias1[id];
     return h_make_dyn(h_off(h), n, classify_dyn(t, p, n), is_quote8(p[n - 1]));
 }

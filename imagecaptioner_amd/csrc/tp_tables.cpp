@@ -881,10 +881,9 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     out.ht_hash.assign(slots, 0);
     out.ht_id.assign(slots, NO_ID);
     for (uint32_t i = 0; i < N; ++i) {
-        uint64_t h = HASH_SEED;
-        for (unsigned char c : out.strings[i]) h = hash_step(h, c);
-        h = hash_fin(h);
-        if (h == 0) h = 1;
+        Hasher hs;
+        for (unsigned char c : out.strings[i]) hs.add(c);
+        uint64_t h = hs.done();
         uint32_t s = (uint32_t)h & (slots - 1);
         while (out.ht_hash[s] != 0) s = (s + 1) & (slots - 1);
         out.ht_hash[s] = h;
@@ -1009,12 +1008,28 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     if (out.step_ids.empty()) out.step_ids.push_back(0);
     if (out.reach_ent.empty()) { out.reach_ent.push_back(0); out.reach_ent.push_back(0); }
     out.rec.resize(N);
-    for (uint32_t i = 0; i < N; ++i) out.rec[i] = Rec{out.flags[i], out.next[i], out.lit[i], out.str_off[i + 1] - out.str_off[i]};
+    for (uint32_t i = 0; i < N; ++i) {
+        uint32_t so = out.step_off[i], sc = out.step_off[i + 1] - so;
+        out.rec[i] = Rec{out.flags[i], out.next[i], out.lit[i], out.str_off[i + 1] - out.str_off[i], so, sc,
+                         sc > 0 ? out.step_ids[so] : NO_ID, sc > 1 ? out.step_ids[so + 1] : NO_ID};
+    }
+    std::vector<uint32_t> word_off(N);
+    out.str_words.clear();
+    for (uint32_t i = 0; i < N; ++i) {
+        word_off[i] = (uint32_t)out.str_words.size();
+        const std::string& str = out.strings[i];
+        for (size_t b = 0; b < str.size(); b += 8) {
+            uint64_t wv = 0;
+            for (size_t k = 0; k < 8 && b + k < str.size(); ++k) wv |= (uint64_t)(unsigned char)str[b + k] << (8 * k);
+            out.str_words.push_back(wv);
+        }
+    }
+    out.str_words.push_back(0);
     out.ht_info.assign(slots, HtInfo{0, 0, 0, 0});
     for (uint32_t s = 0; s < slots; ++s) {
         if (!out.ht_hash[s]) continue;
         uint32_t id = out.ht_id[s];
-        out.ht_info[s] = HtInfo{out.alias1[id], out.str_off[id], out.str_off[id + 1] - out.str_off[id], 0};
+        out.ht_info[s] = HtInfo{out.alias1[id], word_off[id], out.str_off[id + 1] - out.str_off[id], 0};
     }
     // the wave-per-file kernel keeps its literal bitset in 128 LDS words and assumes scores fall with the token index
     sc.fast_ok = (sc.lit_words <= 128 && sc.fired_words <= 64 && n_lits < 0xFFFFFFu && cfg.line_weight > 0.0) ? 1 : 0;
@@ -1058,6 +1073,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.facet_rules = ht.facet_rules.data();
     t.rec = ht.rec.data();
     t.ht_info = ht.ht_info.data();
+    t.str_words = ht.str_words.data();
     t.step_off = ht.step_off.data();
     t.step_ids = ht.step_ids.data();
     t.reach_off = ht.reach_off.data();

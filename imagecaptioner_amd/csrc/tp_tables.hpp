@@ -30,6 +30,7 @@ struct HostTables {
     std::vector<DSub> facet_rules;
     std::vector<Rec> rec;
     std::vector<HtInfo> ht_info;
+    std::vector<uint64_t> str_words;
     std::vector<uint32_t> step_off, step_ids, reach_off, reach_ent;
     DevTables scalars;                      // scalar members filled, pointer members null
     // host-side facts
