@@ -14,7 +14,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 
 SOURCES = ["tp_kernels.hip", "tp_api.cpp", "tp_tables.cpp"]
-HEADERS = ["tp_common.h", "tp_pipeline.h", "tp_launch.h", "tp_tables.hpp", "tp_json.hpp", "tp_case_tables.inc",
+HEADERS = ["tp_common.h", "tp_pipeline.h", "tp_fast.h", "tp_launch.h", "tp_tables.hpp", "tp_json.hpp", "tp_case_tables.inc",
            os.path.join("..", "..", "include", "tagpipe.h")]
 # -ffp-contract=off: the score arithmetic (1.0 - i * 0.01) must round like the reference's, with no fused multiply-add.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -27,13 +27,20 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, prof=False):
+    """prof=True builds the diagnostic variant libtagpipe_hip_prof.so (per-section cycle counters inside k_fast)."""
+    if prof:
+        return _build(LIB.replace(".so", "_prof.so"), "_prof.o", ["-DTP_PROF"], verbose)
     if not force and not _stale():
         return LIB
+    return _build(LIB, ".o", [], verbose)
+
+
+def _build(lib, obj_suffix, extra, verbose):
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [HIPCC, "--offload-arch=gfx950"] + COMMON
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + obj_suffix)
+        cmd = [HIPCC, "--offload-arch=gfx950"] + COMMON + extra
         if src.endswith(".hip"):
             cmd += ["-x", "hip"]
         else:
@@ -43,12 +50,12 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, prof="--prof" in sys.argv)

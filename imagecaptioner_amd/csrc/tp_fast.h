@@ -32,8 +32,9 @@ constexpr uint32_t FAST_LIT_WORDS = 128;   // evidence bitset words (4096 rule l
 constexpr uint32_t FAST_FIRED_WORDS = 64;  // fired-rule bitmap words (2048 rules + subtypes)
 
 struct alignas(16) FastLds {
-    uint8_t line[FAST_LINE_MAX + 48];
+    uint8_t line[FAST_LINE_MAX + 96];
     uint16_t cpos[FAST_TOK_MAX];
+    uint32_t tspec[FAST_TOK_MAX / 32];   // bit k: token k holds a byte that needs the byte-wise normaliser
     uint32_t cand[FAST_TOK_MAX];
     uint32_t fin[FAST_FIN_MAX];
     uint32_t set_key[FAST_SET_SLOTS];
@@ -70,6 +71,30 @@ TP_HD uint32_t clz64(uint64_t x) {   // x != 0
 #endif
 }
 
+// Branch-free byte predicates on values < 0x80 (results are 0 / 1).
+TP_HD uint32_t ws32(uint32_t c) { return (uint32_t)(c == 0x20u) | (uint32_t)(c - 9u <= 4u); }      // char.IsWhiteSpace below U+0080
+TP_HD uint32_t upper32(uint32_t c) { return (uint32_t)(c - 'A' <= 25u); }
+TP_HD uint32_t alnum32(uint32_t c) { return (uint32_t)(c - 'a' <= 25u) | (uint32_t)(c - '0' <= 9u); }   // lower-case letters and digits
+// the other characters ValidTagRegex allows after the first one: _ ( ) ! ' / -   (Program.cs:40)
+TP_HD uint32_t tagextra32(uint32_t c) {
+    constexpr uint64_t M = (1ull << ('!' - 32)) | (1ull << ('\'' - 32)) | (1ull << ('(' - 32)) | (1ull << (')' - 32)) | (1ull << ('-' - 32)) | (1ull << ('/' - 32)) | (1ull << ('_' - 32));
+    return (uint32_t)(M >> ((c - 32u) & 63u)) & (uint32_t)(c - 32u < 64u);
+}
+TP_HD uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+TP_HD uint64_t ld64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+// Lower-cases four ASCII bytes at once; a byte >= 0x80 only disturbs the bytes above it.
+TP_HD uint32_t lower4(uint32_t x) {
+    uint32_t up = ((x + 0x3F3F3F3Fu) & ~(x + 0x25252525u)) & 0x80808080u;
+    return x | (up >> 2);
+}
+constexpr uint32_t c4(char a, char b, char c, char d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
+// The low min(max(n - 8k, 0), 8) bytes of word k of an n-byte string.
+TP_HD uint64_t word_mask(uint32_t n, uint32_t k) {
+    int rem = (int)n - (int)(8 * k);
+    rem = rem < 0 ? 0 : (rem > 8 ? 8 : rem);
+    return rem == 8 ? ~0ull : ((1ull << (8 * rem)) - 1);
+}
+
 template <class W>
 TP_HD uint32_t wave_sum(W& w, uint32_t v) {
     for (uint32_t d = 32; d >= 1; d >>= 1) v += w.shfl(v, w.lane() ^ d);
@@ -79,7 +104,9 @@ TP_HD uint32_t wave_sum(W& w, uint32_t v) {
 // ---- LDS hash set: key -> smallest order value seen ---------------------------------------------------------------
 template <class W>
 TP_HD void set_clear(W& w, FastLds& L) {
-    for (uint32_t k = w.lane(); k < FAST_SET_SLOTS; k += 64) { L.set_key[k] = NO_ID; L.set_min[k] = 0xFFFFFFFFu; }
+    static_assert(FAST_SET_SLOTS == 256 && NO_ID == 0xFFFFFFFFu, "one 16-byte store per lane and array");
+    w.fill16(&L.set_key[4 * w.lane()], 0xFFFFFFFFu);
+    w.fill16(&L.set_min[4 * w.lane()], 0xFFFFFFFFu);
     w.sync();
 }
 // Returns the slot, or NO_ID when the table is full.  `created` is true for exactly one caller per key.
@@ -127,39 +154,80 @@ TP_HD bool lds_match(const uint8_t* s, uint32_t pos, uint32_t end, const char* p
     return true;
 }
 
+// Hash-table lookup of a normalised string of n <= 32 bytes given as zero-padded little-endian words.
+TP_HD uint32_t ht_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3) {
+    uint32_t slot = (uint32_t)hsh & t.ht_mask;
+    for (;;) {
+        uint64_t hh = t.ht_hash[slot];
+        if (hh == 0) return NO_ID;
+        if (hh == hsh) {
+            HtInfo info = t.ht_info[slot];
+            if (info.slen == n) {
+                const uint64_t* q = t.str_words + info.woff;     // the arena ends with three spare words
+                uint64_t d = q[0] ^ w0;
+                d |= n > 8 ? q[1] ^ w1 : 0;
+                d |= n > 16 ? q[2] ^ w2 : 0;
+                d |= n > 24 ? q[3] ^ w3 : 0;
+                if (d == 0) return info.val;
+            }
+        }
+        slot = (slot + 1) & t.ht_mask;
+    }
+}
+
 // One token of the line (LDS bytes [i, j)) -> what NormalizeTag makes of it (Program.cs:1149-1158).
 //   returns 0: empty after trimming, skipped (Program.cs:1183-1185)
 //           1: interned, id in `out`
 //           2: not in any table
-// The normalised bytes are packed into 8-byte words as they are produced (the first 32 bytes stay in registers), so
-// hashing costs one multiply per word and a probe hit is verified word by word against DevTables::str_words.
-TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, uint32_t& out, bool& valid_dyn, uint32_t& dyn_len) {
-    while (i < j && is_ws8(s[i])) ++i;
-    while (j > i && is_ws8(s[j - 1])) --j;
+// `special` is false when the token is known to hold nothing for the normaliser to change apart from one leading
+// white-space byte: then its bytes are the normalised string and are hashed straight from the line.  Otherwise the
+// bytes go through the byte-wise normaliser; they are packed into 8-byte words as they are produced (the first 32 bytes
+// stay in registers), so hashing costs one multiply per word and a probe hit is verified word by word against
+// DevTables::str_words.
+TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, bool special, uint32_t& out, bool& valid_dyn, uint32_t& dyn_len) {
+    if (!special) {
+        const uint32_t i1 = i + ((uint32_t)(i < j) & ws32(s[i]));
+        const uint32_t n = j - i1;
+        if (n == 0) return 0;
+        if (n <= 32) {
+            const uint64_t w0 = ld64u(s + i1) & word_mask(n, 0), w1 = ld64u(s + i1 + 8) & word_mask(n, 1), w2 = ld64u(s + i1 + 16) & word_mask(n, 2),
+                           w3 = ld64u(s + i1 + 24) & word_mask(n, 3);
+            uint64_t h = hash_word(HASH_SEED, w0);
+            h = n > 8 ? hash_word(h, w1) : h;
+            h = n > 16 ? hash_word(h, w2) : h;
+            h = n > 24 ? hash_word(h, w3) : h;
+            uint32_t id = ht_find32(t, hash_finish(h, n), n, w0, w1, w2, w3);
+            if (id != NO_ID) { out = id; return 1; }
+        }
+    }
+    while (i < j && ws32(s[i])) ++i;
+    while (j > i && ws32(s[j - 1])) --j;
     if (i == j) return 0;
     while (i < j && is_quote8(s[i])) ++i;
     while (j > i && is_quote8(s[j - 1])) --j;
     while (j > i && is_punct8(s[j - 1])) --j;
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, cur = 0, h = HASH_SEED;
-    uint32_t n = 0;
-    bool last_us = false, valid = true;
+    uint32_t n = 0, last_us = 0, valid = 1;
     for (uint32_t p = i; p < j; ++p) {                       // \s+ -> "_", _+ -> "_", lower case (Program.cs:1152-1154)
-        uint8_t c = s[p];
-        if (is_ws8(c) || c == '_') { if (last_us) continue; last_us = true; c = '_'; }
-        else { last_us = false; c = lower8(c); }
-        if (!(n == 0 ? is_tag_first8(c) : is_tag_rest8(c))) valid = false;
-        cur |= (uint64_t)c << (8 * (n & 7));
-        if ((++n & 7) == 0) {
+        uint32_t c = s[p];
+        const uint32_t us = ws32(c) | (uint32_t)(c == '_');
+        const uint32_t skip = us & last_us;
+        last_us = us;
+        c = us ? (uint32_t)'_' : c + (upper32(c) << 5);
+        valid &= skip | alnum32(c) | ((uint32_t)(n != 0) & tagextra32(c));
+        cur |= skip ? 0ull : (uint64_t)c << (8 * (n & 7));
+        n += 1u - skip;
+        if (!skip && (n & 7) == 0) {
             h = hash_word(h, cur);
-            uint32_t wi = (n >> 3) - 1;
-            if (wi == 0) w0 = cur; else if (wi == 1) w1 = cur; else if (wi == 2) w2 = cur; else if (wi == 3) w3 = cur;
+            const uint32_t wi = (n >> 3) - 1;
+            w0 = wi == 0 ? cur : w0; w1 = wi == 1 ? cur : w1; w2 = wi == 2 ? cur : w2; w3 = wi == 3 ? cur : w3;
             cur = 0;
         }
     }
     if (n & 7) {
         h = hash_word(h, cur);
-        uint32_t wi = n >> 3;
-        if (wi == 0) w0 = cur; else if (wi == 1) w1 = cur; else if (wi == 2) w2 = cur; else if (wi == 3) w3 = cur;
+        const uint32_t wi = n >> 3;
+        w0 = wi == 0 ? cur : w0; w1 = wi == 1 ? cur : w1; w2 = wi == 2 ? cur : w2; w3 = wi == 3 ? cur : w3;
     }
     const uint64_t hsh = hash_finish(h, n);
     const uint32_t nwords = (n + 7) >> 3;
@@ -194,7 +262,7 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
         }
         slot = (slot + 1) & t.ht_mask;
     }
-    valid_dyn = valid && n > 0;
+    valid_dyn = valid != 0 && n > 0;
     dyn_len = n;
     return 2;
 }
@@ -217,14 +285,19 @@ TP_HD bool f_match_sub(const DevTables& t, const FastLds& L, const DSub& r) {
 
 // Appends `id` to the final list unless present.  own0/own1 mirror L.fin[lane], L.fin[lane + 64] in registers.
 // Wave-uniform: `id`, `nf` and the return value are the same in every lane.  Returns false on overflow.
+// With in_set the LDS set (which then holds every element of the list with order 0) learns the new element too.
 template <class W>
-TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id) {
+TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id, bool in_set = false) {
     if (w.ballot(own0 == id || own1 == id) != 0) return true;
     if (nf >= FAST_FIN_MAX) return false;
     if (w.lane() == (nf & 63)) { if (nf < 64) own0 = id; else own1 = id; }
-    if (w.lane() == 0) L.fin[nf] = id;
+    bool full = false;
+    if (w.lane() == 0) {
+        L.fin[nf] = id;
+        if (in_set) { bool created; full = set_put(w, L, id, 0, created) == NO_ID; }
+    }
     ++nf;
-    return true;
+    return in_set ? w.ballot(full) == 0 : true;
 }
 
 // The pipeline for one file.  Returns false when the file needs the general kernel.
@@ -235,6 +308,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     const uint32_t lane = w.lane();
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (len > FAST_LINE_MAX) return false;
+    w.tick(0);
 
     // ---- S1: line -> LDS in aligned 16-byte pieces -------------------------------------------------------------------
     const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
@@ -242,60 +316,78 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         const uint8_t* abase = text - shift;
         uint32_t pieces = (shift + len + 15) >> 4;
         for (uint32_t c = lane; c < pieces; c += 64) w.copy16(L.line + 16 * c, abase + 16 * c);
+        if (lane < FAST_TOK_MAX / 32) L.tspec[lane] = 0;
     }
     w.sync();
+    w.tick(1);
     const uint8_t* s = L.line + shift;
 
     // ---- S2: character classes, trim (NormalizeRawTagLine, Program.cs:589-596) ------------------------------------------
     uint32_t first_nonws = 0xFFFFFFFFu, end_nonws = 0, first_nl = 0xFFFFFFFFu, last_nl = 0;
-    bool odd = false;
+    uint64_t any_odd = 0;
     for (uint32_t base = 0; base < len; base += 64) {
-        uint32_t p = base + lane;
-        uint8_t c = p < len ? s[p] : (uint8_t)' ';
-        uint64_t m_nonws = w.ballot(!is_ws8(c));
-        uint64_t m_odd = w.ballot(c >= 0x80 || c == '`');
-        uint64_t m_colon = w.ballot(c == ':');
-        uint64_t m_nl = w.ballot(p < len && (c == '\r' || c == '\n'));
-        if (m_odd) odd = true;
-        if (m_colon) {   // only "positive:" / "negative:" matter (Program.cs:57, 592-594); other colons are ordinary tag text
-            bool key = c == ':' && p >= 8 && (lds_match(s, p - 8, len, "positive", 8) || lds_match(s, p - 8, len, "negative", 8));
-            if (w.ballot(key)) odd = true;
-        }
+        const uint32_t p = base + lane;
+        uint32_t c = s[p];
+        c = p < len ? c : 0x20u;
+        const uint64_t m_nonws = w.ballot(!ws32(c));
+        any_odd |= w.ballot((c >= 0x80u) | (c == '`'));
+        const uint64_t m_nl = w.ballot((c == '\r') | (c == '\n'));
         if (m_nonws) { if (first_nonws == 0xFFFFFFFFu) first_nonws = base + ctz64(m_nonws); end_nonws = base + 64 - clz64(m_nonws); }
         if (m_nl) { if (first_nl == 0xFFFFFFFFu) first_nl = base + ctz64(m_nl); last_nl = base + 63 - clz64(m_nl); }
     }
-    if (odd) return false;
+    if (any_odd) return false;
     const bool blank_line = first_nonws == 0xFFFFFFFFu;
     const uint32_t a = blank_line ? 0 : first_nonws, b = blank_line ? 0 : end_nonws;
     if (!blank_line && first_nl != 0xFFFFFFFFu && first_nl < b && last_nl > a) return false;   // a line break may sit inside the text
 
-    // commas and LooksBad (Program.cs:1141-1147)
+    // commas, tokens that need the byte-wise normaliser, LooksBad (Program.cs:1141-1147)
     uint32_t ncomma = 0;
-    bool refusal = false;
+    bool refusal = false, keyword = false;
     for (uint32_t base = a; base < b; base += 64) {
-        uint32_t p = base + lane;
-        bool inb = p < b;
-        uint8_t c = inb ? s[p] : 0;
-        uint64_t m_c = w.ballot(inb && c == ',');
-        if (inb && c == ',') { uint32_t k = ncomma + popc64(m_c & lt); if (k < FAST_TOK_MAX) L.cpos[k] = (uint16_t)p; }
+        const uint32_t p = base + lane;
+        const bool inb = p < b;
+        const uint32_t c = s[p];
+        const uint32_t prev = p > a ? (uint32_t)s[p - 1] : (uint32_t)',';
+        const bool comma = inb & (c == ',');
+        const uint64_t m_c = w.ballot(comma);
+        const uint32_t k = ncomma + popc64(m_c & lt);             // commas before p = index of the token p belongs to
+        if (comma && k < FAST_TOK_MAX) L.cpos[k] = (uint16_t)p;
         ncomma += popc64(m_c);
-        bool hit = false;
-        if (inb) {
-            switch (lower8(c)) {                                  // DropTagsContains without the two entries that hold ':' (Program.cs:56-58)
-                case 's': hit = lds_match(s, p, b, "sorry", 5); break;
-                case 'i': hit = lds_match(s, p, b, "i can't", 7) || lds_match(s, p, b, "i cannot", 8) || lds_match(s, p, b, "i'm not able", 12) || lds_match(s, p, b, "i won't", 7); break;
-                case 'c': hit = lds_match(s, p, b, "cannot provide", 14); break;
-                case 'u': hit = lds_match(s, p, b, "unable to", 9); break;
-                case 'a': hit = lds_match(s, p, b, "as an ai", 8); break;
-                default: break;
-            }
+        // A byte the normaliser would change or drop: upper case, quotes, trailing-punctuation characters, white space
+        // other than a single byte right after a comma, the second of two underscores.
+        const uint32_t wsb = ws32(c);
+        const uint32_t sp = upper32(c) | (uint32_t)(c == '"') | (uint32_t)(c == '\'') | (uint32_t)(c == ';') | (uint32_t)(c == '.') |
+                            (wsb & (uint32_t)(prev != ',')) | ((uint32_t)(c == '_') & (uint32_t)(prev == '_'));
+        if (inb && sp && k < FAST_TOK_MAX) w.lds_or(&L.tspec[k >> 5], 1u << (k & 31));
+        if (w.ballot(inb & (c == ':'))) {   // only "positive:" / "negative:" matter (Program.cs:57, 592-594); other colons are ordinary tag text
+            bool key = inb && c == ':' && p >= 8 && (lds_match(s, p - 8, len, "positive", 8) || lds_match(s, p - 8, len, "negative", 8));
+            if (w.ballot(key)) keyword = true;
         }
-        if (w.ballot(hit)) refusal = true;
+        // DropTagsContains without the two entries that hold ':' (Program.cs:56-58): compare four bytes first
+        const uint32_t q = lower4(ld32u(s + p));
+        const bool pre = inb & ((q == c4('s', 'o', 'r', 'r')) | (q == c4('i', ' ', 'c', 'a')) | (q == c4('i', '\'', 'm', ' ')) | (q == c4('i', ' ', 'w', 'o')) |
+                                (q == c4('c', 'a', 'n', 'n')) | (q == c4('u', 'n', 'a', 'b')) | (q == c4('a', 's', ' ', 'a')));
+        if (w.ballot(pre)) {
+            bool hit = false;
+            if (pre) {
+                switch (q & 0xFFu) {
+                    case 's': hit = lds_match(s, p, b, "sorry", 5); break;
+                    case 'i': hit = lds_match(s, p, b, "i can't", 7) || lds_match(s, p, b, "i cannot", 8) || lds_match(s, p, b, "i'm not able", 12) || lds_match(s, p, b, "i won't", 7); break;
+                    case 'c': hit = lds_match(s, p, b, "cannot provide", 14); break;
+                    case 'u': hit = lds_match(s, p, b, "unable to", 9); break;
+                    case 'a': hit = lds_match(s, p, b, "as an ai", 8); break;
+                    default: break;
+                }
+            }
+            if (w.ballot(hit)) refusal = true;
+        }
     }
+    if (keyword) return false;
     const uint32_t T = ncomma + 1;
     if (T > FAST_TOK_MAX) return false;
     const bool rejected = blank_line || refusal || (ncomma < 2 && (b - a) > 40);
     w.sync();
+    w.tick(2);
 
     // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
     uint32_t n = 0;   // candidates, two per lane: candidate index = blk * 64 + lane
@@ -311,7 +403,8 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                     uint32_t j = tix == T - 1 ? b : (uint32_t)L.cpos[tix];
                     uint32_t id = NO_ID, dlen = 0;
                     bool vdyn = false;
-                    int kind = fast_token(t, s, i, j, id, vdyn, dlen);
+                    const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u;
+                    int kind = fast_token(t, s, i, j, special, id, vdyn, dlen);
                     if (kind == 1) {
                         uint32_t f = t.rec[id].flags;
                         if ((f & FL_LEN2) && !(f & FL_DROP)) { tid[blk] = id; keep[blk] = true; }
@@ -332,6 +425,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         w.sync();
     }
 
+    w.tick(3);
     // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
     // In line ingest the scores fall with the candidate index, so "sorted" order is candidate order and the first of
     // two candidates that NormalizeTag merges carries the merged score, order and source.
@@ -369,6 +463,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         ev_seed[blk] = ev_seed[blk] && first2[blk];
     }
 
+    w.tick(4);
     // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
     uint32_t t3[2];
     bool ok3[2];
@@ -412,6 +507,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
     const uint32_t n_selected = nr;
 
+    w.tick(5);
     // ---- S7: EvaluateCoverage (Program.cs:1056-1095) and normalizedFinalSet (Program.cs:303) -------------------------------
     uint32_t own0 = NO_ID, own1 = NO_ID;   // the final list, entry k in lane k & 63
     uint32_t nf = 0;
@@ -452,6 +548,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
     uint32_t flags = (rejected ? TP_F_LINE_REJECTED : 0u) | (nr < 3 ? TP_F_FALLBACK : 0u);
 
+    w.tick(6);
     // ---- S8: evidence closure (Program.cs:301-302) -> literal bitset, count, feet/penis ---------------------------------------
     for (uint32_t k = lane; k < t.lit_words; k += 64) L.ebits[k] = 0;
     w.sync();
@@ -508,42 +605,90 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         w.sync();
     }
 
+    w.tick(7);
     // ---- S9: final-set closure, in the reference's insertion order (ExpandImpliedTags, Program.cs:304, 1160-1179) ------------
-    // The set grows breadth-first: a round visits every element in order and appends NormalizeTag(it) and its implied tags.
+    // The set grows breadth-first: a round visits every element in order and appends NormalizeTag(it) and its implied tags
+    // (its "steps").  A round whose elements have at most two steps each runs in parallel: every step is offered to the LDS
+    // set under the key (element index, step index); the smallest key of an id new to the set wins, and a winner's place
+    // in the list is the number of winners with smaller keys.  From here to S11 the set holds the list's elements.
     uint32_t gnext[2] = {EMPTY_ID, EMPTY_ID}, gflags[2] = {0, 0};   // NormalizeTag and flags of the entries this lane owns, read once here
     {
+        set_clear(w, L);
+        if (lane < nf) { bool created; set_put(w, L, own0, 0, created); }   // nf <= 64 here, and 256 slots cannot fill up
+        w.sync();
         uint32_t lo = 0, hi = nf;
         while (lo < hi) {
-            for (int blk = 0; blk < 2; ++blk) {
-                uint32_t idx = (uint32_t)blk * 64 + lane;
-                bool in = idx >= lo && idx < hi;
-                uint32_t id = blk == 0 ? own0 : own1;
-                uint32_t so = 0, sc = 0, s0 = NO_ID, s1 = NO_ID;
-                bool edge = false;
+            const int nblk = hi > 64 ? 2 : 1;
+            uint32_t so[2] = {0, 0}, sc[2] = {0, 0}, sid[2][2] = {{NO_ID, NO_ID}, {NO_ID, NO_ID}};
+            bool edge[2] = {false, false};
+            uint64_t m_edge[2] = {0, 0}, m_long = 0;
+            for (int blk = 0; blk < nblk; ++blk) {
+                const uint32_t idx = (uint32_t)blk * 64 + lane;
+                const bool in = idx >= lo && idx < hi;
                 if (in) {
-                    Rec rr = t.rec[id];
+                    const Rec rr = t.rec[blk == 0 ? own0 : own1];
                     gnext[blk] = rr.next;
                     gflags[blk] = rr.flags;
-                    edge = (rr.flags & FL_EDGE) != 0;
-                    so = rr.step_off; sc = rr.step_cnt; s0 = rr.step0; s1 = rr.step1;
+                    edge[blk] = (rr.flags & FL_EDGE) != 0;
+                    so[blk] = rr.step_off; sc[blk] = rr.step_cnt; sid[blk][0] = rr.step0; sid[blk][1] = rr.step1;
                 }
-                uint64_t m = w.ballot(edge);
-                while (m) {
-                    uint32_t q = ctz64(m);
-                    m &= m - 1;
-                    uint32_t cnt = w.shfl(sc, q), off = w.shfl(so, q), a0 = w.shfl(s0, q), a1 = w.shfl(s1, q);
-                    for (uint32_t k = 0; k < cnt; ++k) {
-                        uint32_t sid = k == 0 ? a0 : (k == 1 ? a1 : t.step_ids[off + k]);
-                        if (!fin_append(w, L, own0, own1, nf, sid)) return false;
+                m_edge[blk] = w.ballot(edge[blk]);
+                m_long |= w.ballot(edge[blk] && sc[blk] > 2);
+            }
+            const uint32_t nf0 = nf;
+            if (m_long) {                                          // long step lists: one element at a time
+                for (int blk = 0; blk < nblk; ++blk) {
+                    uint64_t m = m_edge[blk];
+                    while (m) {
+                        const uint32_t q = ctz64(m);
+                        m &= m - 1;
+                        const uint32_t cnt = w.shfl(sc[blk], q), off = w.shfl(so[blk], q), a0 = w.shfl(sid[blk][0], q), a1 = w.shfl(sid[blk][1], q);
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                            const uint32_t x = k == 0 ? a0 : (k == 1 ? a1 : t.step_ids[off + k]);
+                            if (!fin_append(w, L, own0, own1, nf, x, true)) return false;
+                        }
                     }
                 }
+                w.sync();
+            } else if (m_edge[0] | m_edge[1]) {
+                uint32_t slot[2][2] = {{NO_ID, NO_ID}, {NO_ID, NO_ID}};
+                bool full = false;
+                for (int blk = 0; blk < nblk; ++blk)
+                    for (uint32_t j = 0; j < 2; ++j)
+                        if (edge[blk] && j < sc[blk]) {
+                            bool created;
+                            slot[blk][j] = set_put(w, L, sid[blk][j], 1 + ((((uint32_t)blk * 64 + lane) << 1) | j), created);
+                            if (slot[blk][j] == NO_ID) full = true;
+                        }
+                w.sync();
+                if (w.ballot(full)) return false;
+                bool win[2][2] = {{false, false}, {false, false}};
+                uint64_t mw[2][2] = {{0, 0}, {0, 0}};
+                for (int blk = 0; blk < nblk; ++blk)
+                    for (uint32_t j = 0; j < 2; ++j) {
+                        win[blk][j] = slot[blk][j] != NO_ID && L.set_min[slot[blk][j]] == 1 + ((((uint32_t)blk * 64 + lane) << 1) | j);
+                        mw[blk][j] = w.ballot(win[blk][j]);
+                    }
+                const uint32_t c0 = popc64(mw[0][0]) + popc64(mw[0][1]), c1 = popc64(mw[1][0]) + popc64(mw[1][1]);
+                if (nf + c0 + c1 > FAST_FIN_MAX) return false;
+                for (int blk = 0; blk < nblk; ++blk) {
+                    uint32_t pos = nf + (blk ? c0 : 0) + popc64(mw[blk][0] & lt) + popc64(mw[blk][1] & lt);
+                    if (win[blk][0]) { L.fin[pos] = sid[blk][0]; L.set_min[slot[blk][0]] = 0; ++pos; }
+                    if (win[blk][1]) { L.fin[pos] = sid[blk][1]; L.set_min[slot[blk][1]] = 0; }
+                }
+                nf += c0 + c1;
+                w.sync();
+                own0 = lane < nf ? L.fin[lane] : NO_ID;
+                own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
             }
+            (void)nf0;
             lo = hi;
             hi = nf;
         }
         w.sync();
     }
 
+    w.tick(8);
     // ---- S10: InferActionTags (Program.cs:731-753) ---------------------------------------------------------------------------
     {
         // inferred = Select(NormalizeTag).Where(non-blank).Distinct()
@@ -568,6 +713,11 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             w.sync();
             own0 = lane < nf ? L.fin[lane] : NO_ID;
             own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
+            set_clear(w, L);                                       // the set follows the rewritten list
+            bool created;
+            if (lane < nf) set_put(w, L, own0, 0, created);
+            if (lane + 64 < nf) set_put(w, L, own1, 0, created);
+            w.sync();
         }
         if (lane < t.fired_words) L.firedw[lane] = 0;
         w.sync();
@@ -585,7 +735,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                 uint32_t q = ctz64(m);
                 m &= m - 1;
                 uint32_t parent = w.shfl(rule.parent_id, q), sub_off = w.shfl(rule.sub_off, q), sub_cnt = w.shfl(rule.sub_cnt, q);
-                if (!fin_append(w, L, own0, own1, nf, parent)) return false;
+                if (!fin_append(w, L, own0, own1, nf, parent, true)) return false;
                 for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
                     uint32_t si = s0 + lane;
                     bool shit = false;
@@ -599,12 +749,13 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                     while (ms) {
                         uint32_t qs = ctz64(ms);
                         ms &= ms - 1;
-                        if (!fin_append(w, L, own0, own1, nf, w.shfl(sub.tag_id, qs))) return false;
+                        if (!fin_append(w, L, own0, own1, nf, w.shfl(sub.tag_id, qs), true)) return false;
                     }
                 }
             }
         }
     }
+    w.tick(9);
     // ---- S11: EnsureRequiredFacets (Program.cs:755-775) -----------------------------------------------------------------------
     for (uint32_t f0 = 0; f0 < t.n_facets; f0 += 64) {
         uint32_t f = f0 + lane;
@@ -619,12 +770,25 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             }
             if (facet_choice) facet_choice[f] = choice;
         }
-        uint32_t cnt = t.n_facets - f0 < 64 ? t.n_facets - f0 : 64;
-        for (uint32_t q = 0; q < cnt; ++q)
-            if (!fin_append(w, L, own0, own1, nf, w.shfl(selected, q))) return false;
+        // append the chosen tags in facet order, skipping those already in the list: the first facet to offer a new id wins
+        w.sync();
+        uint32_t slot = NO_ID;
+        bool full = false;
+        if (f < t.n_facets) { bool created; slot = set_put(w, L, selected, 1 + lane, created); full = slot == NO_ID; }
+        w.sync();
+        if (w.ballot(full)) return false;
+        const bool win = slot != NO_ID && L.set_min[slot] == 1 + lane;
+        const uint64_t mw = w.ballot(win);
+        if (nf + popc64(mw) > FAST_FIN_MAX) return false;
+        if (win) { L.fin[nf + popc64(mw & lt)] = selected; L.set_min[slot] = 0; }
+        nf += popc64(mw);
+        w.sync();
+        own0 = lane < nf ? L.fin[lane] : NO_ID;
+        own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
     }
     w.sync();
 
+    w.tick(10);
     // ---- S12: verdicts on the final list (Program.cs:319, 329), GetUnknownTags (:817-824), FormatCaptionSingleLine (:971-974) ---
     uint32_t c[2], clen[2];
     bool cnb[2], cknown[2];
@@ -676,6 +840,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     if (keepc[1]) fin32[popc64(mc0) + popc64(mc1 & lt)] = c[1];
     if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (footjob) flags |= TP_F_FOOTJOB; }
 
+    w.tick(11);
     tp_verdict& v = out.verdict;
     v.coverage = (uint8_t)coverage;
     v.flags = (uint8_t)flags;

@@ -26,7 +26,24 @@ namespace tp {
 // Wave collectives for tp_fast.h.  LDS traffic between lanes of one wavefront needs no barrier in hardware (the lanes
 // run in lock step and LDS operations of a wave complete in order); the fence keeps the compiler from moving LDS
 // accesses across the exchange point.
+#ifdef TP_PROF
+__device__ unsigned long long g_prof[32];   // cycles per pipeline section, summed over wavefronts (diagnostic builds only)
+#endif
+
 struct DevWave {
+#ifdef TP_PROF
+    uint64_t last = 0, acc[16] = {0};
+    __device__ __forceinline__ void tick(int k) {
+        uint64_t now = __builtin_readcyclecounter();
+        if (k > 0) acc[k] += now - last;      // section 0 starts the file's clock
+        last = now;
+    }
+    __device__ void flush() {
+        if (lane() == 0) for (int k = 0; k < 16; ++k) if (acc[k]) atomicAdd(&g_prof[k], (unsigned long long)acc[k]);
+    }
+#else
+    __device__ void tick(int) const {}
+#endif
     __device__ uint32_t lane() const { return threadIdx.x & 63u; }
     __device__ uint64_t ballot(bool p) const { return __ballot(p ? 1 : 0); }
     __device__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)(src & 63u), 64); }
@@ -39,6 +56,7 @@ struct DevWave {
     __device__ void lds_min(uint32_t* p, uint32_t v) const { atomicMin(p, v); }
     __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
     __device__ void copy16(uint8_t* lds_dst, const uint8_t* src) const { *(uint4*)lds_dst = *(const uint4*)src; }
+    __device__ void fill16(uint32_t* lds_dst, uint32_t v) const { *(uint4*)lds_dst = make_uint4(v, v, v, v); }
 };
 
 constexpr int FAST_WAVES_PER_BLOCK = 4;
@@ -71,6 +89,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast(DevTables t,
         }
         w.sync();
     }
+#ifdef TP_PROF
+    w.flush();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,3 +360,14 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
 }
 
 }  // namespace tp
+
+#ifdef TP_PROF
+extern "C" int tp_debug_prof(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(tp::g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tp::g_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -966,8 +966,14 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         if (!(out.flags[i] & FL_EDGE)) continue;
         uint32_t s = out.next[i];
         if (out.flags[s] & FL_BLANK) continue;                     // snapshot drops blank forms (Program.cs:1164)
-        out.step_ids.push_back(s);
-        for (uint32_t m = out.imp_off[s]; m < out.imp_off[s + 1]; ++m) out.step_ids.push_back(out.imp_ids[m]);
+        // a step that names the visited string itself, or repeats an earlier step of the same visit, can never append
+        auto push = [&](uint32_t x) {
+            if (x == i) return;
+            for (uint32_t m = out.step_off[i]; m < out.step_ids.size(); ++m) if (out.step_ids[m] == x) return;
+            out.step_ids.push_back(x);
+        };
+        push(s);
+        for (uint32_t m = out.imp_off[s]; m < out.imp_off[s + 1]; ++m) push(out.imp_ids[m]);
     }
     out.step_off[N] = (uint32_t)out.step_ids.size();
     for (uint32_t i = 0; i < N; ++i) {                              // FL_EDGE now means exactly "a visit can append something"
@@ -1024,7 +1030,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             out.str_words.push_back(wv);
         }
     }
-    out.str_words.push_back(0);
+    for (int k = 0; k < 4; ++k) out.str_words.push_back(0);   // lookups compare four words at a time, whatever the string's length
     out.ht_info.assign(slots, HtInfo{0, 0, 0, 0});
     for (uint32_t s = 0; s < slots; ++s) {
         if (!out.ht_hash[s]) continue;

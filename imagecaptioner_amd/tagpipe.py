@@ -33,9 +33,10 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise TagPipeError(-3, "HIP extension not built: %s is missing (run `python -m imagecaptioner_amd.build`)" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    path = os.environ.get("TAGPIPE_LIBRARY") or LIB_PATH     # the override is for diagnostic builds of the same library
+    if not os.path.exists(path):
+        raise TagPipeError(-3, "HIP extension not built: %s is missing (run `python -m imagecaptioner_amd.build`)" % path)
+    L = C.CDLL(path)
     L.tp_config_init.argtypes = [C.POINTER(tp_config)]
     L.tp_config_init.restype = None
     L.tp_create.argtypes = [C.POINTER(tp_config)]

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-section cycle shares of k_fast, from the diagnostic build (python -m imagecaptioner_amd.build --prof).
+
+usage: TAGPIPE_LIBRARY=imagecaptioner_amd/libtagpipe_hip_prof.so python3 tools/prof_sections.py [config] [files]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from imagecaptioner_amd import Config, TagPipe
+from imagecaptioner_amd._abi import tp_device_io
+from imagecaptioner_amd.corpus import make_corpus
+from imagecaptioner_amd.tagpipe import load_library
+
+NAMES = ["S1 copy", "S2 scan", "S4 tokens+dedupe", "S5 candidates", "S6 buckets", "S7 coverage", "S8 evidence", "S9 closure", "S10 rules", "S11 facets", "S12 verdict"]
+
+
+def main():
+    cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
+    corpus = make_corpus(cfgname, n, seed=1234)
+    pipe = TagPipe(Config(device=0, **corpus.config_kwargs))
+    dev = torch.device("cuda", 0)
+    arena = torch.cat([torch.from_numpy(corpus.arena).to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)])
+    offsets = torch.from_numpy(corpus.offsets.astype(np.int64)).to(dev)
+    cap = max(4 * int(corpus.offsets[-1]), 1 << 20)
+    captions = torch.empty(cap, dtype=torch.uint8, device=dev)
+    cap_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    verdicts = torch.empty(n * 16, dtype=torch.uint8, device=dev)
+    io = tp_device_io()
+    io.arena, io.offsets, io.n_files = arena.data_ptr(), offsets.data_ptr(), n
+    io.captions, io.caption_capacity, io.caption_offsets = captions.data_ptr(), cap, cap_off.data_ptr()
+    io.verdicts, io.histogram, io.counters, io.fired, io.facet_choice, io.stream = verdicts.data_ptr(), None, None, None, None, None
+    lib = load_library()
+    buf = (C.c_ulonglong * 32)()
+    pipe.run_lines_device(io)
+    lib.tp_debug_prof(buf, 1)
+    pipe.run_lines_device(io)
+    lib.tp_debug_prof(buf, 1)
+    tot = float(sum(buf)) or 1.0
+    print("k_fast ms", pipe.last_timing()["select_ms"], "files", n, "config", cfgname)
+    for k, name in enumerate(NAMES):
+        print("%-20s %6.2f %%  %8.0f cycles/file" % (name, 100.0 * buf[k + 1] / tot, buf[k + 1] / n))
+
+
+if __name__ == "__main__":
+    main()
