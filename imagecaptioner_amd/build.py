@@ -31,6 +31,10 @@ def build(force=False, verbose=False, prof=False):
     """prof=True builds the diagnostic variant libtagpipe_hip_prof.so (per-section cycle counters inside k_fast)."""
     if prof:
         return _build(LIB.replace(".so", "_prof.so"), "_prof.o", ["-DTP_PROF"], verbose)
+    variant = os.environ.get("TAGPIPE_BUILD_VARIANT")          # experiments: "name:-Dflag,-Dflag" -> libtagpipe_hip_name.so
+    if variant:
+        name, flags = variant.split(":", 1)
+        return _build(LIB.replace(".so", "_%s.so" % name), "_%s.o" % name, [f for f in flags.split(",") if f], verbose)
     if not force and not _stale():
         return LIB
     return _build(LIB, ".o", [], verbose)

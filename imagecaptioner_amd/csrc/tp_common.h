@@ -181,6 +181,9 @@ struct DevTables {
     uint32_t n_fb_final; uint32_t fb_final[MAX_FALLBACK];        // normalizedFinalSet of the fallback selection (Program.cs:298, 303)
     uint32_t final_cap;          // capacity of the per-file final-tag list
     uint32_t evidence_grow;      // evidence list capacity = candidates + this
+    // Line ingest scores fall with the candidate index (Program.cs:581), so score tests are index tests:
+    uint32_t seed_ci_limit;      // candidates below this index have !(score < 0.28)  (BuildEvidenceTags, Program.cs:724)
+    uint32_t style_ci_limit;     // candidates below this index have score >= 0.60     (DetermineStyleQualityCap, Program.cs:706)
 };
 
 TP_HD int source_rank(uint32_t s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : 3; }   // Program.cs:712-717

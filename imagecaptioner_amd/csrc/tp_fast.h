@@ -22,6 +22,12 @@
 #include "../../include/tagpipe.h"
 #include "tp_common.h"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TP_UNROLL _Pragma("unroll")
+#else
+#define TP_UNROLL
+#endif
+
 namespace tp {
 
 constexpr uint32_t FAST_LINE_MAX = 2048;   // bytes of one line held in LDS
@@ -32,7 +38,7 @@ constexpr uint32_t FAST_LIT_WORDS = 128;   // evidence bitset words (4096 rule l
 constexpr uint32_t FAST_FIRED_WORDS = 64;  // fired-rule bitmap words (2048 rules + subtypes)
 
 struct alignas(16) FastLds {
-    uint8_t line[FAST_LINE_MAX + 96];
+    uint8_t line[FAST_LINE_MAX + 64];    // 16 spare bytes in front (the byte before the line is read), the line at its 16-byte phase, tail padding
     uint16_t cpos[FAST_TOK_MAX];
     uint32_t tspec[FAST_TOK_MAX / 32];   // bit k: token k holds a byte that needs the byte-wise normaliser
     uint32_t cand[FAST_TOK_MAX];
@@ -87,6 +93,20 @@ TP_HD uint32_t lower4(uint32_t x) {
     uint32_t up = ((x + 0x3F3F3F3Fu) & ~(x + 0x25252525u)) & 0x80808080u;
     return x | (up >> 2);
 }
+// Four bytes at a time: the result holds 0x80 in every byte position where the test is true.
+constexpr uint32_t rep4(char c) { return 0x01010101u * (uint32_t)(uint8_t)c; }
+TP_HD uint32_t eq4(uint32_t x, uint32_t pat) { uint32_t y = x ^ pat; return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); }   // exact for any bytes
+TP_HD uint32_t ge4(uint32_t x, uint32_t k) { return (x + 0x01010101u * (0x80u - k)) & 0x80808080u; }                             // bytes of x below 0x80 only
+TP_HD uint32_t ws4(uint32_t x) { return eq4(x, 0x20202020u) | (ge4(x, 9) & ~ge4(x, 14)); }
+TP_HD uint32_t win4(uint32_t lo, uint32_t hi, uint32_t k) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * k)); }        // bytes k .. k+3 of hi:lo
+// Byte mask of the positions p .. p+3 that lie below `limit`.
+TP_HD uint32_t keep4(uint32_t p, uint32_t limit) {
+    int nv = (int)limit - (int)p;
+    nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+    return nv == 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1u);
+}
+TP_HD uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }   // x != 0
+TP_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }   // x != 0
 constexpr uint32_t c4(char a, char b, char c, char d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
 // The low min(max(n - 8k, 0), 8) bytes of word k of an n-byte string.
 TP_HD uint64_t word_mask(uint32_t n, uint32_t k) {
@@ -126,15 +146,15 @@ TP_HD uint32_t set_put(W& w, FastLds& L, uint32_t key, uint32_t order, bool& cre
     return NO_ID;
 }
 
-// First-occurrence filter over up to 128 (key, valid) pairs held two per lane (element index = blk * 64 + lane).
-// On return first[blk] marks the elements that are the first with their key; returns false if the set overflowed.
+// First-occurrence filter over up to 128 (key, valid) pairs held two per lane (element index = blk * 64 + lane); only the
+// first nblk blocks are looked at.  On return first[blk] marks the elements that are the first with their key; returns
+// false if the set overflowed.
 template <class W>
-TP_HD bool dedupe_first(W& w, FastLds& L, const uint32_t key[2], const bool valid[2], bool first[2]) {
+TP_HD bool dedupe_first(W& w, FastLds& L, const uint32_t key[2], const bool valid[2], bool first[2], int nblk = 2) {
     set_clear(w, L);
-    uint32_t slot[2];
+    uint32_t slot[2] = {NO_ID, NO_ID};
     bool full = false;
-    for (int blk = 0; blk < 2; ++blk) {
-        slot[blk] = NO_ID;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
         if (valid[blk]) {
             bool created;
             slot[blk] = set_put(w, L, key[blk], (uint32_t)blk * 64 + w.lane(), created);
@@ -142,7 +162,8 @@ TP_HD bool dedupe_first(W& w, FastLds& L, const uint32_t key[2], const bool vali
         }
     }
     w.sync();
-    for (int blk = 0; blk < 2; ++blk) first[blk] = valid[blk] && slot[blk] != NO_ID && L.set_min[slot[blk]] == (uint32_t)blk * 64 + w.lane();
+    first[0] = first[1] = false;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) first[blk] = valid[blk] && slot[blk] != NO_ID && L.set_min[slot[blk]] == (uint32_t)blk * 64 + w.lane();
     bool any_full = w.ballot(full) != 0;
     w.sync();
     return !any_full;
@@ -315,25 +336,37 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     {
         const uint8_t* abase = text - shift;
         uint32_t pieces = (shift + len + 15) >> 4;
-        for (uint32_t c = lane; c < pieces; c += 64) w.copy16(L.line + 16 * c, abase + 16 * c);
+        for (uint32_t c = lane; c < pieces; c += 64) w.copy16(L.line + 16 + 16 * c, abase + 16 * c);
         if (lane < FAST_TOK_MAX / 32) L.tspec[lane] = 0;
     }
     w.sync();
     w.tick(1);
-    const uint8_t* s = L.line + shift;
+    const uint8_t* s = L.line + 16 + shift;
 
-    // ---- S2: character classes, trim (NormalizeRawTagLine, Program.cs:589-596) ------------------------------------------
+    // ---- S2: character classes, trim (NormalizeRawTagLine, Program.cs:589-596); four bytes per lane ---------------------
+    constexpr uint32_t H4 = 0x80808080u;
     uint32_t first_nonws = 0xFFFFFFFFu, end_nonws = 0, first_nl = 0xFFFFFFFFu, last_nl = 0;
     uint64_t any_odd = 0;
-    for (uint32_t base = 0; base < len; base += 64) {
-        const uint32_t p = base + lane;
-        uint32_t c = s[p];
-        c = p < len ? c : 0x20u;
-        const uint64_t m_nonws = w.ballot(!ws32(c));
-        any_odd |= w.ballot((c >= 0x80u) | (c == '`'));
-        const uint64_t m_nl = w.ballot((c == '\r') | (c == '\n'));
-        if (m_nonws) { if (first_nonws == 0xFFFFFFFFu) first_nonws = base + ctz64(m_nonws); end_nonws = base + 64 - clz64(m_nonws); }
-        if (m_nl) { if (first_nl == 0xFFFFFFFFu) first_nl = base + ctz64(m_nl); last_nl = base + 63 - clz64(m_nl); }
+    for (uint32_t base = 0; base < len; base += 256) {
+        const uint32_t p = base + 4 * lane;
+        const uint32_t keep = keep4(p, len);
+        const uint32_t x = (ld32u(s + (p < len ? p : len)) & keep) | (0x20202020u & ~keep);
+        const uint32_t odd = (x & H4) | eq4(x, rep4('`'));
+        const uint32_t nonws = ~ws4(x) & H4;
+        const uint32_t nl = eq4(x, rep4('\n')) | eq4(x, rep4('\r'));
+        const uint64_t m_nonws = w.ballot(nonws != 0);
+        any_odd |= w.ballot(odd != 0);
+        const uint64_t m_nl = w.ballot(nl != 0);
+        if (m_nonws) {
+            if (first_nonws == 0xFFFFFFFFu) { const uint32_t q = ctz64(m_nonws); first_nonws = base + 4 * q + (ctz32(w.shfl(nonws, q)) >> 3); }
+            const uint32_t q = 63 - clz64(m_nonws);
+            end_nonws = base + 4 * q + ((31 - clz32(w.shfl(nonws, q))) >> 3) + 1;
+        }
+        if (m_nl) {
+            if (first_nl == 0xFFFFFFFFu) { const uint32_t q = ctz64(m_nl); first_nl = base + 4 * q + (ctz32(w.shfl(nl, q)) >> 3); }
+            const uint32_t q = 63 - clz64(m_nl);
+            last_nl = base + 4 * q + ((31 - clz32(w.shfl(nl, q))) >> 3);
+        }
     }
     if (any_odd) return false;
     const bool blank_line = first_nonws == 0xFFFFFFFFu;
@@ -343,43 +376,74 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     // commas, tokens that need the byte-wise normaliser, LooksBad (Program.cs:1141-1147)
     uint32_t ncomma = 0;
     bool refusal = false, keyword = false;
-    for (uint32_t base = a; base < b; base += 64) {
-        const uint32_t p = base + lane;
-        const bool inb = p < b;
-        const uint32_t c = s[p];
-        const uint32_t prev = p > a ? (uint32_t)s[p - 1] : (uint32_t)',';
-        const bool comma = inb & (c == ',');
-        const uint64_t m_c = w.ballot(comma);
-        const uint32_t k = ncomma + popc64(m_c & lt);             // commas before p = index of the token p belongs to
-        if (comma && k < FAST_TOK_MAX) L.cpos[k] = (uint16_t)p;
-        ncomma += popc64(m_c);
+    uint64_t any_blank = 0;
+    for (uint32_t base = a; base < b; base += 256) {
+        const uint32_t p = base + 4 * lane;
+        const uint32_t pp = p < b ? p : b;
+        const uint32_t inm = keep4(p, b) & H4;
+        const uint32_t x = ld32u(s + pp);
+        uint32_t pv = ld32u(s + pp - 1);                           // the bytes before them
+        if (p == a) pv = (pv & ~0xFFu) | (uint32_t)',';
+        const uint32_t cm = eq4(x, rep4(',')) & inm;
+        const uint64_t mc[4] = {w.ballot(cm & 0x80u), w.ballot(cm & 0x8000u), w.ballot(cm & 0x800000u), w.ballot(cm & 0x80000000u)};
+        uint32_t k[4];                                             // commas before byte j = index of the token it belongs to
+        k[0] = ncomma + popc64(mc[0] & lt) + popc64(mc[1] & lt) + popc64(mc[2] & lt) + popc64(mc[3] & lt);
+        k[1] = k[0] + ((cm >> 7) & 1u);
+        k[2] = k[1] + ((cm >> 15) & 1u);
+        k[3] = k[2] + ((cm >> 23) & 1u);
+        if (cm) {
+            for (uint32_t j = 0; j < 4; ++j)
+                if ((cm & (0x80u << (8 * j))) && k[j] < FAST_TOK_MAX) L.cpos[k[j]] = (uint16_t)(p + j);
+        }
+        ncomma += popc64(mc[0]) + popc64(mc[1]) + popc64(mc[2]) + popc64(mc[3]);
         // A byte the normaliser would change or drop: upper case, quotes, trailing-punctuation characters, white space
         // other than a single byte right after a comma, the second of two underscores.
-        const uint32_t wsb = ws32(c);
-        const uint32_t sp = upper32(c) | (uint32_t)(c == '"') | (uint32_t)(c == '\'') | (uint32_t)(c == ';') | (uint32_t)(c == '.') |
-                            (wsb & (uint32_t)(prev != ',')) | ((uint32_t)(c == '_') & (uint32_t)(prev == '_'));
-        if (inb && sp && k < FAST_TOK_MAX) w.lds_or(&L.tspec[k >> 5], 1u << (k & 31));
-        if (w.ballot(inb & (c == ':'))) {   // only "positive:" / "negative:" matter (Program.cs:57, 592-594); other colons are ordinary tag text
-            bool key = inb && c == ':' && p >= 8 && (lds_match(s, p - 8, len, "positive", 8) || lds_match(s, p - 8, len, "negative", 8));
+        const uint32_t blank = ws4(x) & ~eq4(pv, rep4(',')) & inm;
+        const uint32_t sp = (((ge4(x, 'A') & ~ge4(x, 'Z' + 1)) | eq4(x, rep4('"')) | eq4(x, rep4('\'')) | eq4(x, rep4(';')) | eq4(x, rep4('.')) |
+                              (eq4(x, rep4('_')) & eq4(pv, rep4('_')))) & inm) | blank;
+        any_blank |= w.ballot(blank != 0);
+        if (sp) {
+            for (uint32_t j = 0; j < 4; ++j)
+                if ((sp & (0x80u << (8 * j))) && k[j] < FAST_TOK_MAX) w.lds_or(&L.tspec[k[j] >> 5], 1u << (k[j] & 31));
+        }
+        const uint32_t colon = eq4(x, rep4(':')) & inm;
+        if (w.ballot(colon != 0)) {   // only "positive:" / "negative:" matter (Program.cs:57, 592-594); other colons are ordinary tag text
+            bool key = false;
+            for (uint32_t j = 0; j < 4; ++j)
+                if ((colon & (0x80u << (8 * j))) && p + j >= 8 && (lds_match(s, p + j - 8, len, "positive", 8) || lds_match(s, p + j - 8, len, "negative", 8))) key = true;
             if (w.ballot(key)) keyword = true;
         }
-        // DropTagsContains without the two entries that hold ':' (Program.cs:56-58): compare four bytes first
-        const uint32_t q = lower4(ld32u(s + p));
-        const bool pre = inb & ((q == c4('s', 'o', 'r', 'r')) | (q == c4('i', ' ', 'c', 'a')) | (q == c4('i', '\'', 'm', ' ')) | (q == c4('i', ' ', 'w', 'o')) |
-                                (q == c4('c', 'a', 'n', 'n')) | (q == c4('u', 'n', 'a', 'b')) | (q == c4('a', 's', ' ', 'a')));
-        if (w.ballot(pre)) {
+        // DropTagsContains (Program.cs:56-58): "sorry" is the one entry without a blank inside
+        const uint32_t xl = x | 0x20202020u, nx = ld32u(s + pp + 4) | 0x20202020u;
+        const uint32_t sor = eq4(xl, rep4('s')) & eq4(win4(xl, nx, 1), rep4('o')) & eq4(win4(xl, nx, 2), rep4('r')) & inm;
+        if (w.ballot(sor != 0)) {
             bool hit = false;
-            if (pre) {
-                switch (q & 0xFFu) {
-                    case 's': hit = lds_match(s, p, b, "sorry", 5); break;
-                    case 'i': hit = lds_match(s, p, b, "i can't", 7) || lds_match(s, p, b, "i cannot", 8) || lds_match(s, p, b, "i'm not able", 12) || lds_match(s, p, b, "i won't", 7); break;
-                    case 'c': hit = lds_match(s, p, b, "cannot provide", 14); break;
-                    case 'u': hit = lds_match(s, p, b, "unable to", 9); break;
-                    case 'a': hit = lds_match(s, p, b, "as an ai", 8); break;
-                    default: break;
-                }
-            }
+            for (uint32_t j = 0; j < 4; ++j)
+                if ((sor & (0x80u << (8 * j))) && lds_match(s, p + j, b, "sorry", 5)) hit = true;
             if (w.ballot(hit)) refusal = true;
+        }
+    }
+    if (any_blank && !refusal) {
+        // The other entries (without the two that hold ':') all have a blank that follows a letter; such a blank was seen.
+        for (uint32_t base = a; base < b; base += 64) {
+            const uint32_t p = base + lane;
+            const bool inb = p < b;
+            const uint32_t q = lower4(ld32u(s + (inb ? p : b)));
+            const bool pre = inb & ((q == c4('i', ' ', 'c', 'a')) | (q == c4('i', '\'', 'm', ' ')) | (q == c4('i', ' ', 'w', 'o')) | (q == c4('c', 'a', 'n', 'n')) |
+                                    (q == c4('u', 'n', 'a', 'b')) | (q == c4('a', 's', ' ', 'a')));
+            if (w.ballot(pre)) {
+                bool hit = false;
+                if (pre) {
+                    switch (q & 0xFFu) {
+                        case 'i': hit = lds_match(s, p, b, "i can't", 7) || lds_match(s, p, b, "i cannot", 8) || lds_match(s, p, b, "i'm not able", 12) || lds_match(s, p, b, "i won't", 7); break;
+                        case 'c': hit = lds_match(s, p, b, "cannot provide", 14); break;
+                        case 'u': hit = lds_match(s, p, b, "unable to", 9); break;
+                        case 'a': hit = lds_match(s, p, b, "as an ai", 8); break;
+                        default: break;
+                    }
+                }
+                if (w.ballot(hit)) refusal = true;
+            }
         }
     }
     if (keyword) return false;
@@ -390,13 +454,18 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     w.tick(2);
 
     // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
-    uint32_t n = 0;   // candidates, two per lane: candidate index = blk * 64 + lane
+    // A token's lane stays its candidate's lane: candidate index = number of kept tokens before it.
+    const int nblk = T > 64 ? 2 : 1;                              // tokens (and so candidates) sit two per lane only in long lines
+    uint32_t n = 0;
+    bool act[2] = {false, false};
+    uint32_t h1[2] = {EMPTY_ID, EMPTY_ID}, ci[2] = {0, 0};
+    Rec r1[2];
+    r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
     {
-        uint32_t tid[2] = {NO_ID, NO_ID};
         bool keep[2] = {false, false};
         bool dyn_survivor = false;
         if (!rejected) {
-            for (int blk = 0; blk < 2; ++blk) {
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
                 uint32_t tix = (uint32_t)blk * 64 + lane;
                 if (tix < T) {
                     uint32_t i = tix == 0 ? a : (uint32_t)L.cpos[tix - 1] + 1;
@@ -406,8 +475,8 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                     const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u;
                     int kind = fast_token(t, s, i, j, special, id, vdyn, dlen);
                     if (kind == 1) {
-                        uint32_t f = t.rec[id].flags;
-                        if ((f & FL_LEN2) && !(f & FL_DROP)) { tid[blk] = id; keep[blk] = true; }
+                        const Rec rr = t.rec[id];
+                        if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) { h1[blk] = id; r1[blk] = rr; keep[blk] = true; }
                     } else if (kind == 2) {
                         // a string outside the tables: gone under strict vocabulary, too short, or invalid; anything else may survive
                         if (!t.drop_unknown && dlen >= 2 && vdyn) dyn_survivor = true;
@@ -416,48 +485,43 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             }
         }
         if (w.ballot(dyn_survivor)) return false;
-        bool first[2];
-        if (!dedupe_first(w, L, tid, keep, first)) return false;
-        uint64_t m0 = w.ballot(first[0]), m1 = w.ballot(first[1]);
+        if (!dedupe_first(w, L, h1, keep, act, nblk)) return false;
+        const uint64_t m0 = w.ballot(act[0]), m1 = nblk > 1 ? w.ballot(act[1]) : 0;
         n = popc64(m0) + popc64(m1);
-        if (first[0]) L.cand[popc64(m0 & lt)] = tid[0];
-        if (first[1]) L.cand[popc64(m0) + popc64(m1 & lt)] = tid[1];
-        w.sync();
+        ci[0] = popc64(m0 & lt);
+        ci[1] = popc64(m0) + popc64(m1 & lt);
+        if (!act[0]) { h1[0] = EMPTY_ID; r1[0] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
+        if (!act[1]) { h1[1] = EMPTY_ID; r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
     }
 
     w.tick(3);
     // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
     // In line ingest the scores fall with the candidate index, so "sorted" order is candidate order and the first of
     // two candidates that NormalizeTag merges carries the merged score, order and source.
-    bool act[2], nonblank2[2], first2[2], bad2[2], uniq[2], ev_seed[2];
-    uint32_t h1[2], t2[2];
+    bool nonblank2[2] = {false, false}, first2[2] = {false, false}, bad2[2] = {false, false}, uniq[2] = {false, false}, ev_seed[2] = {false, false};
+    uint32_t t2[2] = {EMPTY_ID, EMPTY_ID};
     Rec r2[2];
+    r2[0] = r1[0]; r2[1] = r1[1];
     uint32_t style_n = 0;
     uint64_t m_hop2 = 0;
-    for (int blk = 0; blk < 2; ++blk) {
-        uint32_t ci = (uint32_t)blk * 64 + lane;
-        act[blk] = ci < n;
-        h1[blk] = act[blk] ? L.cand[ci] : EMPTY_ID;
-        Rec r1 = t.rec[h1[blk]];
-        t2[blk] = r1.next;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+        t2[blk] = r1[blk].next;
         bool hop = act[blk] && t2[blk] != h1[blk];
         uint64_t mh = w.ballot(hop);
         m_hop2 |= mh;
-        r2[blk] = r1;
         if (mh && hop) r2[blk] = t.rec[t2[blk]];
-        double score = fmax(0.05, 1.0 - (double)(int)ci * 0.01) * t.line_weight;          // Program.cs:581
-        style_n += popc64(w.ballot(act[blk] && fl_bucket(r1.flags) == B_STYLE && score >= 0.60));   // DetermineStyleQualityCap, Program.cs:702-710
+        style_n += popc64(w.ballot(act[blk] && fl_bucket(r1[blk].flags) == B_STYLE && ci[blk] < t.style_ci_limit));   // DetermineStyleQualityCap, Program.cs:702-710
         nonblank2[blk] = act[blk] && !(r2[blk].flags & FL_BLANK);
         first2[blk] = nonblank2[blk];
         bad2[blk] = nonblank2[blk] && (!(r2[blk].flags & FL_VALID) || (r2[blk].flags & FL_DROP));
-        ev_seed[blk] = !(score < 0.28);
+        ev_seed[blk] = ci[blk] < t.seed_ci_limit;                  // !(score < 0.28), Program.cs:724
     }
     const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
     if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences
-        if (!dedupe_first(w, L, t2, nonblank2, first2)) return false;
+        if (!dedupe_first(w, L, t2, nonblank2, first2, nblk)) return false;
     }
     uint32_t n_dropped = 0;
-    for (int blk = 0; blk < 2; ++blk) {
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
         uniq[blk] = first2[blk] && !bad2[blk];
         n_dropped += popc64(w.ballot(first2[blk] && bad2[blk]));                            // distinct "{n}:invalid_tag" / "{n}:policy_drop"
         ev_seed[blk] = ev_seed[blk] && first2[blk];
@@ -465,10 +529,10 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
 
     w.tick(4);
     // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
-    uint32_t t3[2];
-    bool ok3[2];
+    uint32_t t3[2] = {EMPTY_ID, EMPTY_ID};
+    bool ok3[2] = {false, false};
     uint64_t m_hop3 = 0;
-    for (int blk = 0; blk < 2; ++blk) {
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
         t3[blk] = r2[blk].next;
         bool hop = uniq[blk] && t3[blk] != t2[blk];
         uint64_t mh = w.ballot(hop);
@@ -479,7 +543,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
     if (m_hop3) {
         bool fst[2];
-        if (!dedupe_first(w, L, t3, ok3, fst)) return false;
+        if (!dedupe_first(w, L, t3, ok3, fst, nblk)) return false;
         if (w.ballot((ok3[0] && !fst[0]) || (ok3[1] && !fst[1]))) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
     }
     uint32_t nr = t.n_prefix;
@@ -490,7 +554,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         for (uint32_t bk = 0; bk <= 6; ++bk) {                    // FillBucket for the six capped buckets in order, then (bk == 6) the final sweep (Program.cs:670-680)
             bool el0 = ok3[0] && !taken[0] && (bk == 6 || fl_bucket(r2[0].flags) == bk);
             bool el1 = ok3[1] && !taken[1] && (bk == 6 || fl_bucket(r2[1].flags) == bk);
-            uint64_t m0 = w.ballot(el0), m1 = w.ballot(el1);
+            uint64_t m0 = w.ballot(el0), m1 = nblk > 1 ? w.ballot(el1) : 0;
             uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
             uint32_t take = popc64(m0) + popc64(m1);
             if (bk < 6 && take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
@@ -556,7 +620,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     bool ev_feet = false, ev_penis = false;
     {
         uint64_t m_edge = 0;
-        for (int blk = 0; blk < 2; ++blk) {
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
             m_edge |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE));
             if (ev_seed[blk]) {
                 uint32_t li = r2[blk].lit;
@@ -566,7 +630,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             }
         }
         if (!m_edge) {
-            n_evidence = popc64(w.ballot(ev_seed[0])) + popc64(w.ballot(ev_seed[1]));
+            n_evidence = popc64(w.ballot(ev_seed[0])) + (nblk > 1 ? popc64(w.ballot(ev_seed[1])) : 0);
         } else {
             if (!t.closure_tables) return false;
             set_clear(w, L);
@@ -622,7 +686,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             uint32_t so[2] = {0, 0}, sc[2] = {0, 0}, sid[2][2] = {{NO_ID, NO_ID}, {NO_ID, NO_ID}};
             bool edge[2] = {false, false};
             uint64_t m_edge[2] = {0, 0}, m_long = 0;
-            for (int blk = 0; blk < nblk; ++blk) {
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
                 const uint32_t idx = (uint32_t)blk * 64 + lane;
                 const bool in = idx >= lo && idx < hi;
                 if (in) {
@@ -637,7 +701,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             }
             const uint32_t nf0 = nf;
             if (m_long) {                                          // long step lists: one element at a time
-                for (int blk = 0; blk < nblk; ++blk) {
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
                     uint64_t m = m_edge[blk];
                     while (m) {
                         const uint32_t q = ctz64(m);
@@ -653,7 +717,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             } else if (m_edge[0] | m_edge[1]) {
                 uint32_t slot[2][2] = {{NO_ID, NO_ID}, {NO_ID, NO_ID}};
                 bool full = false;
-                for (int blk = 0; blk < nblk; ++blk)
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk)
                     for (uint32_t j = 0; j < 2; ++j)
                         if (edge[blk] && j < sc[blk]) {
                             bool created;
@@ -664,14 +728,14 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                 if (w.ballot(full)) return false;
                 bool win[2][2] = {{false, false}, {false, false}};
                 uint64_t mw[2][2] = {{0, 0}, {0, 0}};
-                for (int blk = 0; blk < nblk; ++blk)
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk)
                     for (uint32_t j = 0; j < 2; ++j) {
                         win[blk][j] = slot[blk][j] != NO_ID && L.set_min[slot[blk][j]] == 1 + ((((uint32_t)blk * 64 + lane) << 1) | j);
                         mw[blk][j] = w.ballot(win[blk][j]);
                     }
                 const uint32_t c0 = popc64(mw[0][0]) + popc64(mw[0][1]), c1 = popc64(mw[1][0]) + popc64(mw[1][1]);
                 if (nf + c0 + c1 > FAST_FIN_MAX) return false;
-                for (int blk = 0; blk < nblk; ++blk) {
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
                     uint32_t pos = nf + (blk ? c0 : 0) + popc64(mw[blk][0] & lt) + popc64(mw[blk][1] & lt);
                     if (win[blk][0]) { L.fin[pos] = sid[blk][0]; L.set_min[slot[blk][0]] = 0; ++pos; }
                     if (win[blk][1]) { L.fin[pos] = sid[blk][1]; L.set_min[slot[blk][1]] = 0; }

@@ -61,7 +61,10 @@ struct DevWave {
 
 constexpr int FAST_WAVES_PER_BLOCK = 4;
 
-__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast(DevTables t, FastArgs a) {
+#ifndef TP_FAST_WAVES_PER_SIMD
+#define TP_FAST_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_FAST_WAVES_PER_SIMD))) void k_fast(DevTables t, FastArgs a) {
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
     FastLds& L = lds[threadIdx.x >> 6];
     DevWave w;
@@ -236,13 +239,21 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
 // ------------------------------------------------------------------------------------------------
 // k_emit
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t HOT_IDS = 2048;   // ids below this are counted in LDS; the table compiler gives the frequent tags the low ids
+constexpr uint32_t HOT_IDS = 24576;   // ids below this are counted in LDS (96 KB); the table compiler gives the frequent tags the low ids
+constexpr int EMIT_WAVES = 16;          // one block per CU: the LDS histogram takes most of the CU's 160 KB
+constexpr uint32_t EMIT_STAGE = 2048;   // captions up to this many bytes are put together in LDS and stored 16 bytes per lane
 
-__global__ __launch_bounds__(256) void k_emit(DevTables t, EmitArgs a) {
+__device__ inline uint64_t ldg64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ inline uint32_t ldg32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ inline uint16_t ldg16u(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+__global__ __launch_bounds__(64 * EMIT_WAVES) void k_emit(DevTables t, EmitArgs a) {
     __shared__ uint32_t hot[HOT_IDS];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[EMIT_WAVES][EMIT_STAGE + 32];
     for (uint32_t i = threadIdx.x; i < HOT_IDS; i += blockDim.x) hot[i] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
+    uint8_t* stage = stage_all[threadIdx.x >> 6];
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t hot_n = t.n_strings < HOT_IDS ? t.n_strings : HOT_IDS;
@@ -262,6 +273,58 @@ __global__ __launch_bounds__(256) void k_emit(DevTables t, EmitArgs a) {
         const uint32_t slot = a.slot_of[f];
         const bool fast = slot == SLOT_FAST;
         const uint32_t* ids = a.fin32 + (f - a.file0) * FAST_FIN_MAX;
+        if (fast && total <= EMIT_STAGE && nfin <= 128) {
+            // Every tag of a file from the wave-per-file kernel is an interned string.  The caption is put together in LDS
+            // at the same 16-byte phase as its place in the output, then stored with aligned 16-byte stores.
+            const uint32_t head = (uint32_t)((uintptr_t)(a.captions + out0) & 15);
+            uint32_t id[2], len[2], seg[2], incl[2];
+            const uint8_t* src[2];
+            for (int blk = 0; blk < 2; ++blk) {
+                const uint32_t k = (uint32_t)blk * 64 + lane;
+                const bool live = k < nfin;
+                id[blk] = live ? ids[k] : 0;
+                const uint32_t o = t.str_off[id[blk]];
+                len[blk] = live ? t.str_off[id[blk] + 1] - o : 0;
+                src[blk] = t.str_bytes + o;
+                seg[blk] = len[blk] + ((live && k + 1 < nfin) ? 2u : 0u);
+                incl[blk] = seg[blk];
+                if (blk == 0 || nfin > 64)
+                    for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(incl[blk], d); if ((int)lane >= d) incl[blk] += o2; }
+            }
+            const uint32_t tot0 = __shfl(incl[0], 63);
+            for (int blk = 0; blk < 2; ++blk) {
+                if (blk == 1 && nfin <= 64) break;
+                uint8_t* dst = stage + head + (blk ? tot0 : 0) + incl[blk] - seg[blk];
+                const uint8_t* sp = src[blk];
+                uint32_t n = len[blk], done = 0;
+                while (n - done >= 8) { uint64_t v = ldg64u(sp + done); __builtin_memcpy(dst + done, &v, 8); done += 8; }
+                if ((n - done) & 4) { uint32_t v = ldg32u(sp + done); __builtin_memcpy(dst + done, &v, 4); done += 4; }
+                if ((n - done) & 2) { uint16_t v = ldg16u(sp + done); __builtin_memcpy(dst + done, &v, 2); done += 2; }
+                if ((n - done) & 1) { dst[done] = sp[done]; }
+                if (seg[blk] != len[blk]) { dst[n] = ','; dst[n + 1] = ' '; }
+                if (len[blk] && a.histogram) {
+                    if (id[blk] < hot_n) atomicAdd(&hot[id[blk]], 1u);
+                    else atomicAdd((unsigned long long*)&a.histogram[id[blk]], 1ull);
+                }
+            }
+            if (lane < t.newline_len) stage[head + total - t.newline_len + lane] = t.newline[lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint8_t* gbase = a.captions + out0 - head;                    // 16-byte aligned
+            const uint32_t end = head + total, nchunks = (end + 15) >> 4;
+            for (uint32_t c = lane; c < nchunks; c += 64) {
+                if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
+            }
+            if (lane < 32) {                                              // the partial first and last pieces, one byte per lane
+                const uint32_t c = lane < 16 ? 0u : nchunks - 1;
+                const uint32_t off = 16 * c + (lane & 15);
+                const bool partial = !(16 * c >= head && 16 * c + 16 <= end) && (lane < 16 || nchunks > 1);
+                if (partial && off >= head && off < end) gbase[off] = stage[off];
+            }
+            __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next file's are written
+            continue;
+        }
         FileWs ws;
         if (!fast) {
             uint64_t w = slot >> 6;
@@ -353,9 +416,9 @@ hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
-    uint64_t want = (n + 3) / 4;                    // four wavefronts (files in flight) per block
-    unsigned blocks = (unsigned)(want < 1024 ? want : 1024);
-    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, t, a);
+    uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;   // sixteen wavefronts (files in flight) per block, one block per CU
+    unsigned blocks = (unsigned)(want < 256 ? want : 256);
+    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #include "tp_tables.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -942,6 +943,12 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         }
     }
     sc.final_cap = MAX_TOTAL_TAGS + std::min<uint32_t>(MAX_TOTAL_TAGS * reach_max, 2048) + sc.n_rules + sc.n_subs + sc.n_facets + 16;
+    sc.seed_ci_limit = sc.style_ci_limit = 0;
+    for (int ci = 0; ci < 4096; ++ci) {                             // the same arithmetic as the per-candidate score, Program.cs:581
+        double score = std::fmax(0.05, 1.0 - (double)ci * 0.01) * cfg.line_weight;
+        if (!(score < 0.28) && sc.seed_ci_limit == (uint32_t)ci) sc.seed_ci_limit = (uint32_t)ci + 1;
+        if (score >= 0.60 && sc.style_ci_limit == (uint32_t)ci) sc.style_ci_limit = (uint32_t)ci + 1;
+    }
     sc.evidence_grow = std::min<uint32_t>(73 * reach_max, 2048) + 16;   // at most 73 line-ingest candidates score >= 0.28
     // ---- tables of the wave-per-file kernel ----
     // prefix: the result list after AddOne(trigger), AddOne("1girl"), AddOne(always-add...) (Program.cs:664-668, 692-699)
