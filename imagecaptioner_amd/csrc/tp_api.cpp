@@ -199,7 +199,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     EmitArgs ea{};
     ea.file0 = f0; ea.file_end = f1;
     ea.wave_T = c->wave_T.as<uint32_t>(); ea.wave_LB = c->wave_LB.as<uint32_t>(); ea.wave_off = c->wave_off.as<uint64_t>(); ea.workspace = c->workspace.as<uint8_t>();
-    ea.fin32 = c->fin32.as<uint32_t>(); ea.slot_of = slot_of; ea.n_final = n_final;
+    ea.fin32 = use_fast ? c->fin32.as<uint32_t>() : nullptr; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
     ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
     ea.histogram = io.histogram; ea.counters = io.counters;
     hipEvent_t q0 = c->event(st.ev++), q1 = c->event(st.ev++);

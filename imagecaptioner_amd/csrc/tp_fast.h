@@ -36,6 +36,7 @@ constexpr uint32_t FAST_FIN_MAX = 128;     // final tags (two per lane)
 constexpr uint32_t FAST_SET_SLOTS = 256;   // LDS hash set
 constexpr uint32_t FAST_LIT_WORDS = 128;   // evidence bitset words (4096 rule literals)
 constexpr uint32_t FAST_FIRED_WORDS = 64;  // fired-rule bitmap words (2048 rules + subtypes)
+constexpr uint32_t FAST_CAPTION_MAX = 2048; // caption bytes (the emit kernel puts a caption together in LDS)
 
 struct alignas(16) FastLds {
     uint8_t line[FAST_LINE_MAX + 64];    // 16 spare bytes in front (the byte before the line is read), the line at its 16-byte phase, tail padding
@@ -917,7 +918,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     v.n_dropped = (uint16_t)n_dropped;
     out.n_final = nc;
     out.caption_len = bytes + (nc ? 2 * (nc - 1) : 0) + t.newline_len;
-    return true;
+    return out.caption_len <= FAST_CAPTION_MAX;
 }
 
 }  // namespace tp

@@ -47,10 +47,12 @@ struct DevWave {
     __device__ uint32_t lane() const { return threadIdx.x & 63u; }
     __device__ uint64_t ballot(bool p) const { return __ballot(p ? 1 : 0); }
     __device__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)(src & 63u), 64); }
+    // Orders the wave's own LDS traffic (each wavefront owns its LDS state): LDS instructions of one wave execute in
+    // order, so wavefront scope is enough and, unlike a wider scope, does not wait for outstanding global loads and stores.
     __device__ void sync() const {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __device__ uint32_t lds_cas(uint32_t* p, uint32_t cmp, uint32_t val) const { return atomicCAS(p, cmp, val); }
     __device__ void lds_min(uint32_t* p, uint32_t v) const { atomicMin(p, v); }
@@ -239,14 +241,46 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
 // ------------------------------------------------------------------------------------------------
 // k_emit
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t HOT_IDS = 24576;   // ids below this are counted in LDS (96 KB); the table compiler gives the frequent tags the low ids
-constexpr int EMIT_WAVES = 16;          // one block per CU: the LDS histogram takes most of the CU's 160 KB
-constexpr uint32_t EMIT_STAGE = 2048;   // captions up to this many bytes are put together in LDS and stored 16 bytes per lane
+constexpr uint32_t HOT_IDS = 24576;    // ids below this are counted in LDS (96 KB: global atomics are what this kernel can least afford);
+                                       // the table compiler gives the frequent tags the low ids
+constexpr int EMIT_WAVES = 16;          // wavefronts (files in flight) per block of the staged emit kernel, one block per CU
+constexpr uint32_t EMIT_STAGE = FAST_CAPTION_MAX;   // captions are put together in LDS and stored 16 bytes per lane
 
-__device__ inline uint64_t ldg64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ inline uint32_t ldg32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-__device__ inline uint16_t ldg16u(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (no LDS traffic).
+__device__ inline uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
 
+struct EmitCounts {
+    uint64_t files = 0, low = 0, elig = 0, foot = 0, fb = 0, rej = 0, uns = 0, safe = 0;
+    __device__ void add(uint32_t fl) {
+        ++files;
+        low += (fl & TP_F_LOW) != 0; elig += (fl & TP_F_ELIGIBLE) != 0; foot += (fl & TP_F_FOOTJOB) != 0; fb += (fl & TP_F_FALLBACK) != 0;
+        rej += (fl & TP_F_LINE_REJECTED) != 0; uns += (fl & TP_F_UNSUPPORTED) != 0; safe += (fl & TP_F_SAFE_REJECT) != 0;
+    }
+    __device__ void flush(tp_counters* out) const {
+        unsigned long long* c = (unsigned long long*)out;
+        if (files) atomicAdd(&c[0], (unsigned long long)files);
+        if (low) atomicAdd(&c[1], (unsigned long long)low);
+        if (elig) atomicAdd(&c[2], (unsigned long long)elig);
+        if (foot) atomicAdd(&c[3], (unsigned long long)foot);
+        if (fb) atomicAdd(&c[4], (unsigned long long)fb);
+        if (rej) atomicAdd(&c[5], (unsigned long long)rej);
+        if (uns) atomicAdd(&c[6], (unsigned long long)uns);
+        if (safe) atomicAdd(&c[7], (unsigned long long)safe);
+    }
+};
+
+// Files of the wave-per-file kernel: every tag is an interned string, at most 128 tags, at most EMIT_STAGE caption bytes.
+// One wavefront per file.  The caption is put together in LDS at the same 16-byte phase as its place in the output,
+// then stored with aligned 16-byte stores.  Two files ahead the wave loads a file's sizes and tag ids, one file ahead
+// the tags' string offsets, so that the dependent loads of three files are in flight at once.
 __global__ __launch_bounds__(64 * EMIT_WAVES) void k_emit(DevTables t, EmitArgs a) {
     __shared__ uint32_t hot[HOT_IDS];
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[EMIT_WAVES][EMIT_STAGE + 32];
@@ -257,86 +291,135 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void k_emit(DevTables t, EmitArgs 
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t hot_n = t.n_strings < HOT_IDS ? t.n_strings : HOT_IDS;
-    uint64_t c_files = 0, c_low = 0, c_elig = 0, c_foot = 0, c_fb = 0, c_rej = 0, c_uns = 0, c_safe = 0, c_other = 0;
+    EmitCounts cnt;
 
-    for (uint64_t f = a.file0 + wave_global; f < a.file_end; f += n_waves) {
-        uint32_t nfin = a.n_final[f];
-        uint64_t out0 = a.caption_offsets[f];
-        uint32_t total = (uint32_t)(a.caption_offsets[f + 1] - out0);
-        uint8_t fl = a.verdicts[f].flags;
-        if (lane == 0) {
-            ++c_files;
-            c_low += (fl & TP_F_LOW) != 0; c_elig += (fl & TP_F_ELIGIBLE) != 0; c_foot += (fl & TP_F_FOOTJOB) != 0; c_fb += (fl & TP_F_FALLBACK) != 0;
-            c_rej += (fl & TP_F_LINE_REJECTED) != 0; c_uns += (fl & TP_F_UNSUPPORTED) != 0; c_safe += (fl & TP_F_SAFE_REJECT) != 0;
+    struct Meta { uint32_t nfin, total, slot, fl; uint64_t out0; uint32_t id[2]; };
+    struct Strs { uint32_t off[2], len[2]; };
+    auto load_meta = [&](uint64_t f, Meta& m) {
+        m.nfin = 0; m.total = 0; m.slot = 0; m.fl = 0; m.out0 = 0; m.id[0] = m.id[1] = 0;
+        if (f >= a.file_end) return;
+        m.nfin = a.n_final[f];
+        m.out0 = a.caption_offsets[f];
+        m.total = (uint32_t)(a.caption_offsets[f + 1] - m.out0);
+        m.fl = a.verdicts[f].flags;
+        m.slot = a.slot_of[f];
+        // ids are read whatever the file's kind and size turn out to be (the loads must not wait for those): a slot of the
+        // id array exists for every file, and anything that is not an id of this file is clamped to a valid string here and
+        // ignored later.
+        const uint32_t* ids = a.fin32 + (f - a.file0) * FAST_FIN_MAX;
+        const uint32_t i0 = ids[lane], i1 = ids[lane + 64];
+        m.id[0] = i0 < t.n_strings ? i0 : 0;
+        m.id[1] = i1 < t.n_strings ? i1 : 0;
+    };
+    auto load_strs = [&](const Meta& m, Strs& q) {
+        for (int blk = 0; blk < 2; ++blk) {                         // str_off[id], str_off[id + 1] in one 8-byte load
+            uint32_t oo[2];
+            __builtin_memcpy(oo, t.str_off + m.id[blk], 8);
+            q.off[blk] = oo[0];
+            q.len[blk] = oo[1] - oo[0];
         }
+    };
+    Meta m0, m1, m2;
+    Strs q0, q1;
+    const uint64_t f_first = a.file0 + wave_global;
+    load_meta(f_first, m0);
+    load_meta(f_first + n_waves, m1);
+    load_strs(m0, q0);
+    for (uint64_t f = f_first; f < a.file_end; f += n_waves, m0 = m1, m1 = m2, q0 = q1) {
+        load_meta(f + 2 * n_waves, m2);
+        load_strs(m1, q1);
+        if (m0.slot != SLOT_FAST) continue;                        // a file of the general kernel: k_emit_general writes it
+        const uint32_t nfin = m0.nfin, total = m0.total;
+        const uint64_t out0 = m0.out0;
+        if (lane == 0) cnt.add(m0.fl);
+        if (total == 0) continue;
+        const uint32_t head = (uint32_t)((uintptr_t)(a.captions + out0) & 15);
+        uint32_t len[2], seg[2], incl[2];
+        for (int blk = 0; blk < 2; ++blk) {
+            const uint32_t k = (uint32_t)blk * 64 + lane;
+            const bool live = k < nfin;
+            len[blk] = live ? q0.len[blk] : 0;
+            seg[blk] = len[blk] + ((live && k + 1 < nfin) ? 2u : 0u);
+            incl[blk] = (blk == 0 || nfin > 64) ? wave_scan_incl(seg[blk]) : 0;
+        }
+        const uint32_t tot0 = __shfl(incl[0], 63);
+        for (int blk = 0; blk < 2; ++blk) {
+            if (blk == 1 && nfin <= 64) break;
+            uint8_t* dst = stage + head + (blk ? tot0 : 0) + incl[blk] - seg[blk];
+            const uint8_t* sp = t.str_bytes + q0.off[blk];
+            const uint32_t n = len[blk];
+            // the first 32 bytes are fetched at once (the string arena has slack behind its end), stored exactly
+            uint64_t v[4];
+            __builtin_memcpy(&v[0], sp, 16);
+            __builtin_memcpy(&v[2], sp + 16, 16);
+            const uint32_t n32 = n < 32 ? n : 32, nfull = n32 >> 3;
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < nfull) __builtin_memcpy(dst + 8 * k, &v[k], 8);
+            if (n32 & 7) {                                           // the last, partial word in pieces of 4, 2 and 1 bytes
+                uint64_t x = nfull == 0 ? v[0] : (nfull == 1 ? v[1] : (nfull == 2 ? v[2] : v[3]));
+                uint32_t o = 8 * nfull;
+                if (n32 & 4) { uint32_t y = (uint32_t)x; __builtin_memcpy(dst + o, &y, 4); x >>= 32; o += 4; }
+                if (n32 & 2) { uint16_t y = (uint16_t)x; __builtin_memcpy(dst + o, &y, 2); x >>= 16; o += 2; }
+                if (n32 & 1) dst[o] = (uint8_t)x;
+            }
+            for (uint32_t done = 32; done < n; ++done) dst[done] = sp[done];
+            if (seg[blk] != len[blk]) { dst[n] = ','; dst[n + 1] = ' '; }
+            if (len[blk] && a.histogram) {
+                if (m0.id[blk] < hot_n) atomicAdd(&hot[m0.id[blk]], 1u);
+                else atomicAdd((unsigned long long*)&a.histogram[m0.id[blk]], 1ull);
+            }
+        }
+        if (lane < t.newline_len) stage[head + total - t.newline_len + lane] = t.newline[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staging area is this wave's own: no wait for global traffic
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint8_t* gbase = a.captions + out0 - head;                    // 16-byte aligned
+        const uint32_t end = head + total, nchunks = (end + 15) >> 4;
+        for (uint32_t c = lane; c < nchunks; c += 64) {
+            if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
+        }
+        if (lane < 32) {                                              // the partial first and last pieces, one byte per lane
+            const uint32_t c = lane < 16 ? 0u : nchunks - 1;
+            const uint32_t off = 16 * c + (lane & 15);
+            const bool partial = !(16 * c >= head && 16 * c + 16 <= end) && (lane < 16 || nchunks > 1);
+            if (partial && off >= head && off < end) gbase[off] = stage[off];
+        }
+        __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next file's are written
+    }
+    __syncthreads();
+    if (a.histogram)
+        for (uint32_t i = threadIdx.x; i < hot_n; i += blockDim.x) {
+            uint32_t c = hot[i];
+            if (c) atomicAdd((unsigned long long*)&a.histogram[i], (unsigned long long)c);
+        }
+    if (a.counters && lane == 0) cnt.flush(a.counters);
+}
+
+// Files of the general kernel (a.item_list, or every file of the range when it is null): tags may be strings outside the
+// tables, kept in the file's workspace.  One wavefront per file, bytes stored one by one.
+__global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    EmitCounts cnt;
+    uint64_t c_other = 0;
+    for (uint64_t i = wave_global; i < a.n_items; i += n_waves) {
+        const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
+        const uint32_t nfin = a.n_final[f];
+        const uint64_t out0 = a.caption_offsets[f];
+        const uint32_t total = (uint32_t)(a.caption_offsets[f + 1] - out0);
+        if (lane == 0) cnt.add(a.verdicts[f].flags);
         if (total == 0) continue;   // unsupported file: nothing is written
         const uint32_t slot = a.slot_of[f];
-        const bool fast = slot == SLOT_FAST;
-        const uint32_t* ids = a.fin32 + (f - a.file0) * FAST_FIN_MAX;
-        if (fast && total <= EMIT_STAGE && nfin <= 128) {
-            // Every tag of a file from the wave-per-file kernel is an interned string.  The caption is put together in LDS
-            // at the same 16-byte phase as its place in the output, then stored with aligned 16-byte stores.
-            const uint32_t head = (uint32_t)((uintptr_t)(a.captions + out0) & 15);
-            uint32_t id[2], len[2], seg[2], incl[2];
-            const uint8_t* src[2];
-            for (int blk = 0; blk < 2; ++blk) {
-                const uint32_t k = (uint32_t)blk * 64 + lane;
-                const bool live = k < nfin;
-                id[blk] = live ? ids[k] : 0;
-                const uint32_t o = t.str_off[id[blk]];
-                len[blk] = live ? t.str_off[id[blk] + 1] - o : 0;
-                src[blk] = t.str_bytes + o;
-                seg[blk] = len[blk] + ((live && k + 1 < nfin) ? 2u : 0u);
-                incl[blk] = seg[blk];
-                if (blk == 0 || nfin > 64)
-                    for (int d = 1; d < 64; d <<= 1) { uint32_t o2 = __shfl_up(incl[blk], d); if ((int)lane >= d) incl[blk] += o2; }
-            }
-            const uint32_t tot0 = __shfl(incl[0], 63);
-            for (int blk = 0; blk < 2; ++blk) {
-                if (blk == 1 && nfin <= 64) break;
-                uint8_t* dst = stage + head + (blk ? tot0 : 0) + incl[blk] - seg[blk];
-                const uint8_t* sp = src[blk];
-                uint32_t n = len[blk], done = 0;
-                while (n - done >= 8) { uint64_t v = ldg64u(sp + done); __builtin_memcpy(dst + done, &v, 8); done += 8; }
-                if ((n - done) & 4) { uint32_t v = ldg32u(sp + done); __builtin_memcpy(dst + done, &v, 4); done += 4; }
-                if ((n - done) & 2) { uint16_t v = ldg16u(sp + done); __builtin_memcpy(dst + done, &v, 2); done += 2; }
-                if ((n - done) & 1) { dst[done] = sp[done]; }
-                if (seg[blk] != len[blk]) { dst[n] = ','; dst[n + 1] = ' '; }
-                if (len[blk] && a.histogram) {
-                    if (id[blk] < hot_n) atomicAdd(&hot[id[blk]], 1u);
-                    else atomicAdd((unsigned long long*)&a.histogram[id[blk]], 1ull);
-                }
-            }
-            if (lane < t.newline_len) stage[head + total - t.newline_len + lane] = t.newline[lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            uint8_t* gbase = a.captions + out0 - head;                    // 16-byte aligned
-            const uint32_t end = head + total, nchunks = (end + 15) >> 4;
-            for (uint32_t c = lane; c < nchunks; c += 64) {
-                if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
-            }
-            if (lane < 32) {                                              // the partial first and last pieces, one byte per lane
-                const uint32_t c = lane < 16 ? 0u : nchunks - 1;
-                const uint32_t off = 16 * c + (lane & 15);
-                const bool partial = !(16 * c >= head && 16 * c + 16 <= end) && (lane < 16 || nchunks > 1);
-                if (partial && off >= head && off < end) gbase[off] = stage[off];
-            }
-            __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next file's are written
-            continue;
-        }
-        FileWs ws;
-        if (!fast) {
-            uint64_t w = slot >> 6;
-            WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
-            ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63);
-        }
+        const uint64_t w = slot >> 6;
+        WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
+        FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63);
         uint32_t running = 0;
         for (uint32_t k0 = 0; k0 < nfin; k0 += 64) {
             uint32_t k = k0 + lane;
             bool live = k < nfin;
             H h = 0;
-            if (live) h = fast ? (H)ids[k] : ws.fin[k];
+            if (live) h = ws.fin[k];
             const uint8_t* src = nullptr;
             uint32_t len = 0;
             if (live) {
@@ -345,40 +428,23 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void k_emit(DevTables t, EmitArgs 
             }
             bool sep = live && (k + 1 < nfin);
             uint32_t seg = len + (sep ? 2u : 0u);
-            uint32_t incl = seg;
-            for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+            uint32_t incl = wave_scan_incl(seg);
             uint8_t* dst = a.captions + out0 + running + (incl - seg);
             for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
             if (sep) { dst[len] = ','; dst[len + 1] = ' '; }
             running += __shfl(incl, 63);
             if (live && a.histogram) {
                 if (h_is_dyn(h)) ++c_other;
-                else if (h_id(h) < hot_n) atomicAdd(&hot[h_id(h)], 1u);
                 else atomicAdd((unsigned long long*)&a.histogram[h_id(h)], 1ull);
             }
         }
         if (lane < t.newline_len) a.captions[out0 + running + lane] = t.newline[lane];
     }
-    __syncthreads();
     if (a.histogram) {
-        for (uint32_t i = threadIdx.x; i < hot_n; i += blockDim.x) {
-            uint32_t c = hot[i];
-            if (c) atomicAdd((unsigned long long*)&a.histogram[i], (unsigned long long)c);
-        }
         for (int d = 32; d >= 1; d >>= 1) c_other += __shfl_xor(c_other, d);
         if (lane == 0 && c_other) atomicAdd((unsigned long long*)&a.histogram[t.n_strings], (unsigned long long)c_other);
     }
-    if (a.counters && lane == 0) {
-        unsigned long long* c = (unsigned long long*)a.counters;
-        if (c_files) atomicAdd(&c[0], (unsigned long long)c_files);
-        if (c_low) atomicAdd(&c[1], (unsigned long long)c_low);
-        if (c_elig) atomicAdd(&c[2], (unsigned long long)c_elig);
-        if (c_foot) atomicAdd(&c[3], (unsigned long long)c_foot);
-        if (c_fb) atomicAdd(&c[4], (unsigned long long)c_fb);
-        if (c_rej) atomicAdd(&c[5], (unsigned long long)c_rej);
-        if (c_uns) atomicAdd(&c[6], (unsigned long long)c_uns);
-        if (c_safe) atomicAdd(&c[7], (unsigned long long)c_safe);
-    }
+    if (a.counters && lane == 0) cnt.flush(a.counters);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,9 +482,18 @@ hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
-    uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;   // sixteen wavefronts (files in flight) per block, one block per CU
-    unsigned blocks = (unsigned)(want < 256 ? want : 256);
-    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
+    if (a.fin32) {                                          // the wave-per-file kernel ran: its files first
+        uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
+        unsigned blocks = (unsigned)(want < 256 ? want : 256);   // one block per CU
+        hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (a.n_items) {
+        uint64_t want = (a.n_items + 3) / 4;                // four wavefronts per block
+        unsigned blocks = (unsigned)(want < 1024 ? want : 1024);
+        hipLaunchKernelGGL(k_emit_general, dim3(blocks), dim3(256), 0, s, t, a);
+    }
     return hipGetLastError();
 }
 

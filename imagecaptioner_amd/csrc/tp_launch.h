@@ -56,7 +56,9 @@ struct EmitArgs {
     const uint32_t* wave_LB;
     const uint64_t* wave_off;
     uint8_t* workspace;
-    const uint32_t* fin32;        // indexed by file - file0
+    const uint32_t* fin32;        // indexed by file - file0; null when the wave-per-file kernel did not run
+    const uint32_t* item_list;    // the files of the general kernel, relative to file0 (null: all files of the range)
+    uint64_t n_items;             // how many of them
     const uint32_t* slot_of;
     const uint32_t* n_final;
     const uint64_t* caption_offsets;

@@ -799,7 +799,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         out.flags[i] = f;
     }
     out.str_off[N] = (uint32_t)out.str_bytes.size();
-    out.str_bytes.resize(out.str_bytes.size() + 16, 0);   // slack so byte compares never touch the end of the allocation
+    out.str_bytes.resize(out.str_bytes.size() + 64, 0);   // slack: strings are fetched 32 bytes at a time whatever their length
     const uint32_t feet_id = id_of(feet_n), penis_id = id_of(penis_n), footjob_id = id_of(footjob_n);
     // implied lists (Program.cs:1171-1175): NormalizeTag of each entry, blanks removed
     out.imp_off.assign(N + 1, 0);

@@ -39,11 +39,19 @@ def main():
     lib = load_library()
     buf = (C.c_ulonglong * 32)()
     pipe.run_lines_device(io)
-    lib.tp_debug_prof(buf, 1)
+    has_prof = hasattr(lib, "tp_debug_prof")
+    if has_prof:
+        lib.tp_debug_prof(buf, 1)
     pipe.run_lines_device(io)
-    lib.tp_debug_prof(buf, 1)
+    if has_prof:
+        lib.tp_debug_prof(buf, 1)
     tot = float(sum(buf)) or 1.0
     print("k_fast ms", pipe.last_timing()["select_ms"], "files", n, "config", cfgname)
+    print("no histogram:", pipe.last_timing())
+    hist = torch.zeros(pipe.info.n_strings + 1, dtype=torch.int64, device=dev)
+    io.histogram = hist.data_ptr()
+    pipe.run_lines_device(io)
+    print("with histogram:", pipe.last_timing())
     for k, name in enumerate(NAMES):
         print("%-20s %6.2f %%  %8.0f cycles/file" % (name, 100.0 * buf[k + 1] / tot, buf[k + 1] / n))
 
