@@ -34,16 +34,19 @@ def build(force=False, verbose=False, prof=False):
     variant = os.environ.get("TAGPIPE_BUILD_VARIANT")          # experiments: "name:-Dflag,-Dflag" -> libtagpipe_hip_name.so
     if variant:
         name, flags = variant.split(":", 1)
-        return _build(LIB.replace(".so", "_%s.so" % name), "_%s.o" % name, [f for f in flags.split(",") if f], verbose)
+        return _build(LIB.replace(".so", "_%s.so" % name), "_%s.o" % name, [f for f in flags.split(",") if f], verbose, kernels_only=True)
     if not force and not _stale():
         return LIB
     return _build(LIB, ".o", [], verbose)
 
 
-def _build(lib, obj_suffix, extra, verbose):
+def _build(lib, obj_suffix, extra, verbose, kernels_only=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + obj_suffix)
+        if kernels_only and not src.endswith(".hip"):       # experiments only touch the kernels: reuse the main build's host objects
+            objs.append(os.path.join(CSRC, os.path.splitext(src)[0] + ".o"))
+            continue
         cmd = [HIPCC, "--offload-arch=gfx950"] + COMMON + extra
         if src.endswith(".hip"):
             cmd += ["-x", "hip"]

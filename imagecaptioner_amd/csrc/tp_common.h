@@ -124,6 +124,9 @@ constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
 constexpr int MAX_TOTAL_TAGS = 42;        // Program.cs:38
 constexpr int MAX_ALWAYS_ADD = 64;
 constexpr int MAX_FALLBACK = MAX_TOTAL_TAGS;
+constexpr uint32_t RC_REC_WORDS = 8;
+constexpr uint32_t FAST_RC_MAX_WORDS = 8192;   // 32 KB of LDS per block at most
+constexpr uint32_t FAST_FRULES_MAX = 512;      // facet rules the wave-per-file kernel keeps one hit bit each for
 
 // The table image as the kernels see it (all pointers are device pointers; on the host-side
 // logic check they are host pointers).
@@ -182,6 +185,13 @@ struct DevTables {
     uint32_t final_cap;          // capacity of the per-file final-tag list
     uint32_t evidence_grow;      // evidence list capacity = candidates + this
     // Line ingest scores fall with the candidate index (Program.cs:581), so score tests are index tests:
+    // Rule cache of the wave-per-file kernel (copied to LDS by every block): action rules, subtypes and facet rules as
+    // RC_REC_WORDS-word records {tag id, first subtype (rules), all_cnt | any_cnt << 8 | forbidden_cnt << 16,
+    // literal list offset in the cache | subtype count << 16, four literals inline (all, any, forbidden in this order; the
+    // offset is used when there are more)}, then facets as 4-word records {default id, first facet rule, rule count, 0},
+    // then the longer literal lists.
+    const uint32_t* rc;
+    uint32_t rc_words, rc_subs, rc_frules, rc_facets, n_frules;
     uint32_t seed_ci_limit;      // candidates below this index have !(score < 0.28)  (BuildEvidenceTags, Program.cs:724)
     uint32_t style_ci_limit;     // candidates below this index have score >= 0.60     (DetermineStyleQualityCap, Program.cs:706)
 };

@@ -28,6 +28,20 @@
 #define TP_UNROLL
 #endif
 
+// Diagnostic builds stop the pipeline after section TP_STOP_AFTER (the value handed to TP_STOP keeps the section's results
+// alive) so that the kernel's time up to each section can be measured.
+#ifndef TP_STOP_AFTER
+#define TP_STOP_AFTER (-1)
+#endif
+#define TP_STOP(k, expr)                                                                                     \
+    if (TP_STOP_AFTER == (k)) {                                                                              \
+        fin32[lane] = (uint32_t)(expr);                                                                      \
+        out.verdict = tp_verdict{};                                                                          \
+        out.n_final = 0;                                                                                     \
+        out.caption_len = 0;                                                                                 \
+        return true;                                                                                         \
+    }
+
 namespace tp {
 
 constexpr uint32_t FAST_LINE_MAX = 2048;   // bytes of one line held in LDS
@@ -48,6 +62,7 @@ struct alignas(16) FastLds {
     uint32_t set_min[FAST_SET_SLOTS];
     uint32_t ebits[FAST_LIT_WORDS];
     uint32_t firedw[FAST_FIRED_WORDS];
+    uint32_t fhit[FAST_FRULES_MAX / 32];   // bit p: facet rule p matches the evidence
 };
 
 struct FastOut {
@@ -108,6 +123,24 @@ TP_HD uint32_t keep4(uint32_t p, uint32_t limit) {
 }
 TP_HD uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }   // x != 0
 TP_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }   // x != 0
+// Byte classes of the line scan, one table byte per input byte (the table sits in LDS: DevTables-independent).
+constexpr uint32_t CL_WS = 1, CL_COMMA = 2, CL_SPEC = 4, CL_US = 8, CL_COLON = 16, CL_BAD = 32, CL_S = 64, CL_O = 128;
+TP_HD uint8_t byte_class(uint32_t c) {
+    uint32_t k = 0;
+    if (c == 0x20 || (c >= 9 && c <= 13)) k |= CL_WS;
+    if (c == ',') k |= CL_COMMA;
+    if ((c >= 'A' && c <= 'Z') || c == '"' || c == '\'' || c == ';' || c == '.') k |= CL_SPEC;   // what NormalizeTag changes or strips (Program.cs:1150-1154)
+    if (c == '_') k |= CL_US;
+    if (c == ':') k |= CL_COLON;
+    if (c >= 0x80 || c == '`' || c == '\n' || c == '\r') k |= CL_BAD;     // not ASCII, a code fence, a line break: not for this kernel
+    if (c == 's' || c == 'S') k |= CL_S;
+    if (c == 'o' || c == 'O') k |= CL_O;
+    return (uint8_t)k;
+}
+// The classes of the four bytes of x, in the same byte positions.
+TP_HD uint32_t class4(const uint8_t* cls, uint32_t x) {
+    return (uint32_t)cls[x & 0xFFu] | ((uint32_t)cls[(x >> 8) & 0xFFu] << 8) | ((uint32_t)cls[(x >> 16) & 0xFFu] << 16) | ((uint32_t)cls[x >> 24] << 24);
+}
 constexpr uint32_t c4(char a, char b, char c, char d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
 // The low min(max(n - 8k, 0), 8) bytes of word k of an n-byte string.
 TP_HD uint64_t word_mask(uint32_t n, uint32_t k) {
@@ -305,13 +338,29 @@ TP_HD bool f_match_sub(const DevTables& t, const FastLds& L, const DSub& r) {
     return true;
 }
 
+// One record of the rule cache against the evidence bitset: every `all` literal present, some `any` literal present (when
+// there are any), no forbidden literal present (MatchesActionRule / MatchesSubtypeRule / MatchesFacetRule, Program.cs:777-794).
+TP_HD bool rc_match(const FastLds& L, const uint32_t* rc, uint32_t rec) {
+    const uint32_t* r = rc + rec;
+    const uint32_t cnts = r[2], n_all = cnts & 255u, n_any = (cnts >> 8) & 255u, n_forb = (cnts >> 16) & 255u, tot = n_all + n_any + n_forb;
+    const uint32_t* lits = tot <= 4 ? r + 4 : rc + (r[3] & 0xFFFFu);
+    bool ok_all = true, ok_any = n_any == 0, ok_forb = true;
+    for (uint32_t i = 0; i < tot; ++i) {
+        const bool bit = fbit(L, lits[i]);
+        if (i < n_all) ok_all = ok_all && bit;
+        else if (i < n_all + n_any) ok_any = ok_any || bit;
+        else ok_forb = ok_forb && !bit;
+    }
+    return ok_all && ok_any && ok_forb;
+}
+
 // Appends `id` to the final list unless present.  own0/own1 mirror L.fin[lane], L.fin[lane + 64] in registers.
 // Wave-uniform: `id`, `nf` and the return value are the same in every lane.  Returns false on overflow.
 // With in_set the LDS set (which then holds every element of the list with order 0) learns the new element too.
 template <class W>
-TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id, bool in_set = false) {
+TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id, bool in_set, uint32_t fin_max) {
     if (w.ballot(own0 == id || own1 == id) != 0) return true;
-    if (nf >= FAST_FIN_MAX) return false;
+    if (nf >= fin_max) return false;
     if (w.lane() == (nf & 63)) { if (nf < 64) own0 = id; else own1 = id; }
     bool full = false;
     if (w.lane() == 0) {
@@ -323,12 +372,16 @@ TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t
 }
 
 // The pipeline for one file.  Returns false when the file needs the general kernel.
+// NT = 1: at most 64 tokens (so candidates), one per lane; NT = 2: 128, two per lane.  NF likewise for the final tags.
+// Fewer per lane means fewer registers and less work per wavefront.
+// rc: the rule cache (DevTables::rc, or a copy of it in faster memory); cls: byte_class() of 0..255 as a table.
 // fin32: where the caption's tag ids go (FAST_FIN_MAX entries); fired / facet_choice may be null.
-template <class W>
-TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32, uint32_t* fired,
-                     uint16_t* facet_choice) {
+template <int NT, int NF, class W>
+TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
+                     uint32_t* fired, uint16_t* facet_choice) {
+    static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
+    constexpr uint32_t FIN_MAX = 64u * NF;
     const uint32_t lane = w.lane();
-    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     if (len > FAST_LINE_MAX) return false;
     w.tick(0);
 
@@ -343,87 +396,81 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     w.sync();
     w.tick(1);
     const uint8_t* s = L.line + 16 + shift;
+    TP_STOP(1, L.line[16 + lane])
 
-    // ---- S2: character classes, trim (NormalizeRawTagLine, Program.cs:589-596); four bytes per lane ---------------------
-    constexpr uint32_t H4 = 0x80808080u;
-    uint32_t first_nonws = 0xFFFFFFFFu, end_nonws = 0, first_nl = 0xFFFFFFFFu, last_nl = 0;
-    uint64_t any_odd = 0;
+    // ---- S2: trim (NormalizeRawTagLine, Program.cs:589-596): first non-blank byte from the front, last from the back ----
+    constexpr uint32_t B4 = 0x01010101u;                            // bit 0 of each of four bytes
+    uint32_t a = 0, b = 0;
+    bool blank_line = true;
     for (uint32_t base = 0; base < len; base += 256) {
         const uint32_t p = base + 4 * lane;
-        const uint32_t keep = keep4(p, len);
-        const uint32_t x = (ld32u(s + (p < len ? p : len)) & keep) | (0x20202020u & ~keep);
-        const uint32_t odd = (x & H4) | eq4(x, rep4('`'));
-        const uint32_t nonws = ~ws4(x) & H4;
-        const uint32_t nl = eq4(x, rep4('\n')) | eq4(x, rep4('\r'));
-        const uint64_t m_nonws = w.ballot(nonws != 0);
-        any_odd |= w.ballot(odd != 0);
-        const uint64_t m_nl = w.ballot(nl != 0);
-        if (m_nonws) {
-            if (first_nonws == 0xFFFFFFFFu) { const uint32_t q = ctz64(m_nonws); first_nonws = base + 4 * q + (ctz32(w.shfl(nonws, q)) >> 3); }
-            const uint32_t q = 63 - clz64(m_nonws);
-            end_nonws = base + 4 * q + ((31 - clz32(w.shfl(nonws, q))) >> 3) + 1;
-        }
-        if (m_nl) {
-            if (first_nl == 0xFFFFFFFFu) { const uint32_t q = ctz64(m_nl); first_nl = base + 4 * q + (ctz32(w.shfl(nl, q)) >> 3); }
-            const uint32_t q = 63 - clz64(m_nl);
-            last_nl = base + 4 * q + ((31 - clz32(w.shfl(nl, q))) >> 3);
+        const uint32_t keep = keep4(p, len) & B4;
+        const uint32_t nonws = ~class4(cls, ld32u(s + (p < len ? p : len))) & keep;      // CL_WS is bit 0
+        const uint64_t m = w.ballot(nonws != 0);
+        if (m) { const uint32_t q = ctz64(m); a = base + 4 * q + (ctz32(w.shfl(nonws, q)) >> 3); blank_line = false; break; }
+    }
+    if (!blank_line) {
+        for (uint32_t base = ((len - 1) >> 8) << 8;; base -= 256) {
+            const uint32_t p = base + 4 * lane;
+            const uint32_t keep = keep4(p, len) & B4;
+            const uint32_t nonws = ~class4(cls, ld32u(s + (p < len ? p : len))) & keep;
+            const uint64_t m = w.ballot(nonws != 0);
+            if (m) { const uint32_t q = 63 - clz64(m); b = base + 4 * q + ((31 - clz32(w.shfl(nonws, q))) >> 3) + 1; break; }
+            if (base == 0) break;                                  // not reached: a non-blank byte exists
         }
     }
-    if (any_odd) return false;
-    const bool blank_line = first_nonws == 0xFFFFFFFFu;
-    const uint32_t a = blank_line ? 0 : first_nonws, b = blank_line ? 0 : end_nonws;
-    if (!blank_line && first_nl != 0xFFFFFFFFu && first_nl < b && last_nl > a) return false;   // a line break may sit inside the text
 
-    // commas, tokens that need the byte-wise normaliser, LooksBad (Program.cs:1141-1147)
+    // commas, tokens that need the byte-wise normaliser, bytes this kernel leaves to the general one, LooksBad (Program.cs:1141-1147)
     uint32_t ncomma = 0;
     bool refusal = false, keyword = false;
-    uint64_t any_blank = 0;
+    uint64_t any_blank = 0, any_bad = 0;
     for (uint32_t base = a; base < b; base += 256) {
         const uint32_t p = base + 4 * lane;
         const uint32_t pp = p < b ? p : b;
-        const uint32_t inm = keep4(p, b) & H4;
+        const uint32_t inm = keep4(p, b) & B4;
         const uint32_t x = ld32u(s + pp);
-        uint32_t pv = ld32u(s + pp - 1);                           // the bytes before them
-        if (p == a) pv = (pv & ~0xFFu) | (uint32_t)',';
-        const uint32_t cm = eq4(x, rep4(',')) & inm;
-        const uint64_t mc[4] = {w.ballot(cm & 0x80u), w.ballot(cm & 0x8000u), w.ballot(cm & 0x800000u), w.ballot(cm & 0x80000000u)};
+        const uint32_t cw = class4(cls, x);
+        uint32_t pcw = (cw << 8) | (p == a ? CL_COMMA : (uint32_t)cls[s[pp - 1]]);   // the classes of the bytes before them
+        const uint32_t ncw = (cw >> 8) | ((uint32_t)cls[s[pp + 4]] << 24);            // ... and after them
+        const uint32_t cm = (cw >> 1) & inm;                        // commas
+        const uint64_t mc[4] = {w.ballot(cm & 1u), w.ballot(cm & 0x100u), w.ballot(cm & 0x10000u), w.ballot(cm & 0x1000000u)};
         uint32_t k[4];                                             // commas before byte j = index of the token it belongs to
-        k[0] = ncomma + popc64(mc[0] & lt) + popc64(mc[1] & lt) + popc64(mc[2] & lt) + popc64(mc[3] & lt);
-        k[1] = k[0] + ((cm >> 7) & 1u);
-        k[2] = k[1] + ((cm >> 15) & 1u);
-        k[3] = k[2] + ((cm >> 23) & 1u);
+        k[0] = ncomma + w.rank(mc[0]) + w.rank(mc[1]) + w.rank(mc[2]) + w.rank(mc[3]);
+        k[1] = k[0] + (cm & 1u);
+        k[2] = k[1] + ((cm >> 8) & 1u);
+        k[3] = k[2] + ((cm >> 16) & 1u);
         if (cm) {
             for (uint32_t j = 0; j < 4; ++j)
-                if ((cm & (0x80u << (8 * j))) && k[j] < FAST_TOK_MAX) L.cpos[k[j]] = (uint16_t)(p + j);
+                if ((cm & (1u << (8 * j))) && k[j] < FAST_TOK_MAX) L.cpos[k[j]] = (uint16_t)(p + j);
         }
         ncomma += popc64(mc[0]) + popc64(mc[1]) + popc64(mc[2]) + popc64(mc[3]);
         // A byte the normaliser would change or drop: upper case, quotes, trailing-punctuation characters, white space
         // other than a single byte right after a comma, the second of two underscores.
-        const uint32_t blank = ws4(x) & ~eq4(pv, rep4(',')) & inm;
-        const uint32_t sp = (((ge4(x, 'A') & ~ge4(x, 'Z' + 1)) | eq4(x, rep4('"')) | eq4(x, rep4('\'')) | eq4(x, rep4(';')) | eq4(x, rep4('.')) |
-                              (eq4(x, rep4('_')) & eq4(pv, rep4('_')))) & inm) | blank;
+        const uint32_t blank = cw & ~(pcw >> 1) & inm;
+        const uint32_t sp = (((cw >> 2) | ((cw >> 3) & (pcw >> 3))) & inm) | blank;
         any_blank |= w.ballot(blank != 0);
+        any_bad |= w.ballot(((cw >> 5) & inm) != 0);
         if (sp) {
             for (uint32_t j = 0; j < 4; ++j)
-                if ((sp & (0x80u << (8 * j))) && k[j] < FAST_TOK_MAX) w.lds_or(&L.tspec[k[j] >> 5], 1u << (k[j] & 31));
+                if ((sp & (1u << (8 * j))) && k[j] < FAST_TOK_MAX) w.lds_or(&L.tspec[k[j] >> 5], 1u << (k[j] & 31));
         }
-        const uint32_t colon = eq4(x, rep4(':')) & inm;
+        const uint32_t colon = (cw >> 4) & inm;
         if (w.ballot(colon != 0)) {   // only "positive:" / "negative:" matter (Program.cs:57, 592-594); other colons are ordinary tag text
             bool key = false;
             for (uint32_t j = 0; j < 4; ++j)
-                if ((colon & (0x80u << (8 * j))) && p + j >= 8 && (lds_match(s, p + j - 8, len, "positive", 8) || lds_match(s, p + j - 8, len, "negative", 8))) key = true;
+                if ((colon & (1u << (8 * j))) && p + j >= 8 && (lds_match(s, p + j - 8, len, "positive", 8) || lds_match(s, p + j - 8, len, "negative", 8))) key = true;
             if (w.ballot(key)) keyword = true;
         }
-        // DropTagsContains (Program.cs:56-58): "sorry" is the one entry without a blank inside
-        const uint32_t xl = x | 0x20202020u, nx = ld32u(s + pp + 4) | 0x20202020u;
-        const uint32_t sor = eq4(xl, rep4('s')) & eq4(win4(xl, nx, 1), rep4('o')) & eq4(win4(xl, nx, 2), rep4('r')) & inm;
-        if (w.ballot(sor != 0)) {
+        // DropTagsContains (Program.cs:56-58): "sorry" is the one entry without a blank inside; look closer after "so"
+        const uint32_t so = (cw >> 6) & (ncw >> 7) & inm;
+        if (w.ballot(so != 0)) {
             bool hit = false;
             for (uint32_t j = 0; j < 4; ++j)
-                if ((sor & (0x80u << (8 * j))) && lds_match(s, p + j, b, "sorry", 5)) hit = true;
+                if ((so & (1u << (8 * j))) && lds_match(s, p + j, b, "sorry", 5)) hit = true;
             if (w.ballot(hit)) refusal = true;
         }
     }
+    if (any_bad) return false;
     if (any_blank && !refusal) {
         // The other entries (without the two that hold ':') all have a blank that follows a letter; such a blank was seen.
         for (uint32_t base = a; base < b; base += 64) {
@@ -449,14 +496,15 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
     if (keyword) return false;
     const uint32_t T = ncomma + 1;
-    if (T > FAST_TOK_MAX) return false;
+    if (T > 64u * NT) return false;
     const bool rejected = blank_line || refusal || (ncomma < 2 && (b - a) > 40);
     w.sync();
     w.tick(2);
+    TP_STOP(2, a ^ b ^ ncomma ^ T ^ (uint32_t)rejected ^ L.cpos[lane] ^ L.tspec[lane & 3])
 
     // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
     // A token's lane stays its candidate's lane: candidate index = number of kept tokens before it.
-    const int nblk = T > 64 ? 2 : 1;                              // tokens (and so candidates) sit two per lane only in long lines
+    const int nblk = NT == 1 ? 1 : (T > 64 ? 2 : 1);              // tokens (and so candidates) sit two per lane only in long lines
     uint32_t n = 0;
     bool act[2] = {false, false};
     uint32_t h1[2] = {EMPTY_ID, EMPTY_ID}, ci[2] = {0, 0};
@@ -489,13 +537,14 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         if (!dedupe_first(w, L, h1, keep, act, nblk)) return false;
         const uint64_t m0 = w.ballot(act[0]), m1 = nblk > 1 ? w.ballot(act[1]) : 0;
         n = popc64(m0) + popc64(m1);
-        ci[0] = popc64(m0 & lt);
-        ci[1] = popc64(m0) + popc64(m1 & lt);
+        ci[0] = w.rank(m0);
+        ci[1] = popc64(m0) + w.rank(m1);
         if (!act[0]) { h1[0] = EMPTY_ID; r1[0] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
         if (!act[1]) { h1[1] = EMPTY_ID; r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
     }
 
     w.tick(3);
+    TP_STOP(3, h1[0] ^ h1[1] ^ r1[0].flags ^ r1[0].next ^ r1[1].flags ^ r1[0].lit ^ r1[0].step0 ^ ci[0] ^ ci[1] ^ n ^ (uint32_t)act[0] ^ (uint32_t)act[1])
     // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
     // In line ingest the scores fall with the candidate index, so "sorted" order is candidate order and the first of
     // two candidates that NormalizeTag merges carries the merged score, order and source.
@@ -529,6 +578,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
 
     w.tick(4);
+    TP_STOP(4, t2[0] ^ t2[1] ^ r2[0].flags ^ r2[1].flags ^ r2[0].next ^ (uint32_t)uniq[0] ^ (uint32_t)uniq[1] ^ (uint32_t)ev_seed[0] ^ (uint32_t)ev_seed[1] ^ (uint32_t)style_cap ^ n_dropped)
     // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
     uint32_t t3[2] = {EMPTY_ID, EMPTY_ID};
     bool ok3[2] = {false, false};
@@ -560,7 +610,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
             uint32_t take = popc64(m0) + popc64(m1);
             if (bk < 6 && take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
             if (take > room) take = room;
-            uint32_t rank0 = popc64(m0 & lt), rank1 = popc64(m0) + popc64(m1 & lt);
+            uint32_t rank0 = w.rank(m0), rank1 = popc64(m0) + w.rank(m1);
             if (el0 && rank0 < take) { taken[0] = true; pos[0] = nr + rank0; }
             if (el1 && rank1 < take) { taken[1] = true; pos[1] = nr + rank1; }
             nr += take;
@@ -573,6 +623,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     const uint32_t n_selected = nr;
 
     w.tick(5);
+    TP_STOP(5, L.fin[lane] ^ nr ^ n_selected)
     // ---- S7: EvaluateCoverage (Program.cs:1056-1095) and normalizedFinalSet (Program.cs:303) -------------------------------
     uint32_t own0 = NO_ID, own1 = NO_ID;   // the final list, entry k in lane k & 63
     uint32_t nf = 0;
@@ -596,13 +647,13 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                 uint32_t key[2] = {t4, NO_ID};
                 bool valid[2] = {nb4, false};
                 bool fst[2];
-                if (!dedupe_first(w, L, key, valid, fst)) return false;
+                if (!dedupe_first(w, L, key, valid, fst, 1)) return false;
                 keep4 = fst[0];
             }
             uint64_t m = w.ballot(keep4);
             nf = popc64(m);
             w.sync();
-            if (keep4) L.fin[popc64(m & lt)] = t4;
+            if (keep4) L.fin[w.rank(m)] = t4;
         } else {                                                   // fewer than 3 tags: the minimal fallback selection (Program.cs:297-298)
             nf = t.n_fb_final;
             w.sync();
@@ -614,6 +665,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     uint32_t flags = (rejected ? TP_F_LINE_REJECTED : 0u) | (nr < 3 ? TP_F_FALLBACK : 0u);
 
     w.tick(6);
+    TP_STOP(6, own0 ^ nf ^ coverage ^ flags)
     // ---- S8: evidence closure (Program.cs:301-302) -> literal bitset, count, feet/penis ---------------------------------------
     for (uint32_t k = lane; k < t.lit_words; k += 64) L.ebits[k] = 0;
     w.sync();
@@ -671,6 +723,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
 
     w.tick(7);
+    TP_STOP(7, own0 ^ nf ^ n_evidence ^ (uint32_t)ev_feet ^ (uint32_t)ev_penis ^ L.ebits[lane])
     // ---- S9: final-set closure, in the reference's insertion order (ExpandImpliedTags, Program.cs:304, 1160-1179) ------------
     // The set grows breadth-first: a round visits every element in order and appends NormalizeTag(it) and its implied tags
     // (its "steps").  A round whose elements have at most two steps each runs in parallel: every step is offered to the LDS
@@ -683,7 +736,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         w.sync();
         uint32_t lo = 0, hi = nf;
         while (lo < hi) {
-            const int nblk = hi > 64 ? 2 : 1;
+            const int nblk = NF == 1 ? 1 : (hi > 64 ? 2 : 1);
             uint32_t so[2] = {0, 0}, sc[2] = {0, 0}, sid[2][2] = {{NO_ID, NO_ID}, {NO_ID, NO_ID}};
             bool edge[2] = {false, false};
             uint64_t m_edge[2] = {0, 0}, m_long = 0;
@@ -710,7 +763,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                         const uint32_t cnt = w.shfl(sc[blk], q), off = w.shfl(so[blk], q), a0 = w.shfl(sid[blk][0], q), a1 = w.shfl(sid[blk][1], q);
                         for (uint32_t k = 0; k < cnt; ++k) {
                             const uint32_t x = k == 0 ? a0 : (k == 1 ? a1 : t.step_ids[off + k]);
-                            if (!fin_append(w, L, own0, own1, nf, x, true)) return false;
+                            if (!fin_append(w, L, own0, own1, nf, x, true, FIN_MAX)) return false;
                         }
                     }
                 }
@@ -735,9 +788,9 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
                         mw[blk][j] = w.ballot(win[blk][j]);
                     }
                 const uint32_t c0 = popc64(mw[0][0]) + popc64(mw[0][1]), c1 = popc64(mw[1][0]) + popc64(mw[1][1]);
-                if (nf + c0 + c1 > FAST_FIN_MAX) return false;
+                if (nf + c0 + c1 > FIN_MAX) return false;
                 TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-                    uint32_t pos = nf + (blk ? c0 : 0) + popc64(mw[blk][0] & lt) + popc64(mw[blk][1] & lt);
+                    uint32_t pos = nf + (blk ? c0 : 0) + w.rank(mw[blk][0]) + w.rank(mw[blk][1]);
                     if (win[blk][0]) { L.fin[pos] = sid[blk][0]; L.set_min[slot[blk][0]] = 0; ++pos; }
                     if (win[blk][1]) { L.fin[pos] = sid[blk][1]; L.set_min[slot[blk][1]] = 0; }
                 }
@@ -754,13 +807,14 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
 
     w.tick(8);
+    TP_STOP(8, own0 ^ own1 ^ nf ^ gnext[0] ^ gflags[0] ^ gnext[1] ^ gflags[1])
     // ---- S10: InferActionTags (Program.cs:731-753) ---------------------------------------------------------------------------
     {
         // inferred = Select(NormalizeTag).Where(non-blank).Distinct()
-        uint32_t g[2];
-        bool nb[2];
+        uint32_t g[2] = {EMPTY_ID, EMPTY_ID};
+        bool nb[2] = {false, false};
         bool changed = false;
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NF; ++blk) {
             uint32_t idx = (uint32_t)blk * 64 + lane;
             uint32_t id = blk == 0 ? own0 : own1;
             bool in = idx < nf;
@@ -770,11 +824,11 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         }
         if (w.ballot(changed)) {
             bool fst[2];
-            if (!dedupe_first(w, L, g, nb, fst)) return false;
-            uint64_t m0 = w.ballot(fst[0]), m1 = w.ballot(fst[1]);
+            if (!dedupe_first(w, L, g, nb, fst, NF)) return false;
+            uint64_t m0 = w.ballot(fst[0]), m1 = NF > 1 ? w.ballot(fst[1]) : 0;
             nf = popc64(m0) + popc64(m1);
-            if (fst[0]) L.fin[popc64(m0 & lt)] = g[0];
-            if (fst[1]) L.fin[popc64(m0) + popc64(m1 & lt)] = g[1];
+            if (fst[0]) L.fin[w.rank(m0)] = g[0];
+            if (fst[1]) L.fin[popc64(m0) + w.rank(m1)] = g[1];
             w.sync();
             own0 = lane < nf ? L.fin[lane] : NO_ID;
             own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
@@ -787,51 +841,54 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         if (lane < t.fired_words) L.firedw[lane] = 0;
         w.sync();
         for (uint32_t r0 = 0; r0 < t.n_rules; r0 += 64) {
-            uint32_t r = r0 + lane;
-            bool hit = false;
-            DRule rule = t.rules[r < t.n_rules ? r : 0];
-            if (r < t.n_rules) {                                   // MatchesActionRule, Program.cs:777-782
-                hit = !(rule.all_cnt && !f_all(t, L, rule.all_off, rule.all_cnt)) && !(rule.any_cnt && !f_any(t, L, rule.any_off, rule.any_cnt)) &&
-                      !f_any(t, L, rule.forb_off, rule.forb_cnt);
-            }
+            const uint32_t r = r0 + lane;
+            const bool hit = r < t.n_rules && rc_match(L, rc, r * RC_REC_WORDS);                  // MatchesActionRule, Program.cs:777-782
             uint64_t m = w.ballot(hit);
             if (hit) w.lds_or(&L.firedw[r >> 5], 1u << (r & 31));      // "action:{parent}" (Program.cs:741)
             while (m) {
-                uint32_t q = ctz64(m);
+                const uint32_t* rr = rc + (r0 + ctz64(m)) * RC_REC_WORDS;
                 m &= m - 1;
-                uint32_t parent = w.shfl(rule.parent_id, q), sub_off = w.shfl(rule.sub_off, q), sub_cnt = w.shfl(rule.sub_cnt, q);
-                if (!fin_append(w, L, own0, own1, nf, parent, true)) return false;
+                const uint32_t parent = rr[0], sub_off = rr[1], sub_cnt = rr[3] >> 16;
+                if (!fin_append(w, L, own0, own1, nf, parent, true, FIN_MAX)) return false;
                 for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
-                    uint32_t si = s0 + lane;
-                    bool shit = false;
-                    DSub sub = t.subs[sub_off + (si < sub_cnt ? si : 0)];
-                    if (si < sub_cnt) shit = f_match_sub(t, L, sub);
+                    const uint32_t si = s0 + lane;
+                    const uint32_t srec = t.rc_subs + (sub_off + (si < sub_cnt ? si : 0)) * RC_REC_WORDS;
+                    const bool shit = si < sub_cnt && rc_match(L, rc, srec);
                     uint64_t ms = w.ballot(shit);
                     if (shit) {                                    // "subtype:{parent}:{tag}" (Program.cs:748)
                         uint32_t bit = t.n_rules + sub_off + si;
                         w.lds_or(&L.firedw[bit >> 5], 1u << (bit & 31));
                     }
                     while (ms) {
-                        uint32_t qs = ctz64(ms);
+                        const uint32_t qs = ctz64(ms);
                         ms &= ms - 1;
-                        if (!fin_append(w, L, own0, own1, nf, w.shfl(sub.tag_id, qs), true)) return false;
+                        if (!fin_append(w, L, own0, own1, nf, rc[t.rc_subs + (sub_off + s0 + qs) * RC_REC_WORDS], true, FIN_MAX)) return false;
                     }
                 }
             }
         }
     }
     w.tick(9);
+    TP_STOP(9, own0 ^ own1 ^ nf ^ L.firedw[lane])
     // ---- S11: EnsureRequiredFacets (Program.cs:755-775) -----------------------------------------------------------------------
+    // every facet rule on its own lane first, then every facet picks its first matching rule
+    for (uint32_t p0 = 0; p0 < t.n_frules; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const uint64_t m = w.ballot(p < t.n_frules && rc_match(L, rc, t.rc_frules + p * RC_REC_WORDS));
+        if (lane == 0) { L.fhit[p0 >> 5] = (uint32_t)m; L.fhit[(p0 >> 5) + 1] = (uint32_t)(m >> 32); }
+    }
+    w.sync();
     for (uint32_t f0 = 0; f0 < t.n_facets; f0 += 64) {
-        uint32_t f = f0 + lane;
+        const uint32_t f = f0 + lane;
         uint32_t selected = NO_ID;
         if (f < t.n_facets) {
-            DFacet facet = t.facets[f];
-            selected = facet.def_id;
+            const uint32_t* fr = rc + t.rc_facets + 4 * f;
+            const uint32_t rule_off = fr[1], rule_cnt = fr[2];
+            selected = fr[0];
             uint16_t choice = 0xFFFF;
-            for (uint32_t r = 0; r < facet.rule_cnt; ++r) {
-                DSub fr = t.facet_rules[facet.rule_off + r];
-                if (f_match_sub(t, L, fr)) { selected = fr.tag_id; choice = (uint16_t)r; break; }
+            for (uint32_t r = 0; r < rule_cnt; ++r) {
+                const uint32_t p = rule_off + r;
+                if ((L.fhit[p >> 5] >> (p & 31)) & 1u) { selected = rc[t.rc_frules + p * RC_REC_WORDS]; choice = (uint16_t)r; break; }
             }
             if (facet_choice) facet_choice[f] = choice;
         }
@@ -844,8 +901,8 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
         if (w.ballot(full)) return false;
         const bool win = slot != NO_ID && L.set_min[slot] == 1 + lane;
         const uint64_t mw = w.ballot(win);
-        if (nf + popc64(mw) > FAST_FIN_MAX) return false;
-        if (win) { L.fin[nf + popc64(mw & lt)] = selected; L.set_min[slot] = 0; }
+        if (nf + popc64(mw) > FIN_MAX) return false;
+        if (win) { L.fin[nf + w.rank(mw)] = selected; L.set_min[slot] = 0; }
         nf += popc64(mw);
         w.sync();
         own0 = lane < nf ? L.fin[lane] : NO_ID;
@@ -854,13 +911,14 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     w.sync();
 
     w.tick(10);
+    TP_STOP(10, own0 ^ own1 ^ nf)
     // ---- S12: verdicts on the final list (Program.cs:319, 329), GetUnknownTags (:817-824), FormatCaptionSingleLine (:971-974) ---
-    uint32_t c[2], clen[2];
-    bool cnb[2], cknown[2];
+    uint32_t c[2] = {EMPTY_ID, EMPTY_ID}, clen[2] = {0, 0};
+    bool cnb[2] = {false, false}, cknown[2] = {false, false};
     bool face = false, outfit = false, changed = false;
     uint32_t safe_idx[2] = {0, 0};
     bool safe[2] = {false, false};
-    for (int blk = 0; blk < 2; ++blk) {
+    for (int blk = 0; blk < NF; ++blk) {
         uint32_t idx = (uint32_t)blk * 64 + lane;
         uint32_t id = blk == 0 ? own0 : own1;
         bool in = idx < nf;
@@ -882,7 +940,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     if (!(w.ballot(face) && w.ballot(outfit))) flags |= TP_F_LOW;
     int safe_hit = -1;
     {
-        uint64_t ms0 = w.ballot(safe[0]), ms1 = w.ballot(safe[1]);
+        uint64_t ms0 = w.ballot(safe[0]), ms1 = NF > 1 ? w.ballot(safe[1]) : 0;
         if (t.safe_mode && (ms0 | ms1)) {                          // first final tag in SafeModeRejectTags (Program.cs:942-945)
             uint32_t v = ms0 ? w.shfl(safe_idx[0], ctz64(ms0)) : w.shfl(safe_idx[1], ctz64(ms1));
             safe_hit = (int)v;
@@ -891,18 +949,18 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint8_t* text, 
     }
     bool keepc[2] = {cnb[0], cnb[1]};
     if (w.ballot(changed)) {
-        if (!dedupe_first(w, L, c, cnb, keepc)) return false;
+        if (!dedupe_first(w, L, c, cnb, keepc, NF)) return false;
     }
-    const uint64_t mc0 = w.ballot(keepc[0]), mc1 = w.ballot(keepc[1]);
+    const uint64_t mc0 = w.ballot(keepc[0]), mc1 = NF > 1 ? w.ballot(keepc[1]) : 0;
     const uint32_t nc = popc64(mc0) + popc64(mc1);
     uint32_t bytes = (keepc[0] ? clen[0] : 0) + (keepc[1] ? clen[1] : 0);
     bytes = wave_sum(w, bytes);
-    const uint32_t unknown = t.known_active ? popc64(w.ballot(keepc[0] && !cknown[0])) + popc64(w.ballot(keepc[1] && !cknown[1])) : 0;
+    const uint32_t unknown = t.known_active ? popc64(w.ballot(keepc[0] && !cknown[0])) + (NF > 1 ? popc64(w.ballot(keepc[1] && !cknown[1])) : 0) : 0;
     const bool footjob = w.ballot((keepc[0] && c[0] == t.footjob_n) || (keepc[1] && c[1] == t.footjob_n)) != 0;   // HasTag(finalTags, "footjob"), Program.cs:311
     w.sync();
     if (fired && lane < t.fired_words) fired[lane] = L.firedw[lane];
-    if (keepc[0]) fin32[popc64(mc0 & lt)] = c[0];
-    if (keepc[1]) fin32[popc64(mc0) + popc64(mc1 & lt)] = c[1];
+    if (keepc[0]) fin32[w.rank(mc0)] = c[0];
+    if (keepc[1]) fin32[popc64(mc0) + w.rank(mc1)] = c[1];
     if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (footjob) flags |= TP_F_FOOTJOB; }
 
     w.tick(11);

@@ -46,6 +46,8 @@ struct DevWave {
 #endif
     __device__ uint32_t lane() const { return threadIdx.x & 63u; }
     __device__ uint64_t ballot(bool p) const { return __ballot(p ? 1 : 0); }
+    // how many set bits of m belong to lanes below this one
+    __device__ uint32_t rank(uint64_t m) const { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
     __device__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)(src & 63u), 64); }
     // Orders the wave's own LDS traffic (each wavefront owns its LDS state): LDS instructions of one wave execute in
     // order, so wavefront scope is enough and, unlike a wider scope, does not wait for outstanding global loads and stores.
@@ -63,23 +65,31 @@ struct DevWave {
 
 constexpr int FAST_WAVES_PER_BLOCK = 4;
 
-#ifndef TP_FAST_WAVES_PER_SIMD
-#define TP_FAST_WAVES_PER_SIMD 4
-#endif
-__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_FAST_WAVES_PER_SIMD))) void k_fast(DevTables t, FastArgs a) {
+// The first stage serves files of at most 64 tokens (and 128 final tags) over the whole range [file0, file_end); the second
+// serves the files the first declined (a.item_list, a.item_count entries on the device) with 128 tokens.  Files both decline
+// go to a.slow_list for the general kernel.
+template <int NT>
+__device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a) {
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
+    __shared__ uint8_t cls[256];                                // byte classes of the line scan
+    extern __shared__ uint32_t rc_lds[];                        // the rule cache, t.rc_words words (dynamic LDS)
+    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
+    __syncthreads();
     FastLds& L = lds[threadIdx.x >> 6];
     DevWave w;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t f = a.file0 + wave_global; f < a.file_end; f += n_waves) {
+    const uint64_t n_items = a.item_list ? (uint64_t)*a.item_count : a.file_end - a.file0;
+    for (uint64_t i = wave_global; i < n_items; i += n_waves) {
+        const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
         uint64_t o = a.offsets[f];
         uint64_t len64 = a.offsets[f + 1] - o;
         bool done = false;
         FastOut out;
         if (len64 <= FAST_LINE_MAX) {
-            done = fast_file(w, t, L, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
-                             a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+            done = fast_file<NT, 2>(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
+                                 a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
         }
         if (w.lane() == 0) {
             if (done) {
@@ -98,6 +108,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     w.flush();
 #endif
 }
+#ifndef TP_FAST_WAVES_PER_SIMD
+#define TP_FAST_WAVES_PER_SIMD 5
+#endif
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_FAST_WAVES_PER_SIMD))) void k_fast(DevTables t, FastArgs a) {
+    fast_body<1>(t, a);
+}
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t, FastArgs a) { fast_body<2>(t, a); }
 
 // ------------------------------------------------------------------------------------------------
 // k_wave_sizes
@@ -457,7 +474,8 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint64_t want = (n + FAST_WAVES_PER_BLOCK - 1) / FAST_WAVES_PER_BLOCK;
     unsigned blocks = (unsigned)(want < 256 * 8 ? want : 256 * 8);    // up to 8 blocks per CU, wavefronts stride over the files
-    hipLaunchKernelGGL(k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), 0, s, t, a);
+    if (a.item_list) hipLaunchKernelGGL(k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    else hipLaunchKernelGGL(k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     return hipGetLastError();
 }
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,

@@ -20,8 +20,10 @@ struct FastArgs {
     uint32_t* cap_len;
     uint32_t* fin32;              // FAST_FIN_MAX ids per file, indexed by file - file0
     uint32_t* slot_of;            // per file: SLOT_FAST, or (set later) its position in the general kernel's item list
-    uint32_t* slow_list;          // files (absolute index) left to the general kernel, in no particular order
+    uint32_t* slow_list;          // files (relative to file0) this launch declines, in no particular order
     uint32_t* slow_count;
+    const uint32_t* item_list;    // null: first stage over the whole range; else the files (relative to file0) the first stage declined:
+    const uint32_t* item_count;   //   second stage (two elements per lane) over *item_count of them
     uint32_t* fired;
     uint16_t* facet_choice;
 };

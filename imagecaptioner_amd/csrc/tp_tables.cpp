@@ -1044,8 +1044,65 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         uint32_t id = out.ht_id[s];
         out.ht_info[s] = HtInfo{out.alias1[id], word_off[id], out.str_off[id + 1] - out.str_off[id], 0};
     }
+    // rule cache
+    bool rc_ok = true;
+    {
+        std::vector<uint32_t>& rc = out.rule_cache;
+        rc.clear();
+        std::vector<uint32_t> tail;                                // literal lists longer than four
+        struct Fix { size_t word; uint32_t tail_off; };
+        std::vector<Fix> fixes;
+        auto record = [&](uint32_t tag, uint32_t w1, uint32_t sub_cnt, uint32_t all_off, uint32_t all_cnt, uint32_t any_off, uint32_t any_cnt, uint32_t forb_off,
+                          uint32_t forb_cnt) {
+            if (all_cnt > 255 || any_cnt > 255 || forb_cnt > 255 || sub_cnt > 0xFFFF) rc_ok = false;
+            size_t base = rc.size();
+            rc.resize(base + RC_REC_WORDS, 0);
+            rc[base] = tag;
+            rc[base + 1] = w1;
+            rc[base + 2] = (all_cnt & 255) | ((any_cnt & 255) << 8) | ((forb_cnt & 255) << 16);
+            rc[base + 3] = sub_cnt << 16;
+            std::vector<uint32_t> lits;
+            for (uint32_t k = 0; k < all_cnt; ++k) lits.push_back(out.pool[all_off + k]);
+            for (uint32_t k = 0; k < any_cnt; ++k) lits.push_back(out.pool[any_off + k]);
+            for (uint32_t k = 0; k < forb_cnt; ++k) lits.push_back(out.pool[forb_off + k]);
+            if (lits.size() <= 4) {
+                for (size_t k = 0; k < lits.size(); ++k) rc[base + 4 + k] = lits[k];
+            } else {
+                fixes.push_back(Fix{base + 3, (uint32_t)tail.size()});
+                tail.insert(tail.end(), lits.begin(), lits.end());
+            }
+        };
+        const uint32_t n_rules = (uint32_t)ld.actions.size(), n_subs = (uint32_t)out.sub_names.size(), n_facets = (uint32_t)ld.facets.size();
+        for (uint32_t r = 0; r < n_rules; ++r) {
+            const DRule& d = out.rules[r];
+            record(d.parent_id, d.sub_off, d.sub_cnt, d.all_off, d.all_cnt, d.any_off, d.any_cnt, d.forb_off, d.forb_cnt);
+        }
+        sc.rc_subs = (uint32_t)rc.size();
+        for (uint32_t k = 0; k < n_subs; ++k) {
+            const DSub& d = out.subs[k];
+            record(d.tag_id, 0, 0, d.all_off, d.all_cnt, d.any_off, d.any_cnt, 0, 0);
+        }
+        sc.rc_frules = (uint32_t)rc.size();
+        uint32_t n_frules = 0;
+        for (uint32_t f = 0; f < n_facets; ++f) n_frules += out.facets[f].rule_cnt;
+        for (uint32_t k = 0; k < n_frules; ++k) {
+            const DSub& d = out.facet_rules[k];
+            record(d.tag_id, 0, 0, d.all_off, d.all_cnt, d.any_off, d.any_cnt, 0, 0);
+        }
+        sc.n_frules = n_frules;
+        sc.rc_facets = (uint32_t)rc.size();
+        for (uint32_t f = 0; f < n_facets; ++f) {
+            rc.push_back(out.facets[f].def_id); rc.push_back(out.facets[f].rule_off); rc.push_back(out.facets[f].rule_cnt); rc.push_back(0);
+        }
+        const uint32_t tail_base = (uint32_t)rc.size();
+        for (const Fix& fx : fixes) rc[fx.word] |= (tail_base + fx.tail_off) & 0xFFFFu;
+        rc.insert(rc.end(), tail.begin(), tail.end());
+        if (rc.empty()) rc.push_back(0);
+        sc.rc_words = (uint32_t)rc.size();
+        if (sc.rc_words > FAST_RC_MAX_WORDS || sc.rc_words > 0xFFFFu || n_frules > FAST_FRULES_MAX) rc_ok = false;
+    }
     // the wave-per-file kernel keeps its literal bitset in 128 LDS words and assumes scores fall with the token index
-    sc.fast_ok = (sc.lit_words <= 128 && sc.fired_words <= 64 && n_lits < 0xFFFFFFu && cfg.line_weight > 0.0) ? 1 : 0;
+    sc.fast_ok = (sc.lit_words <= 128 && sc.fired_words <= 64 && n_lits < 0xFFFFFFu && cfg.line_weight > 0.0 && rc_ok) ? 1 : 0;
     sc.n_fb_final = 0;
     out.n_known = (uint32_t)ld.known.size();
     out.strict = ld.strict;
@@ -1087,6 +1144,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.rec = ht.rec.data();
     t.ht_info = ht.ht_info.data();
     t.str_words = ht.str_words.data();
+    t.rc = ht.rule_cache.data();
     t.step_off = ht.step_off.data();
     t.step_ids = ht.step_ids.data();
     t.reach_off = ht.reach_off.data();

@@ -31,7 +31,7 @@ struct HostTables {
     std::vector<Rec> rec;
     std::vector<HtInfo> ht_info;
     std::vector<uint64_t> str_words;
-    std::vector<uint32_t> step_off, step_ids, reach_off, reach_ent;
+    std::vector<uint32_t> step_off, step_ids, reach_off, reach_ent, rule_cache;
     DevTables scalars;                      // scalar members filled, pointer members null
     // host-side facts
     std::vector<std::string> strings;       // UTF-8 text per interned id

@@ -16,6 +16,12 @@
 
 using namespace tp;
 
+static const uint8_t* cls_table() {
+    struct Tab { uint8_t v[256]; Tab() { for (uint32_t i = 0; i < 256; ++i) v[i] = byte_class(i); } };
+    static const Tab tab;                                          // initialised once, thread-safe
+    return tab.v;
+}
+
 namespace {
 thread_local std::string g_err;
 
@@ -181,12 +187,19 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
         uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
         bool ok = t.fast_ok && len <= FAST_LINE_MAX;
         if (ok) {
-            sh.run([&](int lane) {
-                emu::Wave w{&sh, (uint32_t)lane};
-                done[lane] = fast_file(w, t, lds, text, len, outs[lane], fin32.data(), t.fired_words ? &o->fired[f * t.fired_words] : nullptr,
-                                       t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
-            });
-            for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the fast-path verdict"; }
+            // first stage (one element per lane), then the second (two per lane) for what the first declines
+            for (int stage = 1; stage <= 2; ++stage) {
+                std::memset(&lds, 0xCD, sizeof lds);
+                sh.run([&](int lane) {
+                    emu::Wave w{&sh, (uint32_t)lane};
+                    uint32_t* fired = t.fired_words ? &o->fired[f * t.fired_words] : nullptr;
+                    uint16_t* facets = t.n_facets ? &o->facets[f * t.n_facets] : nullptr;
+                    done[lane] = stage == 1 ? fast_file<1, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), fired, facets)
+                                            : fast_file<2, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), fired, facets);
+                });
+                for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the fast-path verdict"; }
+                if (done[0]) break;
+            }
             ok = done[0];
         }
         size_t before = o->captions.size();
