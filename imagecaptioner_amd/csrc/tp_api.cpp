@@ -444,6 +444,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.ht_info = upload(c->table_mem, h.ht_info);
         d.str_words = upload(c->table_mem, h.str_words);
         d.rc = upload(c->table_mem, h.rule_cache);
+        d.slots = upload(c->table_mem, h.slots);
         d.step_off = upload(c->table_mem, h.step_off);
         d.step_ids = upload(c->table_mem, h.step_ids);
         d.reach_off = upload(c->table_mem, h.reach_off);

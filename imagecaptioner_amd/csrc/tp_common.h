@@ -54,6 +54,7 @@ enum : uint32_t {
     FL_NFOOTJOB = 1u << 20,
     FL_NEXT_BLANK = 1u << 21,  // NormalizeTag(it) is blank
     FL_PREFIX = 1u << 22,      // it is one of the tags SelectTags adds before the candidates (trigger, 1girl, always-add)
+    FL_REACH2 = 1u << 23,      // the closure of {it} holds nothing beyond its at most two steps; Rec::s0_info / s1_info describe them
 };
 enum Bucket : uint32_t { B_IDENTITY = 0, B_FACE = 1, B_OUTFIT = 2, B_POSE = 3, B_BACKGROUND = 4, B_STYLE = 5, B_OTHER = 6 };
 TP_HD uint32_t fl_bucket(uint32_t f) { return (f & FL_BUCKET_MASK) >> FL_BUCKET_SHIFT; }
@@ -111,11 +112,26 @@ struct DRule { uint32_t parent_id, all_off, all_cnt, any_off, any_cnt, forb_off,
 struct DSub { uint32_t tag_id, any_off, any_cnt, all_off, all_cnt; };                                            // ActionSubtypeRule / FacetRule, :130-131
 struct DFacet { uint32_t def_id, rule_off, rule_cnt; };                                                          // RequiredFacet, :132
 
-// Per-string record for the wave-per-file kernel: everything one NormalizeTag hop needs, in one 16-byte load.
-struct Rec {
+// Per-string record for the wave-per-file kernel: everything one NormalizeTag hop needs, one cache line.
+struct alignas(64) Rec {
     uint32_t flags, next, lit, len;
     uint32_t step_off, step_cnt, step0, step1;   // its ExpandImpliedTags step list (DevTables::step_ids), the first two entries inline
+    uint32_t s0_info, s1_info;                   // with FL_REACH2: literal index (24 bits, 0xFFFFFF = none) | FL_NFEET-ness << 24 | FL_NPENIS-ness << 25 of step0 / step1
+    uint32_t pad[6];
 };
+// One slot of the wave-per-file kernel's lookup table, two cache lines: a normalised token (key, up to 32 bytes inline) ->
+// the string NormalizeTag makes of it (val) and that string's record, so that a hit needs no second dependent load.
+// The table has the slots of DevTables::ht_hash (same index = same entry).
+struct alignas(128) Slot {
+    uint32_t hash;       // high half of the entry's 64-bit hash
+    uint32_t slen;       // key length in bytes; SLOT_EMPTY in an unused slot
+    uint32_t val;        // id of the alias lookup's result
+    uint32_t woff;       // the key's words in DevTables::str_words (keys longer than 32 bytes are compared there)
+    uint32_t key[8];     // the key's first 32 bytes, zero padded
+    uint32_t pad[4];
+    Rec rec;             // DevTables::rec[val]
+};
+constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
 // Hash-table payload: what the alias lookup makes of the string in this slot, and where its bytes are (to verify a probe).
 struct HtInfo { uint32_t val, woff, slen, pad; };   // woff: first 8-byte word of the string in DevTables::str_words
 
@@ -172,6 +188,7 @@ struct DevTables {
     uint32_t newline_len; uint8_t newline[4];
     // extra tables of the wave-per-file kernel
     const Rec* rec;              // n_strings
+    const Slot* slots;           // ht_mask + 1
     const HtInfo* ht_info;       // per hash slot
     const uint64_t* str_words;   // every string again as zero-padded little-endian 8-byte words, for word-wise probe verification
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:

@@ -13,7 +13,7 @@
 // Both kernels restate the same reference span (Program.cs:223-229, 292-329, 574-605) and must give identical
 // results; citations below name the reference lines each step stands for.
 //
-// All wave collectives (ballot / shfl / sync) are executed in wave-uniform control flow: every branch around one
+// All wave collectives (ballot / bcast / sum / sync) are executed in wave-uniform control flow: every branch around one
 // depends only on ballot results or kernel arguments.  `W` supplies the collectives: hardware intrinsics on the GPU,
 // a lock-step emulation in the host-side logic test.
 #pragma once
@@ -149,11 +149,6 @@ TP_HD uint64_t word_mask(uint32_t n, uint32_t k) {
     return rem == 8 ? ~0ull : ((1ull << (8 * rem)) - 1);
 }
 
-template <class W>
-TP_HD uint32_t wave_sum(W& w, uint32_t v) {
-    for (uint32_t d = 32; d >= 1; d >>= 1) v += w.shfl(v, w.lane() ^ d);
-    return v;
-}
 
 // ---- LDS hash set: key -> smallest order value seen ---------------------------------------------------------------
 template <class W>
@@ -209,23 +204,19 @@ TP_HD bool lds_match(const uint8_t* s, uint32_t pos, uint32_t end, const char* p
     return true;
 }
 
-// Hash-table lookup of a normalised string of n <= 32 bytes given as zero-padded little-endian words.
-TP_HD uint32_t ht_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3) {
+// Lookup of a normalised string of n <= 32 bytes, given as zero-padded little-endian words, in the slot table: both cache
+// lines of the first slot are fetched at once, so a first-probe hit costs one memory round trip and brings the record along.
+TP_HD uint32_t slot_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, Rec& rec) {
     uint32_t slot = (uint32_t)hsh & t.ht_mask;
+    const uint32_t h32 = (uint32_t)(hsh >> 32);
     for (;;) {
-        uint64_t hh = t.ht_hash[slot];
-        if (hh == 0) return NO_ID;
-        if (hh == hsh) {
-            HtInfo info = t.ht_info[slot];
-            if (info.slen == n) {
-                const uint64_t* q = t.str_words + info.woff;     // the arena ends with three spare words
-                uint64_t d = q[0] ^ w0;
-                d |= n > 8 ? q[1] ^ w1 : 0;
-                d |= n > 16 ? q[2] ^ w2 : 0;
-                d |= n > 24 ? q[3] ^ w3 : 0;
-                if (d == 0) return info.val;
-            }
-        }
+        const Slot* sl = t.slots + slot;
+        const uint32_t hash = sl->hash, slen = sl->slen, val = sl->val;
+        uint64_t k[4];
+        __builtin_memcpy(k, sl->key, 32);
+        rec = sl->rec;
+        if (slen == SLOT_EMPTY) return NO_ID;
+        if (hash == h32 && slen == n && ((k[0] ^ w0) | (k[1] ^ w1) | (k[2] ^ w2) | (k[3] ^ w3)) == 0) return val;
         slot = (slot + 1) & t.ht_mask;
     }
 }
@@ -234,12 +225,13 @@ TP_HD uint32_t ht_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_t 
 //   returns 0: empty after trimming, skipped (Program.cs:1183-1185)
 //           1: interned, id in `out`
 //           2: not in any table
+// On a hit `rec` receives the record of `out`.
 // `special` is false when the token is known to hold nothing for the normaliser to change apart from one leading
 // white-space byte: then its bytes are the normalised string and are hashed straight from the line.  Otherwise the
 // bytes go through the byte-wise normaliser; they are packed into 8-byte words as they are produced (the first 32 bytes
 // stay in registers), so hashing costs one multiply per word and a probe hit is verified word by word against
 // DevTables::str_words.
-TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, bool special, uint32_t& out, bool& valid_dyn, uint32_t& dyn_len) {
+TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, bool special, uint32_t& out, Rec& rec, bool& valid_dyn, uint32_t& dyn_len) {
     if (!special) {
         const uint32_t i1 = i + ((uint32_t)(i < j) & ws32(s[i]));
         const uint32_t n = j - i1;
@@ -251,7 +243,7 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
             h = n > 8 ? hash_word(h, w1) : h;
             h = n > 16 ? hash_word(h, w2) : h;
             h = n > 24 ? hash_word(h, w3) : h;
-            uint32_t id = ht_find32(t, hash_finish(h, n), n, w0, w1, w2, w3);
+            uint32_t id = slot_find32(t, hash_finish(h, n), n, w0, w1, w2, w3, rec);
             if (id != NO_ID) { out = id; return 1; }
         }
     }
@@ -312,7 +304,7 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
                     }
                     if (same && (k & 7) && q[k >> 3] != acc) same = false;
                 }
-                if (same) { out = info.val; return 1; }
+                if (same) { out = info.val; rec = t.rec[info.val]; return 1; }
             }
         }
         slot = (slot + 1) & t.ht_mask;
@@ -407,7 +399,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         const uint32_t keep = keep4(p, len) & B4;
         const uint32_t nonws = ~class4(cls, ld32u(s + (p < len ? p : len))) & keep;      // CL_WS is bit 0
         const uint64_t m = w.ballot(nonws != 0);
-        if (m) { const uint32_t q = ctz64(m); a = base + 4 * q + (ctz32(w.shfl(nonws, q)) >> 3); blank_line = false; break; }
+        if (m) { const uint32_t q = ctz64(m); a = base + 4 * q + (ctz32(w.bcast(nonws, q)) >> 3); blank_line = false; break; }
     }
     if (!blank_line) {
         for (uint32_t base = ((len - 1) >> 8) << 8;; base -= 256) {
@@ -415,7 +407,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
             const uint32_t keep = keep4(p, len) & B4;
             const uint32_t nonws = ~class4(cls, ld32u(s + (p < len ? p : len))) & keep;
             const uint64_t m = w.ballot(nonws != 0);
-            if (m) { const uint32_t q = 63 - clz64(m); b = base + 4 * q + ((31 - clz32(w.shfl(nonws, q))) >> 3) + 1; break; }
+            if (m) { const uint32_t q = 63 - clz64(m); b = base + 4 * q + ((31 - clz32(w.bcast(nonws, q))) >> 3) + 1; break; }
             if (base == 0) break;                                  // not reached: a non-blank byte exists
         }
     }
@@ -522,9 +514,9 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                     uint32_t id = NO_ID, dlen = 0;
                     bool vdyn = false;
                     const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u;
-                    int kind = fast_token(t, s, i, j, special, id, vdyn, dlen);
+                    Rec rr;
+                    int kind = fast_token(t, s, i, j, special, id, rr, vdyn, dlen);
                     if (kind == 1) {
-                        const Rec rr = t.rec[id];
                         if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) { h1[blk] = id; r1[blk] = rr; keep[blk] = true; }
                     } else if (kind == 2) {
                         // a string outside the tables: gone under strict vocabulary, too short, or invalid; anything else may survive
@@ -682,10 +674,12 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                 ev_penis |= (r2[blk].flags & FL_NPENIS) != 0;
             }
         }
+        uint64_t m_far = 0;                                        // seeds whose closure reaches beyond their own two steps
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) m_far |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_REACH2));
         if (!m_edge) {
             n_evidence = popc64(w.ballot(ev_seed[0])) + (nblk > 1 ? popc64(w.ballot(ev_seed[1])) : 0);
         } else {
-            if (!t.closure_tables) return false;
+            if (m_far && !t.closure_tables) return false;
             set_clear(w, L);
             uint32_t made = 0;
             bool full = false;
@@ -697,24 +691,29 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                 }
             }
             w.sync();
+            auto add = [&](uint32_t id, uint32_t info) {            // one member of a seed's closure
+                bool created;
+                if (set_put(w, L, id, 0, created) == NO_ID) { full = true; return; }
+                if (created) {
+                    ++made;
+                    const uint32_t li = info & 0xFFFFFFu;
+                    if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                }
+                ev_feet |= (info >> 24) & 1u;
+                ev_penis |= (info >> 25) & 1u;
+            };
             for (int blk = 0; blk < 2; ++blk) {
                 if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
-                    for (uint32_t m = t.reach_off[t2[blk]]; m < t.reach_off[t2[blk] + 1] && !full; ++m) {
-                        uint32_t id = t.reach_ent[2 * m], info = t.reach_ent[2 * m + 1];
-                        bool created;
-                        if (set_put(w, L, id, 0, created) == NO_ID) { full = true; break; }
-                        if (created) {
-                            ++made;
-                            uint32_t li = info & 0xFFFFFFu;
-                            if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
-                        }
-                        ev_feet |= (info >> 24) & 1u;
-                        ev_penis |= (info >> 25) & 1u;
+                    if (r2[blk].flags & FL_REACH2) {                // the usual case: the record itself lists the closure
+                        if (r2[blk].step_cnt > 0) add(r2[blk].step0, r2[blk].s0_info);
+                        if (r2[blk].step_cnt > 1) add(r2[blk].step1, r2[blk].s1_info);
+                    } else {
+                        for (uint32_t m = t.reach_off[t2[blk]]; m < t.reach_off[t2[blk] + 1] && !full; ++m) add(t.reach_ent[2 * m], t.reach_ent[2 * m + 1]);
                     }
                 }
             }
             if (w.ballot(full)) return false;
-            n_evidence = wave_sum(w, made);
+            n_evidence = w.sum(made);
             if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
         }
         ev_feet = w.ballot(ev_feet) != 0;
@@ -760,7 +759,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                     while (m) {
                         const uint32_t q = ctz64(m);
                         m &= m - 1;
-                        const uint32_t cnt = w.shfl(sc[blk], q), off = w.shfl(so[blk], q), a0 = w.shfl(sid[blk][0], q), a1 = w.shfl(sid[blk][1], q);
+                        const uint32_t cnt = w.bcast(sc[blk], q), off = w.bcast(so[blk], q), a0 = w.bcast(sid[blk][0], q), a1 = w.bcast(sid[blk][1], q);
                         for (uint32_t k = 0; k < cnt; ++k) {
                             const uint32_t x = k == 0 ? a0 : (k == 1 ? a1 : t.step_ids[off + k]);
                             if (!fin_append(w, L, own0, own1, nf, x, true, FIN_MAX)) return false;
@@ -942,7 +941,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     {
         uint64_t ms0 = w.ballot(safe[0]), ms1 = NF > 1 ? w.ballot(safe[1]) : 0;
         if (t.safe_mode && (ms0 | ms1)) {                          // first final tag in SafeModeRejectTags (Program.cs:942-945)
-            uint32_t v = ms0 ? w.shfl(safe_idx[0], ctz64(ms0)) : w.shfl(safe_idx[1], ctz64(ms1));
+            uint32_t v = ms0 ? w.bcast(safe_idx[0], ctz64(ms0)) : w.bcast(safe_idx[1], ctz64(ms1));
             safe_hit = (int)v;
             flags |= TP_F_SAFE_REJECT;
         }
@@ -954,7 +953,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     const uint64_t mc0 = w.ballot(keepc[0]), mc1 = NF > 1 ? w.ballot(keepc[1]) : 0;
     const uint32_t nc = popc64(mc0) + popc64(mc1);
     uint32_t bytes = (keepc[0] ? clen[0] : 0) + (keepc[1] ? clen[1] : 0);
-    bytes = wave_sum(w, bytes);
+    bytes = w.sum(bytes);
     const uint32_t unknown = t.known_active ? popc64(w.ballot(keepc[0] && !cknown[0])) + (NF > 1 ? popc64(w.ballot(keepc[1] && !cknown[1])) : 0) : 0;
     const bool footjob = w.ballot((keepc[0] && c[0] == t.footjob_n) || (keepc[1] && c[1] == t.footjob_n)) != 0;   // HasTag(finalTags, "footjob"), Program.cs:311
     w.sync();

@@ -30,6 +30,17 @@ namespace tp {
 __device__ unsigned long long g_prof[32];   // cycles per pipeline section, summed over wavefronts (diagnostic builds only)
 #endif
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (no LDS traffic).
+__device__ inline uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 struct DevWave {
 #ifdef TP_PROF
     uint64_t last = 0, acc[16] = {0};
@@ -48,6 +59,10 @@ struct DevWave {
     __device__ uint64_t ballot(bool p) const { return __ballot(p ? 1 : 0); }
     // how many set bits of m belong to lanes below this one
     __device__ uint32_t rank(uint64_t m) const { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+    // the value lane `src` holds; src is the same in every lane
+    __device__ uint32_t bcast(uint32_t v, uint32_t src) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)src)); }
+    // the sum over all lanes, in every lane
+    __device__ uint32_t sum(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63); }
     __device__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)(src & 63u), 64); }
     // Orders the wave's own LDS traffic (each wavefront owns its LDS state): LDS instructions of one wave execute in
     // order, so wavefront scope is enough and, unlike a wider scope, does not wait for outstanding global loads and stores.
@@ -262,17 +277,6 @@ constexpr uint32_t HOT_IDS = 24576;    // ids below this are counted in LDS (96 
                                        // the table compiler gives the frequent tags the low ids
 constexpr int EMIT_WAVES = 16;          // wavefronts (files in flight) per block of the staged emit kernel, one block per CU
 constexpr uint32_t EMIT_STAGE = FAST_CAPTION_MAX;   // captions are put together in LDS and stored 16 bytes per lane
-
-// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (no LDS traffic).
-__device__ inline uint32_t wave_scan_incl(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
 
 struct EmitCounts {
     uint64_t files = 0, low = 0, elig = 0, foot = 0, fb = 0, rej = 0, uns = 0, safe = 0;

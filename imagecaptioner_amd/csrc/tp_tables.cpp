@@ -1022,9 +1022,26 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     if (out.reach_ent.empty()) { out.reach_ent.push_back(0); out.reach_ent.push_back(0); }
     out.rec.resize(N);
     for (uint32_t i = 0; i < N; ++i) {
-        uint32_t so = out.step_off[i], sc = out.step_off[i + 1] - so;
-        out.rec[i] = Rec{out.flags[i], out.next[i], out.lit[i], out.str_off[i + 1] - out.str_off[i], so, sc,
-                         sc > 0 ? out.step_ids[so] : NO_ID, sc > 1 ? out.step_ids[so + 1] : NO_ID};
+        uint32_t so = out.step_off[i], scnt = out.step_off[i + 1] - so;
+        Rec r{};
+        r.flags = out.flags[i]; r.next = out.next[i]; r.lit = out.lit[i]; r.len = out.str_off[i + 1] - out.str_off[i];
+        r.step_off = so; r.step_cnt = scnt;
+        r.step0 = scnt > 0 ? out.step_ids[so] : NO_ID;
+        r.step1 = scnt > 1 ? out.step_ids[so + 1] : NO_ID;
+        r.s0_info = r.s1_info = 0xFFFFFFu;
+        // FL_REACH2: the reach list is exactly the (at most two) steps, i.e. the steps lead nowhere further
+        const uint32_t ro = out.reach_off[i], rn = out.reach_off[i + 1] - ro;
+        if (sc.closure_tables && (out.flags[i] & FL_EDGE) && scnt <= 2 && rn == scnt) {
+            bool same = true;
+            for (uint32_t k = 0; k < scnt; ++k) if (out.reach_ent[2 * (ro + k)] != out.step_ids[so + k]) same = false;
+            if (same) {
+                r.flags |= FL_REACH2;
+                out.flags[i] |= FL_REACH2;
+                if (scnt > 0) r.s0_info = out.reach_ent[2 * ro + 1];
+                if (scnt > 1) r.s1_info = out.reach_ent[2 * (ro + 1) + 1];
+            }
+        }
+        out.rec[i] = r;
     }
     std::vector<uint32_t> word_off(N);
     out.str_words.clear();
@@ -1039,10 +1056,20 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     }
     for (int k = 0; k < 4; ++k) out.str_words.push_back(0);   // lookups compare four words at a time, whatever the string's length
     out.ht_info.assign(slots, HtInfo{0, 0, 0, 0});
+    out.slots.assign(slots, Slot{});
     for (uint32_t s = 0; s < slots; ++s) {
+        Slot& sl = out.slots[s];
+        sl.slen = SLOT_EMPTY;
         if (!out.ht_hash[s]) continue;
         uint32_t id = out.ht_id[s];
         out.ht_info[s] = HtInfo{out.alias1[id], word_off[id], out.str_off[id + 1] - out.str_off[id], 0};
+        sl.hash = (uint32_t)(out.ht_hash[s] >> 32);
+        sl.slen = out.str_off[id + 1] - out.str_off[id];
+        sl.val = out.alias1[id];
+        sl.woff = word_off[id];
+        const std::string& str = out.strings[id];
+        for (size_t b = 0; b < str.size() && b < 32; ++b) sl.key[b >> 2] |= (uint32_t)(unsigned char)str[b] << (8 * (b & 3));
+        sl.rec = out.rec[sl.val];
     }
     // rule cache
     bool rc_ok = true;
@@ -1145,6 +1172,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.ht_info = ht.ht_info.data();
     t.str_words = ht.str_words.data();
     t.rc = ht.rule_cache.data();
+    t.slots = ht.slots.data();
     t.step_off = ht.step_off.data();
     t.step_ids = ht.step_ids.data();
     t.reach_off = ht.reach_off.data();

@@ -29,6 +29,7 @@ struct HostTables {
     std::vector<DFacet> facets;
     std::vector<DSub> facet_rules;
     std::vector<Rec> rec;
+    std::vector<Slot> slots;
     std::vector<HtInfo> ht_info;
     std::vector<uint64_t> str_words;
     std::vector<uint32_t> step_off, step_ids, reach_off, reach_ent, rule_cache;
