@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--files", type=int, default=1_000_000, help="files per GPU")
     ap.add_argument("--config", default="c2", help="corpus configuration: c1..c5")
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--cpu-sample", type=int, default=40_000, help="files of the same corpus timed on the host cores (rank 0, 1 GPU only); 0 = skip")
+    ap.add_argument("--cpu-sample", type=int, default=300_000, help="files of the same corpus timed on the host cores (rank 0, 1 GPU only); 0 = skip")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     args = ap.parse_args()
