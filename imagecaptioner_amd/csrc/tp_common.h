@@ -55,6 +55,8 @@ enum : uint32_t {
     FL_NEXT_BLANK = 1u << 21,  // NormalizeTag(it) is blank
     FL_PREFIX = 1u << 22,      // it is one of the tags SelectTags adds before the candidates (trigger, 1girl, always-add)
     FL_REACH2 = 1u << 23,      // the closure of {it} holds nothing beyond its at most two steps; Rec::s0_info / s1_info describe them
+    FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone and that has no steps of
+                               // its own: one ExpandImpliedTags round settles it; Rec::s0_flags .. s1_len describe the steps
 };
 enum Bucket : uint32_t { B_IDENTITY = 0, B_FACE = 1, B_OUTFIT = 2, B_POSE = 3, B_BACKGROUND = 4, B_STYLE = 5, B_OTHER = 6 };
 TP_HD uint32_t fl_bucket(uint32_t f) { return (f & FL_BUCKET_MASK) >> FL_BUCKET_SHIFT; }
@@ -117,7 +119,8 @@ struct alignas(64) Rec {
     uint32_t flags, next, lit, len;
     uint32_t step_off, step_cnt, step0, step1;   // its ExpandImpliedTags step list (DevTables::step_ids), the first two entries inline
     uint32_t s0_info, s1_info;                   // with FL_REACH2: literal index (24 bits, 0xFFFFFF = none) | FL_NFEET-ness << 24 | FL_NPENIS-ness << 25 of step0 / step1
-    uint32_t pad[6];
+    uint32_t s0_flags, s0_len, s1_flags, s1_len; // with FL_LEAF2: flags and byte length of step0 / step1
+    uint32_t pad[2];
 };
 // One slot of the wave-per-file kernel's lookup table, two cache lines: a normalised token (key, up to 32 bytes inline) ->
 // the string NormalizeTag makes of it (val) and that string's record, so that a hit needs no second dependent load.
@@ -140,7 +143,8 @@ constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
 constexpr int MAX_TOTAL_TAGS = 42;        // Program.cs:38
 constexpr int MAX_ALWAYS_ADD = 64;
 constexpr int MAX_FALLBACK = MAX_TOTAL_TAGS;
-constexpr uint32_t RC_REC_WORDS = 8;
+constexpr uint32_t RC_REC_WORDS = 10;
+constexpr uint32_t RC_FACET_WORDS = 6;
 constexpr uint32_t FAST_RC_MAX_WORDS = 8192;   // 32 KB of LDS per block at most
 constexpr uint32_t FAST_FRULES_MAX = 512;      // facet rules the wave-per-file kernel keeps one hit bit each for
 
@@ -204,11 +208,14 @@ struct DevTables {
     // Line ingest scores fall with the candidate index (Program.cs:581), so score tests are index tests:
     // Rule cache of the wave-per-file kernel (copied to LDS by every block): action rules, subtypes and facet rules as
     // RC_REC_WORDS-word records {tag id, first subtype (rules), all_cnt | any_cnt << 8 | forbidden_cnt << 16,
-    // literal list offset in the cache | subtype count << 16, four literals inline (all, any, forbidden in this order; the
-    // offset is used when there are more)}, then facets as 4-word records {default id, first facet rule, rule count, 0},
-    // then the longer literal lists.
+    // literal list offset in the cache (15 bits) | 0x8000 when NormalizeTag does not leave the tag alone | subtype count << 16,
+    // four literals inline (all, any, forbidden in this order; the offset is used when there are more), the tag's flags, its
+    // byte length}, then facets as RC_FACET_WORDS-word records {default id, first facet rule, rule count, the default's flags,
+    // its byte length, 1 when NormalizeTag does not leave the default alone}, then the longer literal lists.
     const uint32_t* rc;
     uint32_t rc_words, rc_subs, rc_frules, rc_facets, n_frules;
+    uint32_t prefix_simple;      // the same for the prefix tags, and none of them has steps
+    uint32_t prefix_flags[MAX_TOTAL_TAGS], prefix_len[MAX_TOTAL_TAGS];   // flags and byte length per prefix tag
     uint32_t seed_ci_limit;      // candidates below this index have !(score < 0.28)  (BuildEvidenceTags, Program.cs:724)
     uint32_t style_ci_limit;     // candidates below this index have score >= 0.60     (DetermineStyleQualityCap, Program.cs:706)
 };

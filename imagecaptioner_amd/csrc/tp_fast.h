@@ -56,8 +56,9 @@ struct alignas(16) FastLds {
     uint8_t line[FAST_LINE_MAX + 64];    // 16 spare bytes in front (the byte before the line is read), the line at its 16-byte phase, tail padding
     uint16_t cpos[FAST_TOK_MAX];
     uint32_t tspec[FAST_TOK_MAX / 32];   // bit k: token k holds a byte that needs the byte-wise normaliser
-    uint32_t cand[FAST_TOK_MAX];
     uint32_t fin[FAST_FIN_MAX];
+    uint32_t fattr[FAST_FIN_MAX];          // flags of fin[k] (files on the settled-tags path)
+    uint32_t flen[FAST_FIN_MAX];           // byte length of fin[k]
     uint32_t set_key[FAST_SET_SLOTS];
     uint32_t set_min[FAST_SET_SLOTS];
     uint32_t ebits[FAST_LIT_WORDS];
@@ -335,7 +336,7 @@ TP_HD bool f_match_sub(const DevTables& t, const FastLds& L, const DSub& r) {
 TP_HD bool rc_match(const FastLds& L, const uint32_t* rc, uint32_t rec) {
     const uint32_t* r = rc + rec;
     const uint32_t cnts = r[2], n_all = cnts & 255u, n_any = (cnts >> 8) & 255u, n_forb = (cnts >> 16) & 255u, tot = n_all + n_any + n_forb;
-    const uint32_t* lits = tot <= 4 ? r + 4 : rc + (r[3] & 0xFFFFu);
+    const uint32_t* lits = tot <= 4 ? r + 4 : rc + (r[3] & 0x7FFFu);
     bool ok_all = true, ok_any = n_any == 0, ok_forb = true;
     for (uint32_t i = 0; i < tot; ++i) {
         const bool bit = fbit(L, lits[i]);
@@ -350,13 +351,16 @@ TP_HD bool rc_match(const FastLds& L, const uint32_t* rc, uint32_t rec) {
 // Wave-uniform: `id`, `nf` and the return value are the same in every lane.  Returns false on overflow.
 // With in_set the LDS set (which then holds every element of the list with order 0) learns the new element too.
 template <class W>
-TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id, bool in_set, uint32_t fin_max) {
+TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id, bool in_set, uint32_t fin_max, uint32_t attr = 0,
+                      uint32_t len = 0) {
     if (w.ballot(own0 == id || own1 == id) != 0) return true;
     if (nf >= fin_max) return false;
     if (w.lane() == (nf & 63)) { if (nf < 64) own0 = id; else own1 = id; }
     bool full = false;
     if (w.lane() == 0) {
         L.fin[nf] = id;
+        L.fattr[nf] = attr;
+        L.flen[nf] = len;
         if (in_set) { bool created; full = set_put(w, L, id, 0, created) == NO_ID; }
     }
     ++nf;
@@ -590,6 +594,12 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         if (w.ballot((ok3[0] && !fst[0]) || (ok3[1] && !fst[1]))) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
     }
     uint32_t nr = t.n_prefix;
+    bool settled = false;
+    // per-position columns of the selected tags' implied tags; they reuse the line buffer, which is not read after S4
+    uint32_t(*kid)[64] = (uint32_t(*)[64])(L.line);
+    uint32_t(*kid_attr)[64] = kid + 2;
+    uint32_t(*kid_len)[64] = kid + 4;
+    static_assert(sizeof(L.line) >= 6 * 64 * sizeof(uint32_t), "six columns of 64 words");
     {
         const int caps[6] = {3, 10, 8, 6, 4, style_cap};
         bool taken[2] = {false, false};
@@ -607,9 +617,28 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
             if (el1 && rank1 < take) { taken[1] = true; pos[1] = nr + rank1; }
             nr += take;
         }
-        if (lane < t.n_prefix) L.fin[lane] = t.prefix_ids[lane];
-        if (taken[0]) L.fin[pos[0]] = t3[0];
-        if (taken[1]) L.fin[pos[1]] = t3[1];
+        // A file is on the settled-tags path when NormalizeTag leaves every selected tag alone and every selected tag's
+        // implied tags are settled leaves (FL_LEAF2): then flags and lengths of everything the final list can hold are known
+        // from records already loaded and from the rule cache, and the rest of the pipeline needs no further table lookups.
+        bool unsettled = false;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk)
+            if (taken[blk] && (r2[blk].next != t2[blk] || ((r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_LEAF2)))) unsettled = true;
+        settled = t.prefix_simple && nr >= 3 && nr <= 64 && !w.ballot(unsettled);
+        if (settled) { kid[0][lane] = NO_ID; kid[1][lane] = NO_ID; }
+        w.sync();
+        if (lane < t.n_prefix) { L.fin[lane] = t.prefix_ids[lane]; L.fattr[lane] = t.prefix_flags[lane]; L.flen[lane] = t.prefix_len[lane]; }
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+            if (taken[blk]) {
+                const uint32_t p = pos[blk];
+                L.fin[p] = t3[blk];
+                L.fattr[p] = r2[blk].flags;
+                L.flen[p] = r2[blk].len;
+                if (settled && (r2[blk].flags & FL_EDGE)) {          // its implied tags, for the one closure round of S9
+                    if (r2[blk].step_cnt > 0) { kid[0][p] = r2[blk].step0; kid_attr[0][p] = r2[blk].s0_flags; kid_len[0][p] = r2[blk].s0_len; }
+                    if (r2[blk].step_cnt > 1) { kid[1][p] = r2[blk].step1; kid_attr[1][p] = r2[blk].s1_flags; kid_len[1][p] = r2[blk].s1_len; }
+                }
+            }
+        }
         w.sync();
     }
     const uint32_t n_selected = nr;
@@ -623,11 +652,15 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     {
         const bool in = lane < nr;
         const uint32_t r = in ? L.fin[lane] : EMPTY_ID;
-        Rec rr = t.rec[r];
-        const uint32_t t4 = rr.next;
-        const uint64_t m_hop4 = w.ballot(in && t4 != r);
-        uint32_t f4 = rr.flags;
-        if (m_hop4 && in && t4 != r) f4 = t.rec[t4].flags;
+        uint32_t t4 = r, f4 = in ? L.fattr[lane] : (uint32_t)FL_BLANK;
+        uint64_t m_hop4 = 0;
+        if (!settled) {
+            Rec rr = t.rec[r];
+            t4 = rr.next;
+            m_hop4 = w.ballot(in && t4 != r);
+            f4 = rr.flags;
+            if (m_hop4 && in && t4 != r) f4 = t.rec[t4].flags;
+        }
         const bool nb4 = in && !(f4 & FL_BLANK);
         const bool has_trigger = w.ballot(nb4 && t4 == t.trigger_id) != 0, has_girl = w.ballot(nb4 && t4 == t.girl_lit_id) != 0;
         coverage = ((has_trigger && has_girl) ? TP_COV_IDENTITY : 0) | (w.ballot(nb4 && (f4 & FL_HAIR)) ? TP_COV_HAIR : 0) |
@@ -729,7 +762,34 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     // set under the key (element index, step index); the smallest key of an id new to the set wins, and a winner's place
     // in the list is the number of winners with smaller keys.  From here to S11 the set holds the list's elements.
     uint32_t gnext[2] = {EMPTY_ID, EMPTY_ID}, gflags[2] = {0, 0};   // NormalizeTag and flags of the entries this lane owns, read once here
-    {
+    if (settled) {
+        // One round settles it: the implied tags of the selected tags (read from the per-position columns written in S6) are
+        // offered to the set under the key (position, first or second); winners are appended in key order with their flags
+        // and lengths; nothing appended has steps of its own.
+        set_clear(w, L);
+        if (lane < nf) { bool created; set_put(w, L, own0, 0, created); }
+        w.sync();
+        uint32_t k_id[2] = {NO_ID, NO_ID}, slot[2] = {NO_ID, NO_ID};
+        bool full = false;
+        if (lane < nf) { k_id[0] = kid[0][lane]; k_id[1] = kid[1][lane]; }
+        for (uint32_t j = 0; j < 2; ++j)
+            if (k_id[j] != NO_ID) { bool created; slot[j] = set_put(w, L, k_id[j], 1 + ((lane << 1) | j), created); if (slot[j] == NO_ID) full = true; }
+        w.sync();
+        if (w.ballot(full)) return false;
+        bool win[2];
+        for (uint32_t j = 0; j < 2; ++j) win[j] = slot[j] != NO_ID && L.set_min[slot[j]] == 1 + ((lane << 1) | j);
+        const uint64_t mw0 = w.ballot(win[0]), mw1 = w.ballot(win[1]);
+        const uint32_t grown = popc64(mw0) + popc64(mw1);
+        if (nf + grown > FIN_MAX) return false;
+        uint32_t p = nf + w.rank(mw0) + w.rank(mw1);
+        if (win[0]) { L.fin[p] = k_id[0]; L.fattr[p] = kid_attr[0][lane]; L.flen[p] = kid_len[0][lane]; L.set_min[slot[0]] = 0; ++p; }
+        if (win[1]) { L.fin[p] = k_id[1]; L.fattr[p] = kid_attr[1][lane]; L.flen[p] = kid_len[1][lane]; L.set_min[slot[1]] = 0; }
+        nf += grown;
+        w.sync();
+        own0 = lane < nf ? L.fin[lane] : NO_ID;
+        own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
+        gnext[0] = own0; gnext[1] = own1;                          // NormalizeTag leaves every element alone
+    } else {
         set_clear(w, L);
         if (lane < nf) { bool created; set_put(w, L, own0, 0, created); }   // nf <= 64 here, and 256 slots cannot fill up
         w.sync();
@@ -813,15 +873,16 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         uint32_t g[2] = {EMPTY_ID, EMPTY_ID};
         bool nb[2] = {false, false};
         bool changed = false;
-        for (int blk = 0; blk < NF; ++blk) {
-            uint32_t idx = (uint32_t)blk * 64 + lane;
-            uint32_t id = blk == 0 ? own0 : own1;
-            bool in = idx < nf;
-            g[blk] = gnext[blk];
-            nb[blk] = in && !(gflags[blk] & FL_NEXT_BLANK);
-            if (in && (g[blk] != id || !nb[blk])) changed = true;
-        }
-        if (w.ballot(changed)) {
+        if (!settled)
+            for (int blk = 0; blk < NF; ++blk) {
+                uint32_t idx = (uint32_t)blk * 64 + lane;
+                uint32_t id = blk == 0 ? own0 : own1;
+                bool in = idx < nf;
+                g[blk] = gnext[blk];
+                nb[blk] = in && !(gflags[blk] & FL_NEXT_BLANK);
+                if (in && (g[blk] != id || !nb[blk])) changed = true;
+            }
+        if (!settled && w.ballot(changed)) {
             bool fst[2];
             if (!dedupe_first(w, L, g, nb, fst, NF)) return false;
             uint64_t m0 = w.ballot(fst[0]), m1 = NF > 1 ? w.ballot(fst[1]) : 0;
@@ -848,7 +909,8 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                 const uint32_t* rr = rc + (r0 + ctz64(m)) * RC_REC_WORDS;
                 m &= m - 1;
                 const uint32_t parent = rr[0], sub_off = rr[1], sub_cnt = rr[3] >> 16;
-                if (!fin_append(w, L, own0, own1, nf, parent, true, FIN_MAX)) return false;
+                if (rr[3] & 0x8000u) settled = false;              // a tag NormalizeTag changes joins the list: S12 looks every tag up again
+                if (!fin_append(w, L, own0, own1, nf, parent, true, FIN_MAX, rr[8], rr[9])) return false;
                 for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
                     const uint32_t si = s0 + lane;
                     const uint32_t srec = t.rc_subs + (sub_off + (si < sub_cnt ? si : 0)) * RC_REC_WORDS;
@@ -861,7 +923,9 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                     while (ms) {
                         const uint32_t qs = ctz64(ms);
                         ms &= ms - 1;
-                        if (!fin_append(w, L, own0, own1, nf, rc[t.rc_subs + (sub_off + s0 + qs) * RC_REC_WORDS], true, FIN_MAX)) return false;
+                        const uint32_t* sr = rc + t.rc_subs + (sub_off + s0 + qs) * RC_REC_WORDS;
+                        if (sr[3] & 0x8000u) settled = false;
+                        if (!fin_append(w, L, own0, own1, nf, sr[0], true, FIN_MAX, sr[8], sr[9])) return false;
                     }
                 }
             }
@@ -879,15 +943,21 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     w.sync();
     for (uint32_t f0 = 0; f0 < t.n_facets; f0 += 64) {
         const uint32_t f = f0 + lane;
-        uint32_t selected = NO_ID;
+        uint32_t selected = NO_ID, sel_attr = 0, sel_len = 0;
+        bool sel_changes = false;                                  // NormalizeTag does not leave the chosen tag alone
         if (f < t.n_facets) {
-            const uint32_t* fr = rc + t.rc_facets + 4 * f;
+            const uint32_t* fr = rc + t.rc_facets + RC_FACET_WORDS * f;
             const uint32_t rule_off = fr[1], rule_cnt = fr[2];
-            selected = fr[0];
+            selected = fr[0]; sel_attr = fr[3]; sel_len = fr[4]; sel_changes = fr[5] != 0;
             uint16_t choice = 0xFFFF;
             for (uint32_t r = 0; r < rule_cnt; ++r) {
                 const uint32_t p = rule_off + r;
-                if ((L.fhit[p >> 5] >> (p & 31)) & 1u) { selected = rc[t.rc_frules + p * RC_REC_WORDS]; choice = (uint16_t)r; break; }
+                if ((L.fhit[p >> 5] >> (p & 31)) & 1u) {
+                    const uint32_t* pr = rc + t.rc_frules + p * RC_REC_WORDS;
+                    selected = pr[0]; sel_attr = pr[8]; sel_len = pr[9]; sel_changes = (pr[3] & 0x8000u) != 0;
+                    choice = (uint16_t)r;
+                    break;
+                }
             }
             if (facet_choice) facet_choice[f] = choice;
         }
@@ -900,8 +970,9 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         if (w.ballot(full)) return false;
         const bool win = slot != NO_ID && L.set_min[slot] == 1 + lane;
         const uint64_t mw = w.ballot(win);
+        if (w.ballot(win && sel_changes)) settled = false;
         if (nf + popc64(mw) > FIN_MAX) return false;
-        if (win) { L.fin[nf + w.rank(mw)] = selected; L.set_min[slot] = 0; }
+        if (win) { const uint32_t p = nf + w.rank(mw); L.fin[p] = selected; L.fattr[p] = sel_attr; L.flen[p] = sel_len; L.set_min[slot] = 0; }
         nf += popc64(mw);
         w.sync();
         own0 = lane < nf ? L.fin[lane] : NO_ID;
@@ -921,20 +992,29 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         uint32_t idx = (uint32_t)blk * 64 + lane;
         uint32_t id = blk == 0 ? own0 : own1;
         bool in = idx < nf;
-        Rec rr = t.rec[in ? id : EMPTY_ID];
+        uint32_t fl, cfl;                                          // flags of the tag and of what NormalizeTag makes of it
+        if (settled) {                                             // ... which is the tag itself; flags and length sit in the list's columns
+            fl = cfl = in ? L.fattr[idx] : (uint32_t)FL_BLANK;
+            c[blk] = in ? id : EMPTY_ID;
+            clen[blk] = in ? L.flen[idx] : 0;
+        } else {
+            Rec rr = t.rec[in ? id : EMPTY_ID];
+            fl = rr.flags;
+            c[blk] = rr.next;
+            Rec rn = rr;
+            if (in && c[blk] != id) { rn = t.rec[c[blk]]; changed = true; }
+            cfl = rn.flags;
+            clen[blk] = rn.len;
+        }
         if (in) {
-            uint32_t bk = fl_bucket(rr.flags);
+            uint32_t bk = fl_bucket(fl);
             face |= bk == B_FACE;                                  // MissingCoreBuckets, Program.cs:1097-1101
             outfit |= bk == B_OUTFIT;
-            if (rr.flags & FL_SAFE) { safe[blk] = true; safe_idx[blk] = (rr.flags >> FL_SAFE_IDX_SHIFT) & 31; }
+            if (fl & FL_SAFE) { safe[blk] = true; safe_idx[blk] = (fl >> FL_SAFE_IDX_SHIFT) & 31; }
         }
-        c[blk] = rr.next;
-        Rec rc = rr;
-        if (in && c[blk] != id) { rc = t.rec[c[blk]]; changed = true; }
-        cnb[blk] = in && !(rc.flags & FL_BLANK);
+        cnb[blk] = in && !(cfl & FL_BLANK);
         if (in && !cnb[blk]) changed = true;
-        clen[blk] = rc.len;
-        cknown[blk] = (rc.flags & FL_KNOWN) != 0;
+        cknown[blk] = (cfl & FL_KNOWN) != 0;
     }
     if (!(w.ballot(face) && w.ballot(outfit))) flags |= TP_F_LOW;
     int safe_hit = -1;

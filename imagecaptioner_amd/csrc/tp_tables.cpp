@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -1039,6 +1041,17 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
                 out.flags[i] |= FL_REACH2;
                 if (scnt > 0) r.s0_info = out.reach_ent[2 * ro + 1];
                 if (scnt > 1) r.s1_info = out.reach_ent[2 * (ro + 1) + 1];
+                bool leaf = true;
+                for (uint32_t k = 0; k < scnt; ++k) {
+                    const uint32_t y = out.step_ids[so + k];
+                    if (out.next[y] != y || (out.flags[y] & (FL_BLANK | FL_EDGE))) leaf = false;
+                }
+                if (leaf) {
+                    r.flags |= FL_LEAF2;
+                    out.flags[i] |= FL_LEAF2;
+                    if (scnt > 0) { r.s0_flags = out.flags[r.step0]; r.s0_len = out.str_off[r.step0 + 1] - out.str_off[r.step0]; }
+                    if (scnt > 1) { r.s1_flags = out.flags[r.step1]; r.s1_len = out.str_off[r.step1 + 1] - out.str_off[r.step1]; }
+                }
             }
         }
         out.rec[i] = r;
@@ -1088,6 +1101,9 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             rc[base + 1] = w1;
             rc[base + 2] = (all_cnt & 255) | ((any_cnt & 255) << 8) | ((forb_cnt & 255) << 16);
             rc[base + 3] = sub_cnt << 16;
+            rc[base + 8] = out.flags[tag];
+            rc[base + 9] = out.str_off[tag + 1] - out.str_off[tag];
+            if (out.next[tag] != tag || (out.flags[tag] & FL_BLANK)) rc[base + 3] |= 0x8000u;   // NormalizeTag does not leave this tag alone
             std::vector<uint32_t> lits;
             for (uint32_t k = 0; k < all_cnt; ++k) lits.push_back(out.pool[all_off + k]);
             for (uint32_t k = 0; k < any_cnt; ++k) lits.push_back(out.pool[any_off + k]);
@@ -1119,14 +1135,30 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         sc.n_frules = n_frules;
         sc.rc_facets = (uint32_t)rc.size();
         for (uint32_t f = 0; f < n_facets; ++f) {
-            rc.push_back(out.facets[f].def_id); rc.push_back(out.facets[f].rule_off); rc.push_back(out.facets[f].rule_cnt); rc.push_back(0);
+            const uint32_t d = out.facets[f].def_id;
+            rc.push_back(d); rc.push_back(out.facets[f].rule_off); rc.push_back(out.facets[f].rule_cnt);
+            rc.push_back(out.flags[d]); rc.push_back(out.str_off[d + 1] - out.str_off[d]);
+            rc.push_back((out.next[d] != d || (out.flags[d] & FL_BLANK)) ? 1u : 0u);
         }
         const uint32_t tail_base = (uint32_t)rc.size();
-        for (const Fix& fx : fixes) rc[fx.word] |= (tail_base + fx.tail_off) & 0xFFFFu;
+        for (const Fix& fx : fixes) rc[fx.word] |= (tail_base + fx.tail_off) & 0x7FFFu;
         rc.insert(rc.end(), tail.begin(), tail.end());
         if (rc.empty()) rc.push_back(0);
         sc.rc_words = (uint32_t)rc.size();
-        if (sc.rc_words > FAST_RC_MAX_WORDS || sc.rc_words > 0xFFFFu || n_frules > FAST_FRULES_MAX) rc_ok = false;
+        sc.prefix_simple = 1;
+        for (uint32_t k = 0; k < sc.n_prefix; ++k) {
+            const uint32_t id = sc.prefix_ids[k];
+            sc.prefix_flags[k] = out.flags[id];
+            sc.prefix_len[k] = out.str_off[id + 1] - out.str_off[id];
+            if (out.next[id] != id || (out.flags[id] & (FL_BLANK | FL_EDGE))) sc.prefix_simple = 0;
+        }
+        if (std::getenv("TAGPIPE_DEBUG_TABLES")) {
+            uint32_t n_edge = 0, n_leaf = 0, n_reach2 = 0;
+            for (uint32_t i = 0; i < N; ++i) { n_edge += (out.flags[i] & FL_EDGE) != 0; n_leaf += (out.flags[i] & FL_LEAF2) != 0; n_reach2 += (out.flags[i] & FL_REACH2) != 0; }
+            std::fprintf(stderr, "tagpipe tables: strings %u edge %u reach2 %u leaf2 %u prefix_simple %u rc_words %u\n", N, n_edge, n_reach2, n_leaf, sc.prefix_simple,
+                         sc.rc_words);
+        }
+        if (sc.rc_words > FAST_RC_MAX_WORDS || sc.rc_words > 0x7FFFu || n_frules > FAST_FRULES_MAX) rc_ok = false;
     }
     // the wave-per-file kernel keeps its literal bitset in 128 LDS words and assumes scores fall with the token index
     sc.fast_ok = (sc.lit_words <= 128 && sc.fired_words <= 64 && n_lits < 0xFFFFFFu && cfg.line_weight > 0.0 && rc_ok) ? 1 : 0;
