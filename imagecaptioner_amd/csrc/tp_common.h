@@ -214,6 +214,9 @@ struct DevTables {
     // its byte length, 1 when NormalizeTag does not leave the default alone}, then the longer literal lists.
     const uint32_t* rc;
     uint32_t rc_words, rc_subs, rc_frules, rc_facets, n_frules;
+    // Literal masks in the cache (lit_words words each): the literals action rules (facet rules) test positively.  A file whose
+    // evidence holds none of them cannot fire a rule, unless some rule has no positive literal at all (the *_vacuous flags).
+    uint32_t rc_rule_mask, rc_frule_mask, rules_vacuous, frules_vacuous;
     uint32_t prefix_simple;      // the same for the prefix tags, and none of them has steps
     uint32_t prefix_flags[MAX_TOTAL_TAGS], prefix_len[MAX_TOTAL_TAGS];   // flags and byte length per prefix tag
     uint32_t seed_ci_limit;      // candidates below this index have !(score < 0.28)  (BuildEvidenceTags, Program.cs:724)

@@ -709,8 +709,20 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         }
         uint64_t m_far = 0;                                        // seeds whose closure reaches beyond their own two steps
         TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) m_far |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_REACH2));
+        const bool count = fired != nullptr;                       // the size of the evidence set is a detail output: it takes the set to count
         if (!m_edge) {
             n_evidence = popc64(w.ballot(ev_seed[0])) + (nblk > 1 ? popc64(w.ballot(ev_seed[1])) : 0);
+        } else if (!count && !m_far) {
+            // literals and the two probes of the seeds' implied tags straight from the seeds' records
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
+                    const uint32_t i0 = r2[blk].step_cnt > 0 ? r2[blk].s0_info : 0xFFFFFFu, i1 = r2[blk].step_cnt > 1 ? r2[blk].s1_info : 0xFFFFFFu;
+                    if ((i0 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i0 & 0xFFFFFFu) >> 5], 1u << (i0 & 31));
+                    if ((i1 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i1 & 0xFFFFFFu) >> 5], 1u << (i1 & 31));
+                    ev_feet |= ((i0 | i1) >> 24) & 1u;
+                    ev_penis |= ((i0 | i1) >> 25) & 1u;
+                }
+            }
         } else {
             if (m_far && !t.closure_tables) return false;
             set_clear(w, L);
@@ -749,6 +761,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
             n_evidence = w.sum(made);
             if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
         }
+        if (!count) n_evidence = 0xFFFF;
         ev_feet = w.ballot(ev_feet) != 0;
         ev_penis = w.ballot(ev_penis) != 0;
         w.sync();
@@ -868,6 +881,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     w.tick(8);
     TP_STOP(8, own0 ^ own1 ^ nf ^ gnext[0] ^ gflags[0] ^ gnext[1] ^ gflags[1])
     // ---- S10: InferActionTags (Program.cs:731-753) ---------------------------------------------------------------------------
+    bool rules_possible = true, frules_possible = true;
     {
         // inferred = Select(NormalizeTag).Where(non-blank).Distinct()
         uint32_t g[2] = {EMPTY_ID, EMPTY_ID};
@@ -900,6 +914,16 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         }
         if (lane < t.fired_words) L.firedw[lane] = 0;
         w.sync();
+        // No rule can fire unless the evidence holds one of the literals some rule tests positively; likewise for facet rules.
+        bool lit_r = false, lit_f = false;
+        for (uint32_t k = lane; k < t.lit_words; k += 64) {
+            const uint32_t e = L.ebits[k];
+            lit_r = lit_r || (e & rc[t.rc_rule_mask + k]) != 0;
+            lit_f = lit_f || (e & rc[t.rc_frule_mask + k]) != 0;
+        }
+        rules_possible = t.rules_vacuous || w.ballot(lit_r) != 0;
+        frules_possible = t.frules_vacuous || w.ballot(lit_f) != 0;
+        if (rules_possible)
         for (uint32_t r0 = 0; r0 < t.n_rules; r0 += 64) {
             const uint32_t r = r0 + lane;
             const bool hit = r < t.n_rules && rc_match(L, rc, r * RC_REC_WORDS);                  // MatchesActionRule, Program.cs:777-782
@@ -937,7 +961,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     // every facet rule on its own lane first, then every facet picks its first matching rule
     for (uint32_t p0 = 0; p0 < t.n_frules; p0 += 64) {
         const uint32_t p = p0 + lane;
-        const uint64_t m = w.ballot(p < t.n_frules && rc_match(L, rc, t.rc_frules + p * RC_REC_WORDS));
+        const uint64_t m = frules_possible ? w.ballot(p < t.n_frules && rc_match(L, rc, t.rc_frules + p * RC_REC_WORDS)) : 0;
         if (lane == 0) { L.fhit[p0 >> 5] = (uint32_t)m; L.fhit[(p0 >> 5) + 1] = (uint32_t)(m >> 32); }
     }
     w.sync();

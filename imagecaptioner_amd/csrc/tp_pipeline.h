@@ -679,7 +679,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
 
     // ---------------- evidence closure (Program.cs:301-302) ----------------
     expand_implied(t, ws, ws.ev, ne, ws.cap_e, overflow);
-    v.n_evidence = (uint16_t)(ne > 0xFFFF ? 0xFFFF : ne);
+    v.n_evidence = (uint16_t)((ne > 0xFFFF || !fired) ? 0xFFFF : ne);   // counted for callers that take the detail arrays
     for (uint32_t w = 0; w < t.lit_words; ++w) ws.ebits[w] = 0;
     bool ev_feet = false, ev_penis = false;
     for (uint32_t i = 0; i < ne; ++i) {

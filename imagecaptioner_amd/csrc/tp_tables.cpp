@@ -1140,6 +1140,25 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             rc.push_back(out.flags[d]); rc.push_back(out.str_off[d + 1] - out.str_off[d]);
             rc.push_back((out.next[d] != d || (out.flags[d] & FL_BLANK)) ? 1u : 0u);
         }
+        {   // positive-literal masks
+            std::vector<uint32_t> rmask(sc.lit_words, 0), fmask(sc.lit_words, 0);
+            sc.rules_vacuous = sc.frules_vacuous = 0;
+            auto mark = [&](std::vector<uint32_t>& m, uint32_t off, uint32_t cnt) { for (uint32_t k = 0; k < cnt; ++k) { uint32_t li = out.pool[off + k]; m[li >> 5] |= 1u << (li & 31); } };
+            for (uint32_t r = 0; r < n_rules; ++r) {
+                const DRule& d = out.rules[r];
+                if (d.all_cnt + d.any_cnt == 0) sc.rules_vacuous = 1;
+                mark(rmask, d.all_off, d.all_cnt); mark(rmask, d.any_off, d.any_cnt);
+            }
+            for (uint32_t k = 0; k < n_frules; ++k) {
+                const DSub& d = out.facet_rules[k];
+                if (d.all_cnt + d.any_cnt == 0) sc.frules_vacuous = 1;
+                mark(fmask, d.all_off, d.all_cnt); mark(fmask, d.any_off, d.any_cnt);
+            }
+            sc.rc_rule_mask = (uint32_t)rc.size();
+            rc.insert(rc.end(), rmask.begin(), rmask.end());
+            sc.rc_frule_mask = (uint32_t)rc.size();
+            rc.insert(rc.end(), fmask.begin(), fmask.end());
+        }
         const uint32_t tail_base = (uint32_t)rc.size();
         for (const Fix& fx : fixes) rc[fx.word] |= (tail_base + fx.tail_off) & 0x7FFFu;
         rc.insert(rc.end(), tail.begin(), tail.end());

@@ -64,7 +64,8 @@ typedef struct tp_verdict {
     uint16_t n_candidates;  /* finalCandidates.Count */
     uint16_t n_selected;    /* finalSelection.Tags.Count (before the fallback) */
     int16_t  safe_hit;      /* index into the SafeModeRejectTags list (Program.cs:43-45 order) of the hit, else -1 */
-    uint16_t n_evidence;    /* evidenceTags.Count after ExpandImpliedTags */
+    uint16_t n_evidence;    /* evidenceTags.Count after ExpandImpliedTags; 0xFFFF (not counted) when the call did not ask for the
+                               detail arrays, i.e. tp_device_io.fired == NULL (tp_run_lines / tp_run_scored always count) */
     uint16_t n_unknown;     /* GetUnknownTags(finalTags).Count, Program.cs:314 */
     uint16_t n_dropped;     /* finalSelection.DroppedTagsWithReason.Count */
 } tp_verdict;

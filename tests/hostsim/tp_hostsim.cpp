@@ -47,7 +47,7 @@ void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint
     const DevTables& t = s.dt;
     o.offsets.assign(n + 1, 0);
     o.verdicts.assign(n, tp_verdict{});
-    o.fired.assign(n * t.fired_words, 0);
+    o.fired.assign(std::max<size_t>(n * t.fired_words, 1), 0);   // never empty: a non-null pointer asks for the detail outputs
     o.facets.assign(n * t.n_facets, 0xFFFF);
     o.hist.assign((size_t)t.n_strings + 1, 0);
     std::memset(&o.ctr, 0, sizeof o.ctr);
@@ -69,7 +69,7 @@ void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint
             if (tag_begin) { in.arena = arena; in.tag_offsets = offsets; in.tag_lo = tag_begin[f]; in.tag_hi = tag_begin[f + 1]; in.scores = scores; in.sources = sources; }
             else { in.text = arena + offsets[f]; in.len = (uint32_t)(offsets[f + 1] - offsets[f]); }
             FileOut fo;
-            process_file(t, in, ws, fo, t.fired_words ? &o.fired[f * t.fired_words] : nullptr, t.n_facets ? &o.facets[f * t.n_facets] : nullptr, mode);
+            process_file(t, in, ws, fo, o.fired.data() + f * t.fired_words, t.n_facets ? &o.facets[f * t.n_facets] : nullptr, mode);
             o.verdicts[f] = fo.verdict;
             if (fin_lists) for (uint32_t k = 0; k < fo.n_final; ++k) (*fin_lists)[f].push_back(ws.fin[k]);
             // caption bytes (what k_emit writes)
@@ -172,7 +172,7 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
     std::vector<std::vector<H>> unused;
     o->offsets.assign(n + 1, 0);
     o->verdicts.assign(n, tp_verdict{});
-    o->fired.assign(n * t.fired_words, 0);
+    o->fired.assign(std::max<size_t>(n * t.fired_words, 1), 0);
     o->facets.assign(n * t.n_facets, 0xFFFF);
     o->hist.assign((size_t)t.n_strings + 1, 0);
     uint64_t slow = 0;
@@ -192,7 +192,7 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
                 std::memset(&lds, 0xCD, sizeof lds);
                 sh.run([&](int lane) {
                     emu::Wave w{&sh, (uint32_t)lane};
-                    uint32_t* fired = t.fired_words ? &o->fired[f * t.fired_words] : nullptr;
+                    uint32_t* fired = o->fired.data() + f * t.fired_words;
                     uint16_t* facets = t.n_facets ? &o->facets[f * t.n_facets] : nullptr;
                     done[lane] = stage == 1 ? fast_file<1, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), fired, facets)
                                             : fast_file<2, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), fired, facets);

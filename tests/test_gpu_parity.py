@@ -140,7 +140,19 @@ def test_device_api_capacity_and_accumulation():
     torch.cuda.synchronize()
     assert np.array_equal(caps.cpu().numpy(), host.captions)
     assert np.array_equal(cap_off.cpu().numpy().astype(np.uint64), host.caption_offsets)
+    got_ver = ver.cpu().numpy().copy().view(host.verdicts.dtype)
+    assert np.all(got_ver["n_evidence"] == 0xFFFF)    # no detail arrays were asked for: the evidence set is not counted
+    got_ver["n_evidence"] = host.verdicts["n_evidence"]
+    assert got_ver.tobytes() == host.verdicts.tobytes()
+    # with the detail arrays the count is there
+    fired = torch.zeros(max(n * p.info.fired_words, 1), dtype=torch.int32, device=dev)
+    io.fired = fired.data_ptr()
+    hist2, ctr2 = torch.zeros_like(hist), torch.zeros_like(ctr)
+    io.histogram, io.counters = hist2.data_ptr(), ctr2.data_ptr()
+    p.run_lines_device(io)
+    torch.cuda.synchronize()
     assert ver.cpu().numpy().tobytes() == host.verdicts.tobytes()
+    assert np.array_equal(fired.cpu().numpy().view(np.uint32)[:n * p.info.fired_words].reshape(n, -1), host.fired)
     assert np.array_equal(hist.cpu().numpy()[:-1].astype(np.uint64), 2 * host.histogram)
     assert int(ctr[0]) == 2 * n
 
