@@ -86,16 +86,18 @@ TP_HD bool is_tag_rest8(uint8_t c) {
     return is_tag_first8(c) || c == '_' || c == '(' || c == ')' || c == '!' || c == '\'' || c == '/' || c == '-';
 }
 
-// ---- hashing (FNV-1a 64 with a final avalanche; equality is always verified on bytes) ------------------
-// The string is taken as little-endian 8-byte words (the last one zero-padded): one multiply per word, not per byte.
+// ---- hashing (equality is always verified on bytes; the hash only places and pre-filters) ----------------
+// The string is taken as little-endian 8-byte words (the last one zero-padded).  Word k is rotated by 13k bits and
+// folded in with xor, so absent (zero) words cost nothing and the words can be folded in any order; two multiply /
+// shift-xor rounds at the end spread the bits.
 constexpr uint64_t HASH_SEED = 0xcbf29ce484222325ull;
-TP_HD uint64_t hash_word(uint64_t h, uint64_t w) {
-    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-    return h ^ (h >> 32);
-}
+TP_HD uint64_t rotl64(uint64_t x, uint32_t r) { r &= 63u; return r ? (x << r) | (x >> (64u - r)) : x; }
+TP_HD uint64_t hash_word(uint64_t h, uint64_t w, uint32_t k) { return h ^ rotl64(w, 13u * k); }
 TP_HD uint64_t hash_finish(uint64_t h, uint32_t n_bytes) {
-    h = (h ^ n_bytes) * 0xD6E8FEB86659FD93ull;
-    h ^= h >> 29;
+    h ^= n_bytes;
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
     return h ? h : 1;          // 0 marks an empty slot
 }
 struct Hasher {
@@ -103,9 +105,9 @@ struct Hasher {
     uint32_t n = 0;
     TP_HD void add(uint8_t c) {
         w |= (uint64_t)c << (8 * (n & 7));
-        if ((++n & 7) == 0) { h = hash_word(h, w); w = 0; }
+        if ((++n & 7) == 0) { h = hash_word(h, w, (n >> 3) - 1); w = 0; }
     }
-    TP_HD uint64_t done() const { return hash_finish((n & 7) ? hash_word(h, w) : h, n); }
+    TP_HD uint64_t done() const { return hash_finish((n & 7) ? hash_word(h, w, n >> 3) : h, n); }
 };
 
 // ---- compiled rules --------------------------------------------------------------------------------------

@@ -240,10 +240,7 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
         if (n <= 32) {
             const uint64_t w0 = ld64u(s + i1) & word_mask(n, 0), w1 = ld64u(s + i1 + 8) & word_mask(n, 1), w2 = ld64u(s + i1 + 16) & word_mask(n, 2),
                            w3 = ld64u(s + i1 + 24) & word_mask(n, 3);
-            uint64_t h = hash_word(HASH_SEED, w0);
-            h = n > 8 ? hash_word(h, w1) : h;
-            h = n > 16 ? hash_word(h, w2) : h;
-            h = n > 24 ? hash_word(h, w3) : h;
+            const uint64_t h = hash_word(hash_word(hash_word(hash_word(HASH_SEED, w0, 0), w1, 1), w2, 2), w3, 3);   // absent words are zero
             uint32_t id = slot_find32(t, hash_finish(h, n), n, w0, w1, w2, w3, rec);
             if (id != NO_ID) { out = id; return 1; }
         }
@@ -266,14 +263,14 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
         cur |= skip ? 0ull : (uint64_t)c << (8 * (n & 7));
         n += 1u - skip;
         if (!skip && (n & 7) == 0) {
-            h = hash_word(h, cur);
+            h = hash_word(h, cur, (n >> 3) - 1);
             const uint32_t wi = (n >> 3) - 1;
             w0 = wi == 0 ? cur : w0; w1 = wi == 1 ? cur : w1; w2 = wi == 2 ? cur : w2; w3 = wi == 3 ? cur : w3;
             cur = 0;
         }
     }
     if (n & 7) {
-        h = hash_word(h, cur);
+        h = hash_word(h, cur, n >> 3);
         const uint32_t wi = n >> 3;
         w0 = wi == 0 ? cur : w0; w1 = wi == 1 ? cur : w1; w2 = wi == 2 ? cur : w2; w3 = wi == 3 ? cur : w3;
     }

@@ -61,6 +61,10 @@ struct DevWave {
     __device__ uint32_t rank(uint64_t m) const { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
     // the value lane `src` holds; src is the same in every lane
     __device__ uint32_t bcast(uint32_t v, uint32_t src) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)src)); }
+    // inclusive prefix sum over the lanes
+    __device__ uint32_t scan_incl(uint32_t v) const { return wave_scan_incl(v); }
+    // the value of the lane below; lane 0 receives `fill`
+    __device__ uint32_t shift_up(uint32_t v, uint32_t fill) const { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
     // the sum over all lanes, in every lane
     __device__ uint32_t sum(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63); }
     __device__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)(src & 63u), 64); }

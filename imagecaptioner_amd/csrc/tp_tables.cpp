@@ -883,15 +883,24 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     while (slots < N * 2u + 2u) slots <<= 1;
     out.ht_hash.assign(slots, 0);
     out.ht_id.assign(slots, NO_ID);
+    uint64_t probe_sum = 0;
+    uint32_t probe_max = 0, probe_multi = 0;
     for (uint32_t i = 0; i < N; ++i) {
         Hasher hs;
         for (unsigned char c : out.strings[i]) hs.add(c);
         uint64_t h = hs.done();
         uint32_t s = (uint32_t)h & (slots - 1);
-        while (out.ht_hash[s] != 0) s = (s + 1) & (slots - 1);
+        uint32_t probes = 1;
+        while (out.ht_hash[s] != 0) { s = (s + 1) & (slots - 1); ++probes; }
         out.ht_hash[s] = h;
         out.ht_id[s] = i;
+        probe_sum += probes;
+        probe_max = std::max(probe_max, probes);
+        if (probes > 1) ++probe_multi;
     }
+    if (std::getenv("TAGPIPE_DEBUG_TABLES"))
+        std::fprintf(stderr, "tagpipe tables: %u strings in %u slots, probes avg %.3f max %u, %.1f %% of the strings off their home slot\n", N, slots,
+                     (double)probe_sum / std::max(1u, N), probe_max, 100.0 * probe_multi / std::max(1u, N));
     out.dfa_next = ld.dfa_next;
     out.dfa_out = ld.dfa_out;
 
