@@ -120,8 +120,23 @@ TP_HD bool heq(const FileWs& ws, H a, H b) {
     for (uint32_t i = 0; i < n; ++i) if (p[i] != q[i]) return false;
     return true;
 }
+// Is h in arr[0 .. n)?  Eight elements are fetched at a time so that their loads overlap: a thread walks these lists
+// alone, and one load per step would cost a full memory latency each.
 TP_HD bool lfind(const FileWs& ws, const LaneArr<H>& arr, uint32_t n, H h) {
-    for (uint32_t i = 0; i < n; ++i) if (heq(ws, arr[i], h)) return true;
+    uint32_t i = 0;
+    if (!h_is_dyn(h)) {                                            // an interned string equals only its own handle
+        for (; i + 8 <= n; i += 8) {
+            const H v0 = arr[i], v1 = arr[i + 1], v2 = arr[i + 2], v3 = arr[i + 3], v4 = arr[i + 4], v5 = arr[i + 5], v6 = arr[i + 6], v7 = arr[i + 7];
+            if ((v0 == h) | (v1 == h) | (v2 == h) | (v3 == h) | (v4 == h) | (v5 == h) | (v6 == h) | (v7 == h)) return true;
+        }
+        for (; i < n; ++i) if (arr[i] == h) return true;
+        return false;
+    }
+    for (; i + 8 <= n; i += 8) {
+        const H v[8] = {arr[i], arr[i + 1], arr[i + 2], arr[i + 3], arr[i + 4], arr[i + 5], arr[i + 6], arr[i + 7]};
+        for (int k = 0; k < 8; ++k) if (h_is_dyn(v[k]) && heq(ws, v[k], h)) return true;
+    }
+    for (; i < n; ++i) if (heq(ws, arr[i], h)) return true;
     return false;
 }
 
