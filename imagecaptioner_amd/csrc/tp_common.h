@@ -133,10 +133,12 @@ struct alignas(128) Slot {
     uint32_t val;        // id of the alias lookup's result
     uint32_t woff;       // the key's words in DevTables::str_words (keys longer than 32 bytes are compared there)
     uint32_t key[8];     // the key's first 32 bytes, zero padded
-    uint32_t pad[4];
+    uint32_t kflags;     // SLOT_KEY_BASIC
+    uint32_t pad[3];
     Rec rec;             // DevTables::rec[val]
 };
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t SLOT_KEY_BASIC = 1u;   // the key is what NormalizeTag's steps before the alias lookup make of itself (Program.cs:1150-1154)
 // Hash-table payload: what the alias lookup makes of the string in this slot, and where its bytes are (to verify a probe).
 struct HtInfo { uint32_t val, woff, slen, pad; };   // woff: first 8-byte word of the string in DevTables::str_words
 

@@ -56,6 +56,7 @@ struct alignas(16) FastLds {
     uint8_t line[FAST_LINE_MAX + 64];    // 16 spare bytes in front (the byte before the line is read), the line at its 16-byte phase, tail padding
     uint16_t cpos[FAST_TOK_MAX];
     uint32_t tspec[FAST_TOK_MAX / 32];   // bit k: token k holds a byte that needs the byte-wise normaliser
+    uint32_t thigh[FAST_TOK_MAX / 32];   // bit k: token k holds a byte >= 0x80
     uint32_t fin[FAST_FIN_MAX];
     uint32_t fattr[FAST_FIN_MAX];          // flags of fin[k] (files on the settled-tags path)
     uint32_t flen[FAST_FIN_MAX];           // byte length of fin[k]
@@ -132,8 +133,9 @@ TP_HD uint8_t byte_class(uint32_t c) {
     if (c == ',') k |= CL_COMMA;
     if ((c >= 'A' && c <= 'Z') || c == '"' || c == '\'' || c == ';' || c == '.') k |= CL_SPEC;   // what NormalizeTag changes or strips (Program.cs:1150-1154)
     if (c == '_') k |= CL_US;
+    if (c >= 0x80) k |= CL_SPEC | CL_US;                                // both at once: a byte of a character outside ASCII
     if (c == ':') k |= CL_COLON;
-    if (c >= 0x80 || c == '`' || c == '\n' || c == '\r') k |= CL_BAD;     // not ASCII, a code fence, a line break: not for this kernel
+    if (c == '`' || c == '\n' || c == '\r') k |= CL_BAD;                 // a code fence, a line break: not for this kernel
     if (c == 's' || c == 'S') k |= CL_S;
     if (c == 'o' || c == 'O') k |= CL_O;
     return (uint8_t)k;
@@ -207,12 +209,13 @@ TP_HD bool lds_match(const uint8_t* s, uint32_t pos, uint32_t end, const char* p
 
 // Lookup of a normalised string of n <= 32 bytes, given as zero-padded little-endian words, in the slot table: both cache
 // lines of the first slot are fetched at once, so a first-probe hit costs one memory round trip and brings the record along.
-TP_HD uint32_t slot_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, Rec& rec) {
+TP_HD uint32_t slot_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, Rec& rec, uint32_t& kflags) {
     uint32_t slot = (uint32_t)hsh & t.ht_mask;
     const uint32_t h32 = (uint32_t)(hsh >> 32);
     for (;;) {
         const Slot* sl = t.slots + slot;
         const uint32_t hash = sl->hash, slen = sl->slen, val = sl->val;
+        kflags = sl->kflags;
         uint64_t k[4];
         __builtin_memcpy(k, sl->key, 32);
         rec = sl->rec;
@@ -226,13 +229,19 @@ TP_HD uint32_t slot_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_
 //   returns 0: empty after trimming, skipped (Program.cs:1183-1185)
 //           1: interned, id in `out`
 //           2: not in any table
+//           3: the file is not for this kernel
 // On a hit `rec` receives the record of `out`.
+// `high`: the token holds bytes of characters outside ASCII.  This kernel does not decode them; it accepts the token only
+// when its bytes as they stand are a known string that the normalisation before the alias lookup leaves alone: then that
+// normalisation of the token yields this very string.
 // `special` is false when the token is known to hold nothing for the normaliser to change apart from one leading
 // white-space byte: then its bytes are the normalised string and are hashed straight from the line.  Otherwise the
 // bytes go through the byte-wise normaliser; they are packed into 8-byte words as they are produced (the first 32 bytes
 // stay in registers), so hashing costs one multiply per word and a probe hit is verified word by word against
 // DevTables::str_words.
-TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, bool special, uint32_t& out, Rec& rec, bool& valid_dyn, uint32_t& dyn_len) {
+TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, bool special, bool high, uint32_t& out, Rec& rec, bool& valid_dyn,
+                     uint32_t& dyn_len) {
+    if (high && special) return 3;
     if (!special) {
         const uint32_t i1 = i + ((uint32_t)(i < j) & ws32(s[i]));
         const uint32_t n = j - i1;
@@ -241,9 +250,11 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
             const uint64_t w0 = ld64u(s + i1) & word_mask(n, 0), w1 = ld64u(s + i1 + 8) & word_mask(n, 1), w2 = ld64u(s + i1 + 16) & word_mask(n, 2),
                            w3 = ld64u(s + i1 + 24) & word_mask(n, 3);
             const uint64_t h = hash_word(hash_word(hash_word(hash_word(HASH_SEED, w0, 0), w1, 1), w2, 2), w3, 3);   // absent words are zero
-            uint32_t id = slot_find32(t, hash_finish(h, n), n, w0, w1, w2, w3, rec);
-            if (id != NO_ID) { out = id; return 1; }
+            uint32_t kflags = 0;
+            uint32_t id = slot_find32(t, hash_finish(h, n), n, w0, w1, w2, w3, rec, kflags);
+            if (id != NO_ID && (!high || (kflags & SLOT_KEY_BASIC))) { out = id; return 1; }
         }
+        if (high) return 3;
     }
     while (i < j && ws32(s[i])) ++i;
     while (j > i && ws32(s[j - 1])) --j;
@@ -384,7 +395,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         const uint8_t* abase = text - shift;
         uint32_t pieces = (shift + len + 15) >> 4;
         for (uint32_t c = lane; c < pieces; c += 64) w.copy16(L.line + 16 + 16 * c, abase + 16 * c);
-        if (lane < FAST_TOK_MAX / 32) L.tspec[lane] = 0;
+        if (lane < FAST_TOK_MAX / 32) { L.tspec[lane] = 0; L.thigh[lane] = 0; }
     }
     w.sync();
     w.tick(1);
@@ -416,7 +427,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     // commas, tokens that need the byte-wise normaliser, bytes this kernel leaves to the general one, LooksBad (Program.cs:1141-1147)
     uint32_t ncomma = 0;
     bool refusal = false, keyword = false;
-    uint64_t any_blank = 0, any_bad = 0;
+    uint64_t any_blank = 0, any_bad = 0, any_high = 0;
     for (uint32_t base = a; base < b; base += 256) {
         const uint32_t p = base + 4 * lane;
         const uint32_t pp = p < b ? p : b;
@@ -440,12 +451,16 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         // A byte the normaliser would change or drop: upper case, quotes, trailing-punctuation characters, white space
         // other than a single byte right after a comma, the second of two underscores.
         const uint32_t blank = cw & ~(pcw >> 1) & inm;
-        const uint32_t sp = (((cw >> 2) | ((cw >> 3) & (pcw >> 3))) & inm) | blank;
+        const uint32_t high = (cw >> 2) & (cw >> 3) & inm;           // bytes of characters outside ASCII: the token must be a known string as it stands
+        const uint32_t sp = ((((cw >> 2) & ~high) | ((cw >> 3) & ~(cw >> 2) & (pcw >> 3) & ~(pcw >> 2))) & inm) | blank;
         any_blank |= w.ballot(blank != 0);
         any_bad |= w.ballot(((cw >> 5) & inm) != 0);
-        if (sp) {
-            for (uint32_t j = 0; j < 4; ++j)
+        any_high |= w.ballot(high != 0);
+        if (sp | high) {
+            for (uint32_t j = 0; j < 4; ++j) {
                 if ((sp & (1u << (8 * j))) && k[j] < FAST_TOK_MAX) w.lds_or(&L.tspec[k[j] >> 5], 1u << (k[j] & 31));
+                if ((high & (1u << (8 * j))) && k[j] < FAST_TOK_MAX) w.lds_or(&L.thigh[k[j] >> 5], 1u << (k[j] & 31));
+            }
         }
         const uint32_t colon = (cw >> 4) & inm;
         if (w.ballot(colon != 0)) {   // only "positive:" / "negative:" matter (Program.cs:57, 592-594); other colons are ordinary tag text
@@ -464,6 +479,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         }
     }
     if (any_bad) return false;
+    if (any_high && ncomma < 2) return false;   // LooksBad measures such a line in UTF-16 units (Program.cs:1145)
     if (any_blank && !refusal) {
         // The other entries (without the two that hold ':') all have a blank that follows a letter; such a blank was seen.
         for (uint32_t base = a; base < b; base += 64) {
@@ -514,11 +530,13 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                     uint32_t j = tix == T - 1 ? b : (uint32_t)L.cpos[tix];
                     uint32_t id = NO_ID, dlen = 0;
                     bool vdyn = false;
-                    const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u;
+                    const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u, high = (L.thigh[tix >> 5] >> (tix & 31)) & 1u;
                     Rec rr;
-                    int kind = fast_token(t, s, i, j, special, id, rr, vdyn, dlen);
+                    int kind = fast_token(t, s, i, j, special, high, id, rr, vdyn, dlen);
                     if (kind == 1) {
                         if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) { h1[blk] = id; r1[blk] = rr; keep[blk] = true; }
+                    } else if (kind == 3) {
+                        dyn_survivor = true;                       // declines the file below
                     } else if (kind == 2) {
                         // a string outside the tables: gone under strict vocabulary, too short, or invalid; anything else may survive
                         if (!t.drop_unknown && dlen >= 2 && vdyn) dyn_survivor = true;

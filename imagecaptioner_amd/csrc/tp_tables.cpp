@@ -765,6 +765,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     out.str_off.assign(N + 1, 0);
     out.flags.assign(N, 0);
     out.next.assign(N, 0);
+    out.basic_fixed.assign(N, 0);
     out.alias1.assign(N, 0);
     out.lit.assign(N, NO_ID);
     out.str_bytes.clear();
@@ -782,6 +783,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         out.str_bytes.insert(out.str_bytes.end(), out.strings[i].begin(), out.strings[i].end());
         out.alias1[i] = id_of(ld.alias_of(s));
         out.next[i] = id_of(ld.alias_of(normalize_basic(s)));
+        out.basic_fixed[i] = normalize_basic(s) == s ? 1 : 0;
         uint32_t mask = class_mask(ld.dfa_next, ld.dfa_out, lowered(s));
         uint32_t f = 0;
         if (blank(s)) f |= FL_BLANK;
@@ -1089,6 +1091,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         sl.slen = out.str_off[id + 1] - out.str_off[id];
         sl.val = out.alias1[id];
         sl.woff = word_off[id];
+        sl.kflags = out.basic_fixed[id] ? SLOT_KEY_BASIC : 0;
         const std::string& str = out.strings[id];
         for (size_t b = 0; b < str.size() && b < 32; ++b) sl.key[b >> 2] |= (uint32_t)(unsigned char)str[b] << (8 * (b & 3));
         sl.rec = out.rec[sl.val];

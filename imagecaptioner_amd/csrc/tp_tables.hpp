@@ -30,6 +30,7 @@ struct HostTables {
     std::vector<DSub> facet_rules;
     std::vector<Rec> rec;
     std::vector<Slot> slots;
+    std::vector<uint8_t> basic_fixed;       // per id: the string is a fixed point of the normalisation before the alias lookup
     std::vector<HtInfo> ht_info;
     std::vector<uint64_t> str_words;
     std::vector<uint32_t> step_off, step_ids, reach_off, reach_ent, rule_cache;

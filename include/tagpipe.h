@@ -43,7 +43,9 @@ extern "C" {
 #define TP_F_FOOTJOB       0x04u  /* ... and the final tags have footjob, Program.cs:311 */
 #define TP_F_FALLBACK      0x08u  /* fewer than 3 selected tags: minimal fallback line used, Program.cs:297-298 */
 #define TP_F_LINE_REJECTED 0x10u  /* NormalizeRawTagLine returned "" (blank or LooksBad), Program.cs:590, 596 */
-#define TP_F_UNSUPPORTED   0x20u  /* input this build does not process (a byte >= 0x80, or a per-file list outgrew its workspace); nothing is written for the file */
+#define TP_F_UNSUPPORTED   0x20u  /* input this build does not process: a tag with characters outside ASCII that is not, as written, a known string
+                                     that normalisation leaves alone (such tags need Unicode case mapping and white-space rules), or a per-file
+                                     list that outgrew its workspace; nothing is written for the file */
 #define TP_F_SAFE_REJECT   0x40u  /* DetectSafeModeRejectReason hit, Program.cs:329, 942-945 */
 
 /* Candidate sources and their SourceRank (Program.cs:398, 712-717). */

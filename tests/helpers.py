@@ -224,3 +224,37 @@ EDGE_LINES = [
     "1girl, smile\n",
     "\n\n1girl, smile, dress\n\n",
 ]
+
+
+# Tags outside ASCII: the wave-per-file kernel takes a token with such bytes when it is, as it stands, a known string that
+# normalisation leaves alone; everything else with such bytes is reported as unsupported.
+NON_ASCII_VOCAB = ["1girl", "solo", "smile", "dress", "caf\u00e9", "\u9752\u3044\u9aea", "pok\u00e9mon_(creature)", "long_hair", "\u00dcber_tag"]
+NON_ASCII_LINES = [
+    ("1girl, caf\u00e9, dress, smile", True),
+    ("1girl, \u9752\u3044\u9aea, pok\u00e9mon_(creature), long_hair, smile", True),
+    ("caf\u00e9,1girl,solo,\u9752\u3044\u9aea,dress", True),
+    ("1girl, CAF\u00c9, dress, smile", False),                 # upper case outside ASCII: lower-casing needed
+    ("1girl,\u3000caf\u00e9, dress, smile", False),           # U+3000 is white space to Trim()
+    ("1girl, caf\u00e9\u3002, dress, smile", False),           # trailing ideographic full stop is stripped
+    ("1girl, caf\u00e9 au lait, dress, smile", False),         # blank inside a token with bytes outside ASCII
+    ("1girl, \u00dcber_tag, dress, smile", False),             # in the vocabulary as written, but normalisation lower-cases it
+    ("1girl, smile, dress, unknown\u00e9", False),             # not a known string as it stands
+]
+
+
+def non_ascii_config():
+    vocab = ("\n".join(NON_ASCII_VOCAB) + "\n").encode("utf-8")
+    return shipped_config(vocabulary=vocab, vocabulary_is_json=0)
+
+
+def check_non_ascii(run_fast, oracle):
+    """run_fast(texts) -> result of the implementation's GPU flow; oracle: Oracle for non_ascii_config()."""
+    texts = [t for t, _ in NON_ASCII_LINES]
+    got, want = run_fast(texts), oracle.run_texts(texts)
+    for i, (text, taken) in enumerate(NON_ASCII_LINES):
+        if taken:
+            assert got.caption(i) == want.caption(i) and got.caption(i) != b"", (text, got.caption(i), want.caption(i))
+            assert got.verdicts[i].tobytes() == want.verdicts[i].tobytes(), text
+        else:
+            assert got.verdicts["flags"][i] & 0x20 and got.caption(i) == b"", text
+    assert got.counters["unsupported"] == sum(1 for _, taken in NON_ASCII_LINES if not taken)

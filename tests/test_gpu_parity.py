@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import EDGE_LINES, Config, Oracle, assert_same_results, pack_lines, shipped_config
+from helpers import EDGE_LINES, Config, Oracle, assert_same_results, check_non_ascii, non_ascii_config, pack_lines, shipped_config
 from test_pipeline_logic_cpu import CONFIGS, fuzz_lines, scored_inputs
 
 pytestmark = pytest.mark.gpu
@@ -92,6 +92,11 @@ def test_non_ascii_is_reported_not_guessed():
     r = p.run_texts(["1girl, smile, dress", "1girl, café, dress", "1girl, 青い髪"])
     assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
     assert r.caption(1) == b"" and r.caption(2) == b"" and r.counters["unsupported"] == 2
+
+
+def test_known_non_ascii_tags_pass_through_the_wave_kernel():
+    cfg = non_ascii_config()
+    check_non_ascii(pipe_for(cfg).run_texts, Oracle(cfg))
 
 
 def test_workspace_chunking_gives_identical_results(monkeypatch):

@@ -9,7 +9,7 @@ import random
 import numpy as np
 import pytest
 
-from helpers import DATA, EDGE_LINES, Config, HostSim, Oracle, assert_same_results, shipped_config
+from helpers import DATA, EDGE_LINES, Config, HostSim, Oracle, assert_same_results, check_non_ascii, non_ascii_config, shipped_config
 from imagecaptioner_amd.corpus import make_corpus
 
 CONFIGS = {
@@ -112,6 +112,11 @@ def test_non_ascii_is_reported_not_guessed():
     assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
     assert r.caption(1) == b"" and r.caption(2) == b""
     assert r.counters["unsupported"] == 2
+
+
+def test_known_non_ascii_tags_pass_through_the_wave_kernel():
+    cfg = non_ascii_config()
+    check_non_ascii(HostSim(cfg).run_texts_fast, Oracle(cfg))
 
 
 # ---- the wave-per-file kernel body (tp_fast.h) on an emulated wavefront ---------------------------------------------
