@@ -52,11 +52,8 @@ constexpr uint32_t FAST_LIT_WORDS = 128;   // evidence bitset words (4096 rule l
 constexpr uint32_t FAST_FIRED_WORDS = 64;  // fired-rule bitmap words (2048 rules + subtypes)
 constexpr uint32_t FAST_CAPTION_MAX = 2048; // caption bytes (the emit kernel puts a caption together in LDS)
 
-struct alignas(16) FastLds {
-    uint8_t line[FAST_LINE_MAX + 64];    // 16 spare bytes in front (the byte before the line is read), the line at its 16-byte phase, tail padding
-    uint16_t cpos[FAST_TOK_MAX];
-    uint32_t tspec[FAST_TOK_MAX / 32];   // bit k: token k holds a byte that needs the byte-wise normaliser
-    uint32_t thigh[FAST_TOK_MAX / 32];   // bit k: token k holds a byte >= 0x80
+// The part of a file's LDS state that the back half of the pipeline (coverage, closures, rules, facets, verdict) works on.
+struct alignas(16) BackLds {
     uint32_t fin[FAST_FIN_MAX];
     uint32_t fattr[FAST_FIN_MAX];          // flags of fin[k] (files on the settled-tags path)
     uint32_t flen[FAST_FIN_MAX];           // byte length of fin[k]
@@ -66,6 +63,16 @@ struct alignas(16) FastLds {
     uint32_t firedw[FAST_FIRED_WORDS];
     uint32_t fhit[FAST_FRULES_MAX / 32];   // bit p: facet rule p matches the evidence
 };
+// ... plus the line and its tokens, sized for LINE bytes and TOK tokens.
+template <uint32_t LINE, uint32_t TOK>
+struct alignas(16) LineLds : BackLds {
+    static constexpr uint32_t LINE_CAP = LINE, TOK_CAP = TOK;
+    uint8_t line[LINE + 64];     // 16 spare bytes in front (the byte before the line is read), the line at its 16-byte phase, tail padding
+    uint16_t cpos[TOK];
+    uint32_t tspec[TOK / 32];    // bit k: token k holds a byte that needs the byte-wise normaliser
+    uint32_t thigh[TOK / 32];    // bit k: token k holds a byte >= 0x80
+};
+using FastLds = LineLds<FAST_LINE_MAX, FAST_TOK_MAX>;
 
 struct FastOut {
     tp_verdict verdict;
@@ -155,7 +162,7 @@ TP_HD uint64_t word_mask(uint32_t n, uint32_t k) {
 
 // ---- LDS hash set: key -> smallest order value seen ---------------------------------------------------------------
 template <class W>
-TP_HD void set_clear(W& w, FastLds& L) {
+TP_HD void set_clear(W& w, BackLds& L) {
     static_assert(FAST_SET_SLOTS == 256 && NO_ID == 0xFFFFFFFFu, "one 16-byte store per lane and array");
     w.fill16(&L.set_key[4 * w.lane()], 0xFFFFFFFFu);
     w.fill16(&L.set_min[4 * w.lane()], 0xFFFFFFFFu);
@@ -163,7 +170,7 @@ TP_HD void set_clear(W& w, FastLds& L) {
 }
 // Returns the slot, or NO_ID when the table is full.  `created` is true for exactly one caller per key.
 template <class W>
-TP_HD uint32_t set_put(W& w, FastLds& L, uint32_t key, uint32_t order, bool& created) {
+TP_HD uint32_t set_put(W& w, BackLds& L, uint32_t key, uint32_t order, bool& created) {
     uint32_t s = (key * 2654435761u) >> 24;
     created = false;
     for (uint32_t probe = 0; probe < FAST_SET_SLOTS; ++probe) {
@@ -182,7 +189,7 @@ TP_HD uint32_t set_put(W& w, FastLds& L, uint32_t key, uint32_t order, bool& cre
 // first nblk blocks are looked at.  On return first[blk] marks the elements that are the first with their key; returns
 // false if the set overflowed.
 template <class W>
-TP_HD bool dedupe_first(W& w, FastLds& L, const uint32_t key[2], const bool valid[2], bool first[2], int nblk = 2) {
+TP_HD bool dedupe_first(W& w, BackLds& L, const uint32_t key[2], const bool valid[2], bool first[2], int nblk = 2) {
     set_clear(w, L);
     uint32_t slot[2] = {NO_ID, NO_ID};
     bool full = false;
@@ -324,16 +331,16 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
 }
 
 // MatchesActionRule / MatchesSubtypeRule / MatchesFacetRule on the LDS evidence bitset (Program.cs:777-794).
-TP_HD bool fbit(const FastLds& L, uint32_t idx) { return (L.ebits[idx >> 5] >> (idx & 31)) & 1u; }
-TP_HD bool f_all(const DevTables& t, const FastLds& L, uint32_t off, uint32_t cnt) {
+TP_HD bool fbit(const BackLds& L, uint32_t idx) { return (L.ebits[idx >> 5] >> (idx & 31)) & 1u; }
+TP_HD bool f_all(const DevTables& t, const BackLds& L, uint32_t off, uint32_t cnt) {
     for (uint32_t k = 0; k < cnt; ++k) if (!fbit(L, t.pool[off + k])) return false;
     return true;
 }
-TP_HD bool f_any(const DevTables& t, const FastLds& L, uint32_t off, uint32_t cnt) {
+TP_HD bool f_any(const DevTables& t, const BackLds& L, uint32_t off, uint32_t cnt) {
     for (uint32_t k = 0; k < cnt; ++k) if (fbit(L, t.pool[off + k])) return true;
     return false;
 }
-TP_HD bool f_match_sub(const DevTables& t, const FastLds& L, const DSub& r) {
+TP_HD bool f_match_sub(const DevTables& t, const BackLds& L, const DSub& r) {
     if (r.any_cnt && !f_any(t, L, r.any_off, r.any_cnt)) return false;
     if (r.all_cnt && !f_all(t, L, r.all_off, r.all_cnt)) return false;
     return true;
@@ -341,7 +348,7 @@ TP_HD bool f_match_sub(const DevTables& t, const FastLds& L, const DSub& r) {
 
 // One record of the rule cache against the evidence bitset: every `all` literal present, some `any` literal present (when
 // there are any), no forbidden literal present (MatchesActionRule / MatchesSubtypeRule / MatchesFacetRule, Program.cs:777-794).
-TP_HD bool rc_match(const FastLds& L, const uint32_t* rc, uint32_t rec) {
+TP_HD bool rc_match(const BackLds& L, const uint32_t* rc, uint32_t rec) {
     const uint32_t* r = rc + rec;
     const uint32_t cnts = r[2], n_all = cnts & 255u, n_any = (cnts >> 8) & 255u, n_forb = (cnts >> 16) & 255u, tot = n_all + n_any + n_forb;
     const uint32_t* lits = tot <= 4 ? r + 4 : rc + (r[3] & 0x7FFFu);
@@ -359,7 +366,7 @@ TP_HD bool rc_match(const FastLds& L, const uint32_t* rc, uint32_t rec) {
 // Wave-uniform: `id`, `nf` and the return value are the same in every lane.  Returns false on overflow.
 // With in_set the LDS set (which then holds every element of the list with order 0) learns the new element too.
 template <class W>
-TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id, bool in_set, uint32_t fin_max, uint32_t attr = 0,
+TP_HD bool fin_append(W& w, BackLds& L, uint32_t& own0, uint32_t& own1, uint32_t& nf, uint32_t id, bool in_set, uint32_t fin_max, uint32_t attr = 0,
                       uint32_t len = 0) {
     if (w.ballot(own0 == id || own1 == id) != 0) return true;
     if (nf >= fin_max) return false;
@@ -375,32 +382,28 @@ TP_HD bool fin_append(W& w, FastLds& L, uint32_t& own0, uint32_t& own1, uint32_t
     return in_set ? w.ballot(full) == 0 : true;
 }
 
-// The pipeline for one file.  Returns false when the file needs the general kernel.
-// NT = 1: at most 64 tokens (so candidates), one per lane; NT = 2: 128, two per lane.  NF likewise for the final tags.
-// Fewer per lane means fewer registers and less work per wavefront.
-// rc: the rule cache (DevTables::rc, or a copy of it in faster memory); cls: byte_class() of 0..255 as a table.
-// fin32: where the caption's tag ids go (FAST_FIN_MAX entries); fired / facet_choice may be null.
-template <int NT, int NF, class W>
-TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice) {
-    static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
-    constexpr uint32_t FIN_MAX = 64u * NF;
-    const uint32_t lane = w.lane();
-    if (len > FAST_LINE_MAX) return false;
-    w.tick(0);
+// What the line scan leaves behind: the line in LDS (s), its trimmed extent [a, b), the comma count (comma positions are in
+// L.cpos, per-token marks in L.tspec / L.thigh) and whether NormalizeRawTagLine rejects the line.
+struct Scan { const uint8_t* s; uint32_t a, b, ncomma; bool rejected; };
 
+// S1 + S2: the line goes to LDS, is trimmed and split at its commas (NormalizeRawTagLine, LooksBad, SplitTags:
+// Program.cs:589-596, 1141-1147, 1181-1187).  Returns false when the file needs the general kernel.
+template <class W, class LDS>
+TP_HD __attribute__((always_inline)) bool scan_line(W& w, LDS& L, const uint8_t* cls, const uint8_t* text, uint32_t len, Scan& sc) {
+    const uint32_t lane = w.lane();
+    if (len > LDS::LINE_CAP) return false;
+    w.tick(0);
     // ---- S1: line -> LDS in aligned 16-byte pieces -------------------------------------------------------------------
     const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
     {
         const uint8_t* abase = text - shift;
         uint32_t pieces = (shift + len + 15) >> 4;
         for (uint32_t c = lane; c < pieces; c += 64) w.copy16(L.line + 16 + 16 * c, abase + 16 * c);
-        if (lane < FAST_TOK_MAX / 32) { L.tspec[lane] = 0; L.thigh[lane] = 0; }
+        if (lane < LDS::TOK_CAP / 32) { L.tspec[lane] = 0; L.thigh[lane] = 0; }
     }
     w.sync();
     w.tick(1);
     const uint8_t* s = L.line + 16 + shift;
-    TP_STOP(1, L.line[16 + lane])
 
     // ---- S2: trim (NormalizeRawTagLine, Program.cs:589-596): first non-blank byte from the front, last from the back ----
     constexpr uint32_t B4 = 0x01010101u;                            // bit 0 of each of four bytes
@@ -445,7 +448,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         k[3] = k[2] + ((cm >> 16) & 1u);
         if (cm) {
             for (uint32_t j = 0; j < 4; ++j)
-                if ((cm & (1u << (8 * j))) && k[j] < FAST_TOK_MAX) L.cpos[k[j]] = (uint16_t)(p + j);
+                if ((cm & (1u << (8 * j))) && k[j] < LDS::TOK_CAP) L.cpos[k[j]] = (uint16_t)(p + j);
         }
         ncomma += popc64(mc[0]) + popc64(mc[1]) + popc64(mc[2]) + popc64(mc[3]);
         // A byte the normaliser would change or drop: upper case, quotes, trailing-punctuation characters, white space
@@ -458,8 +461,8 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         any_high |= w.ballot(high != 0);
         if (sp | high) {
             for (uint32_t j = 0; j < 4; ++j) {
-                if ((sp & (1u << (8 * j))) && k[j] < FAST_TOK_MAX) w.lds_or(&L.tspec[k[j] >> 5], 1u << (k[j] & 31));
-                if ((high & (1u << (8 * j))) && k[j] < FAST_TOK_MAX) w.lds_or(&L.thigh[k[j] >> 5], 1u << (k[j] & 31));
+                if ((sp & (1u << (8 * j))) && k[j] < LDS::TOK_CAP) w.lds_or(&L.tspec[k[j] >> 5], 1u << (k[j] & 31));
+                if ((high & (1u << (8 * j))) && k[j] < LDS::TOK_CAP) w.lds_or(&L.thigh[k[j] >> 5], 1u << (k[j] & 31));
             }
         }
         const uint32_t colon = (cw >> 4) & inm;
@@ -504,159 +507,33 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         }
     }
     if (keyword) return false;
-    const uint32_t T = ncomma + 1;
-    if (T > 64u * NT) return false;
-    const bool rejected = blank_line || refusal || (ncomma < 2 && (b - a) > 40);
+    sc.s = s; sc.a = a; sc.b = b; sc.ncomma = ncomma;
+    sc.rejected = blank_line || refusal || (ncomma < 2 && (b - a) > 40);
     w.sync();
-    w.tick(2);
-    TP_STOP(2, a ^ b ^ ncomma ^ T ^ (uint32_t)rejected ^ L.cpos[lane] ^ L.tspec[lane & 3])
+    return true;
+}
 
-    // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
-    // A token's lane stays its candidate's lane: candidate index = number of kept tokens before it.
-    const int nblk = NT == 1 ? 1 : (T > 64 ? 2 : 1);              // tokens (and so candidates) sit two per lane only in long lines
-    uint32_t n = 0;
-    bool act[2] = {false, false};
-    uint32_t h1[2] = {EMPTY_ID, EMPTY_ID}, ci[2] = {0, 0};
-    Rec r1[2];
-    r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
-    {
-        bool keep[2] = {false, false};
-        bool dyn_survivor = false;
-        if (!rejected) {
-            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-                uint32_t tix = (uint32_t)blk * 64 + lane;
-                if (tix < T) {
-                    uint32_t i = tix == 0 ? a : (uint32_t)L.cpos[tix - 1] + 1;
-                    uint32_t j = tix == T - 1 ? b : (uint32_t)L.cpos[tix];
-                    uint32_t id = NO_ID, dlen = 0;
-                    bool vdyn = false;
-                    const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u, high = (L.thigh[tix >> 5] >> (tix & 31)) & 1u;
-                    Rec rr;
-                    int kind = fast_token(t, s, i, j, special, high, id, rr, vdyn, dlen);
-                    if (kind == 1) {
-                        if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) { h1[blk] = id; r1[blk] = rr; keep[blk] = true; }
-                    } else if (kind == 3) {
-                        dyn_survivor = true;                       // declines the file below
-                    } else if (kind == 2) {
-                        // a string outside the tables: gone under strict vocabulary, too short, or invalid; anything else may survive
-                        if (!t.drop_unknown && dlen >= 2 && vdyn) dyn_survivor = true;
-                    }
-                }
-            }
-        }
-        if (w.ballot(dyn_survivor)) return false;
-        if (!dedupe_first(w, L, h1, keep, act, nblk)) return false;
-        const uint64_t m0 = w.ballot(act[0]), m1 = nblk > 1 ? w.ballot(act[1]) : 0;
-        n = popc64(m0) + popc64(m1);
-        ci[0] = w.rank(m0);
-        ci[1] = popc64(m0) + w.rank(m1);
-        if (!act[0]) { h1[0] = EMPTY_ID; r1[0] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
-        if (!act[1]) { h1[1] = EMPTY_ID; r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
-    }
 
-    w.tick(3);
-    TP_STOP(3, h1[0] ^ h1[1] ^ r1[0].flags ^ r1[0].next ^ r1[1].flags ^ r1[0].lit ^ r1[0].step0 ^ ci[0] ^ ci[1] ^ n ^ (uint32_t)act[0] ^ (uint32_t)act[1])
-    // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
-    // In line ingest the scores fall with the candidate index, so "sorted" order is candidate order and the first of
-    // two candidates that NormalizeTag merges carries the merged score, order and source.
-    bool nonblank2[2] = {false, false}, first2[2] = {false, false}, bad2[2] = {false, false}, uniq[2] = {false, false}, ev_seed[2] = {false, false};
-    uint32_t t2[2] = {EMPTY_ID, EMPTY_ID};
-    Rec r2[2];
-    r2[0] = r1[0]; r2[1] = r1[1];
-    uint32_t style_n = 0;
-    uint64_t m_hop2 = 0;
-    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-        t2[blk] = r1[blk].next;
-        bool hop = act[blk] && t2[blk] != h1[blk];
-        uint64_t mh = w.ballot(hop);
-        m_hop2 |= mh;
-        if (mh && hop) r2[blk] = t.rec[t2[blk]];
-        style_n += popc64(w.ballot(act[blk] && fl_bucket(r1[blk].flags) == B_STYLE && ci[blk] < t.style_ci_limit));   // DetermineStyleQualityCap, Program.cs:702-710
-        nonblank2[blk] = act[blk] && !(r2[blk].flags & FL_BLANK);
-        first2[blk] = nonblank2[blk];
-        bad2[blk] = nonblank2[blk] && (!(r2[blk].flags & FL_VALID) || (r2[blk].flags & FL_DROP));
-        ev_seed[blk] = ci[blk] < t.seed_ci_limit;                  // !(score < 0.28), Program.cs:724
-    }
-    const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
-    if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences
-        if (!dedupe_first(w, L, t2, nonblank2, first2, nblk)) return false;
-    }
-    uint32_t n_dropped = 0;
-    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-        uniq[blk] = first2[blk] && !bad2[blk];
-        n_dropped += popc64(w.ballot(first2[blk] && bad2[blk]));                            // distinct "{n}:invalid_tag" / "{n}:policy_drop"
-        ev_seed[blk] = ev_seed[blk] && first2[blk];
-    }
-
-    w.tick(4);
-    TP_STOP(4, t2[0] ^ t2[1] ^ r2[0].flags ^ r2[1].flags ^ r2[0].next ^ (uint32_t)uniq[0] ^ (uint32_t)uniq[1] ^ (uint32_t)ev_seed[0] ^ (uint32_t)ev_seed[1] ^ (uint32_t)style_cap ^ n_dropped)
-    // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
-    uint32_t t3[2] = {EMPTY_ID, EMPTY_ID};
-    bool ok3[2] = {false, false};
-    uint64_t m_hop3 = 0;
-    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-        t3[blk] = r2[blk].next;
-        bool hop = uniq[blk] && t3[blk] != t2[blk];
-        uint64_t mh = w.ballot(hop);
-        m_hop3 |= mh;
-        uint32_t f3 = r2[blk].flags;
-        if (mh && hop) f3 = t.rec[t3[blk]].flags;
-        ok3[blk] = uniq[blk] && !(f3 & FL_BLANK) && (f3 & FL_VALID) && !(f3 & FL_DROP) && !(f3 & FL_PREFIX);   // AddOne's tests; prefix tags are already in
-    }
-    if (m_hop3) {
-        bool fst[2];
-        if (!dedupe_first(w, L, t3, ok3, fst, nblk)) return false;
-        if (w.ballot((ok3[0] && !fst[0]) || (ok3[1] && !fst[1]))) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
-    }
-    uint32_t nr = t.n_prefix;
-    bool settled = false;
-    // per-position columns of the selected tags' implied tags; they reuse the line buffer, which is not read after S4
-    uint32_t(*kid)[64] = (uint32_t(*)[64])(L.line);
+// The back half of the pipeline for one file, on the selected tags in L.fin[0 .. nr) (with their flags and lengths in
+// L.fattr / L.flen when `settled`): coverage, final-set closure, action rules, required facets, verdict, caption tag ids.
+// kid: the per-position columns of the selected tags' implied tags (settled files only).
+// evidence(n_evidence, ev_feet, ev_penis): the caller's evidence step (it owns the candidates); false = decline the file.
+struct TailIn {
+    uint32_t nr, n, n_selected, n_dropped;
+    bool settled, rejected;
+    uint32_t (*kid)[64];
+};
+template <int NF, class W, class Ev>
+TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, BackLds& L, const uint32_t* rc, const TailIn& in_, Ev& evidence, FastOut& out, uint32_t* fin32,
+                                                   uint32_t* fired, uint16_t* facet_choice) {
+    constexpr uint32_t FIN_MAX = 64u * NF;
+    const uint32_t lane = w.lane();
+    const uint32_t nr = in_.nr, n = in_.n, n_selected = in_.n_selected, n_dropped = in_.n_dropped;
+    bool settled = in_.settled;
+    const bool rejected = in_.rejected;
+    uint32_t(*kid)[64] = in_.kid;
     uint32_t(*kid_attr)[64] = kid + 2;
     uint32_t(*kid_len)[64] = kid + 4;
-    static_assert(sizeof(L.line) >= 6 * 64 * sizeof(uint32_t), "six columns of 64 words");
-    {
-        const int caps[6] = {3, 10, 8, 6, 4, style_cap};
-        bool taken[2] = {false, false};
-        uint32_t pos[2] = {0, 0};
-        for (uint32_t bk = 0; bk <= 6; ++bk) {                    // FillBucket for the six capped buckets in order, then (bk == 6) the final sweep (Program.cs:670-680)
-            bool el0 = ok3[0] && !taken[0] && (bk == 6 || fl_bucket(r2[0].flags) == bk);
-            bool el1 = ok3[1] && !taken[1] && (bk == 6 || fl_bucket(r2[1].flags) == bk);
-            uint64_t m0 = w.ballot(el0), m1 = nblk > 1 ? w.ballot(el1) : 0;
-            uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
-            uint32_t take = popc64(m0) + popc64(m1);
-            if (bk < 6 && take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
-            if (take > room) take = room;
-            uint32_t rank0 = w.rank(m0), rank1 = popc64(m0) + w.rank(m1);
-            if (el0 && rank0 < take) { taken[0] = true; pos[0] = nr + rank0; }
-            if (el1 && rank1 < take) { taken[1] = true; pos[1] = nr + rank1; }
-            nr += take;
-        }
-        // A file is on the settled-tags path when NormalizeTag leaves every selected tag alone and every selected tag's
-        // implied tags are settled leaves (FL_LEAF2): then flags and lengths of everything the final list can hold are known
-        // from records already loaded and from the rule cache, and the rest of the pipeline needs no further table lookups.
-        bool unsettled = false;
-        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk)
-            if (taken[blk] && (r2[blk].next != t2[blk] || ((r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_LEAF2)))) unsettled = true;
-        settled = t.prefix_simple && nr >= 3 && nr <= 64 && !w.ballot(unsettled);
-        if (settled) { kid[0][lane] = NO_ID; kid[1][lane] = NO_ID; }
-        w.sync();
-        if (lane < t.n_prefix) { L.fin[lane] = t.prefix_ids[lane]; L.fattr[lane] = t.prefix_flags[lane]; L.flen[lane] = t.prefix_len[lane]; }
-        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-            if (taken[blk]) {
-                const uint32_t p = pos[blk];
-                L.fin[p] = t3[blk];
-                L.fattr[p] = r2[blk].flags;
-                L.flen[p] = r2[blk].len;
-                if (settled && (r2[blk].flags & FL_EDGE)) {          // its implied tags, for the one closure round of S9
-                    if (r2[blk].step_cnt > 0) { kid[0][p] = r2[blk].step0; kid_attr[0][p] = r2[blk].s0_flags; kid_len[0][p] = r2[blk].s0_len; }
-                    if (r2[blk].step_cnt > 1) { kid[1][p] = r2[blk].step1; kid_attr[1][p] = r2[blk].s1_flags; kid_len[1][p] = r2[blk].s1_len; }
-                }
-            }
-        }
-        w.sync();
-    }
-    const uint32_t n_selected = nr;
 
     w.tick(5);
     TP_STOP(5, L.fin[lane] ^ nr ^ n_selected)
@@ -706,81 +583,9 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
 
     w.tick(6);
     TP_STOP(6, own0 ^ nf ^ coverage ^ flags)
-    // ---- S8: evidence closure (Program.cs:301-302) -> literal bitset, count, feet/penis ---------------------------------------
-    for (uint32_t k = lane; k < t.lit_words; k += 64) L.ebits[k] = 0;
-    w.sync();
     uint32_t n_evidence = 0;
     bool ev_feet = false, ev_penis = false;
-    {
-        uint64_t m_edge = 0;
-        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-            m_edge |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE));
-            if (ev_seed[blk]) {
-                uint32_t li = r2[blk].lit;
-                if (li != NO_ID) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
-                ev_feet |= (r2[blk].flags & FL_NFEET) != 0;         // HasTag(evidenceTags, ...), Program.cs:309, 719
-                ev_penis |= (r2[blk].flags & FL_NPENIS) != 0;
-            }
-        }
-        uint64_t m_far = 0;                                        // seeds whose closure reaches beyond their own two steps
-        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) m_far |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_REACH2));
-        const bool count = fired != nullptr;                       // the size of the evidence set is a detail output: it takes the set to count
-        if (!m_edge) {
-            n_evidence = popc64(w.ballot(ev_seed[0])) + (nblk > 1 ? popc64(w.ballot(ev_seed[1])) : 0);
-        } else if (!count && !m_far) {
-            // literals and the two probes of the seeds' implied tags straight from the seeds' records
-            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
-                if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
-                    const uint32_t i0 = r2[blk].step_cnt > 0 ? r2[blk].s0_info : 0xFFFFFFu, i1 = r2[blk].step_cnt > 1 ? r2[blk].s1_info : 0xFFFFFFu;
-                    if ((i0 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i0 & 0xFFFFFFu) >> 5], 1u << (i0 & 31));
-                    if ((i1 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i1 & 0xFFFFFFu) >> 5], 1u << (i1 & 31));
-                    ev_feet |= ((i0 | i1) >> 24) & 1u;
-                    ev_penis |= ((i0 | i1) >> 25) & 1u;
-                }
-            }
-        } else {
-            if (m_far && !t.closure_tables) return false;
-            set_clear(w, L);
-            uint32_t made = 0;
-            bool full = false;
-            for (int blk = 0; blk < 2; ++blk) {
-                if (ev_seed[blk]) {
-                    bool created;
-                    if (set_put(w, L, t2[blk], 0, created) == NO_ID) full = true;
-                    made += created;
-                }
-            }
-            w.sync();
-            auto add = [&](uint32_t id, uint32_t info) {            // one member of a seed's closure
-                bool created;
-                if (set_put(w, L, id, 0, created) == NO_ID) { full = true; return; }
-                if (created) {
-                    ++made;
-                    const uint32_t li = info & 0xFFFFFFu;
-                    if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
-                }
-                ev_feet |= (info >> 24) & 1u;
-                ev_penis |= (info >> 25) & 1u;
-            };
-            for (int blk = 0; blk < 2; ++blk) {
-                if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
-                    if (r2[blk].flags & FL_REACH2) {                // the usual case: the record itself lists the closure
-                        if (r2[blk].step_cnt > 0) add(r2[blk].step0, r2[blk].s0_info);
-                        if (r2[blk].step_cnt > 1) add(r2[blk].step1, r2[blk].s1_info);
-                    } else {
-                        for (uint32_t m = t.reach_off[t2[blk]]; m < t.reach_off[t2[blk] + 1] && !full; ++m) add(t.reach_ent[2 * m], t.reach_ent[2 * m + 1]);
-                    }
-                }
-            }
-            if (w.ballot(full)) return false;
-            n_evidence = w.sum(made);
-            if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
-        }
-        if (!count) n_evidence = 0xFFFF;
-        ev_feet = w.ballot(ev_feet) != 0;
-        ev_penis = w.ballot(ev_penis) != 0;
-        w.sync();
-    }
+    if (!evidence(n_evidence, ev_feet, ev_penis)) return false;
 
     w.tick(7);
     TP_STOP(7, own0 ^ nf ^ n_evidence ^ (uint32_t)ev_feet ^ (uint32_t)ev_penis ^ L.ebits[lane])
@@ -1095,6 +900,260 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     out.n_final = nc;
     out.caption_len = bytes + (nc ? 2 * (nc - 1) : 0) + t.newline_len;
     return out.caption_len <= FAST_CAPTION_MAX;
+}
+
+// The pipeline for one file.  Returns false when the file needs the general kernel.
+// NT = 1: at most 64 tokens (so candidates), one per lane; NT = 2: 128, two per lane.  NF likewise for the final tags.
+// Fewer per lane means fewer registers and less work per wavefront.
+// rc: the rule cache (DevTables::rc, or a copy of it in faster memory); cls: byte_class() of 0..255 as a table.
+// fin32: where the caption's tag ids go (FAST_FIN_MAX entries); fired / facet_choice may be null.
+template <int NT, int NF, class W>
+TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
+                     uint32_t* fired, uint16_t* facet_choice) {
+    static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
+    constexpr uint32_t FIN_MAX = 64u * NF;
+    const uint32_t lane = w.lane();
+    Scan sc;
+    if (!scan_line(w, L, cls, text, len, sc)) return false;
+    const uint8_t* s = sc.s;
+    const uint32_t a = sc.a, b = sc.b, ncomma = sc.ncomma;
+    const bool rejected = sc.rejected;
+    const uint32_t T = ncomma + 1;
+    if (T > 64u * NT) return false;
+    w.tick(2);
+    TP_STOP(2, a ^ b ^ ncomma ^ T ^ (uint32_t)rejected ^ L.cpos[lane] ^ L.tspec[lane & 3])
+
+    // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
+    // A token's lane stays its candidate's lane: candidate index = number of kept tokens before it.
+    const int nblk = NT == 1 ? 1 : (T > 64 ? 2 : 1);              // tokens (and so candidates) sit two per lane only in long lines
+    uint32_t n = 0;
+    bool act[2] = {false, false};
+    uint32_t h1[2] = {EMPTY_ID, EMPTY_ID}, ci[2] = {0, 0};
+    Rec r1[2];
+    r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
+    {
+        bool keep[2] = {false, false};
+        bool dyn_survivor = false;
+        if (!rejected) {
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                uint32_t tix = (uint32_t)blk * 64 + lane;
+                if (tix < T) {
+                    uint32_t i = tix == 0 ? a : (uint32_t)L.cpos[tix - 1] + 1;
+                    uint32_t j = tix == T - 1 ? b : (uint32_t)L.cpos[tix];
+                    uint32_t id = NO_ID, dlen = 0;
+                    bool vdyn = false;
+                    const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u, high = (L.thigh[tix >> 5] >> (tix & 31)) & 1u;
+                    Rec rr;
+                    int kind = fast_token(t, s, i, j, special, high, id, rr, vdyn, dlen);
+                    if (kind == 1) {
+                        if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) { h1[blk] = id; r1[blk] = rr; keep[blk] = true; }
+                    } else if (kind == 3) {
+                        dyn_survivor = true;                       // declines the file below
+                    } else if (kind == 2) {
+                        // a string outside the tables: gone under strict vocabulary, too short, or invalid; anything else may survive
+                        if (!t.drop_unknown && dlen >= 2 && vdyn) dyn_survivor = true;
+                    }
+                }
+            }
+        }
+        if (w.ballot(dyn_survivor)) return false;
+        if (!dedupe_first(w, L, h1, keep, act, nblk)) return false;
+        const uint64_t m0 = w.ballot(act[0]), m1 = nblk > 1 ? w.ballot(act[1]) : 0;
+        n = popc64(m0) + popc64(m1);
+        ci[0] = w.rank(m0);
+        ci[1] = popc64(m0) + w.rank(m1);
+        if (!act[0]) { h1[0] = EMPTY_ID; r1[0] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
+        if (!act[1]) { h1[1] = EMPTY_ID; r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
+    }
+
+    w.tick(3);
+    TP_STOP(3, h1[0] ^ h1[1] ^ r1[0].flags ^ r1[0].next ^ r1[1].flags ^ r1[0].lit ^ r1[0].step0 ^ ci[0] ^ ci[1] ^ n ^ (uint32_t)act[0] ^ (uint32_t)act[1])
+    // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
+    // In line ingest the scores fall with the candidate index, so "sorted" order is candidate order and the first of
+    // two candidates that NormalizeTag merges carries the merged score, order and source.
+    bool nonblank2[2] = {false, false}, first2[2] = {false, false}, bad2[2] = {false, false}, uniq[2] = {false, false}, ev_seed[2] = {false, false};
+    uint32_t t2[2] = {EMPTY_ID, EMPTY_ID};
+    Rec r2[2];
+    r2[0] = r1[0]; r2[1] = r1[1];
+    uint32_t style_n = 0;
+    uint64_t m_hop2 = 0;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+        t2[blk] = r1[blk].next;
+        bool hop = act[blk] && t2[blk] != h1[blk];
+        uint64_t mh = w.ballot(hop);
+        m_hop2 |= mh;
+        if (mh && hop) r2[blk] = t.rec[t2[blk]];
+        style_n += popc64(w.ballot(act[blk] && fl_bucket(r1[blk].flags) == B_STYLE && ci[blk] < t.style_ci_limit));   // DetermineStyleQualityCap, Program.cs:702-710
+        nonblank2[blk] = act[blk] && !(r2[blk].flags & FL_BLANK);
+        first2[blk] = nonblank2[blk];
+        bad2[blk] = nonblank2[blk] && (!(r2[blk].flags & FL_VALID) || (r2[blk].flags & FL_DROP));
+        ev_seed[blk] = ci[blk] < t.seed_ci_limit;                  // !(score < 0.28), Program.cs:724
+    }
+    const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
+    if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences
+        if (!dedupe_first(w, L, t2, nonblank2, first2, nblk)) return false;
+    }
+    uint32_t n_dropped = 0;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+        uniq[blk] = first2[blk] && !bad2[blk];
+        n_dropped += popc64(w.ballot(first2[blk] && bad2[blk]));                            // distinct "{n}:invalid_tag" / "{n}:policy_drop"
+        ev_seed[blk] = ev_seed[blk] && first2[blk];
+    }
+
+    w.tick(4);
+    TP_STOP(4, t2[0] ^ t2[1] ^ r2[0].flags ^ r2[1].flags ^ r2[0].next ^ (uint32_t)uniq[0] ^ (uint32_t)uniq[1] ^ (uint32_t)ev_seed[0] ^ (uint32_t)ev_seed[1] ^ (uint32_t)style_cap ^ n_dropped)
+    // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
+    uint32_t t3[2] = {EMPTY_ID, EMPTY_ID};
+    bool ok3[2] = {false, false};
+    uint64_t m_hop3 = 0;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+        t3[blk] = r2[blk].next;
+        bool hop = uniq[blk] && t3[blk] != t2[blk];
+        uint64_t mh = w.ballot(hop);
+        m_hop3 |= mh;
+        uint32_t f3 = r2[blk].flags;
+        if (mh && hop) f3 = t.rec[t3[blk]].flags;
+        ok3[blk] = uniq[blk] && !(f3 & FL_BLANK) && (f3 & FL_VALID) && !(f3 & FL_DROP) && !(f3 & FL_PREFIX);   // AddOne's tests; prefix tags are already in
+    }
+    if (m_hop3) {
+        bool fst[2];
+        if (!dedupe_first(w, L, t3, ok3, fst, nblk)) return false;
+        if (w.ballot((ok3[0] && !fst[0]) || (ok3[1] && !fst[1]))) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
+    }
+    uint32_t nr = t.n_prefix;
+    bool settled = false;
+    // per-position columns of the selected tags' implied tags; they reuse the line buffer, which is not read after S4
+    uint32_t(*kid)[64] = (uint32_t(*)[64])(L.line);
+    uint32_t(*kid_attr)[64] = kid + 2;
+    uint32_t(*kid_len)[64] = kid + 4;
+    static_assert(sizeof(L.line) >= 6 * 64 * sizeof(uint32_t), "six columns of 64 words");
+    {
+        const int caps[6] = {3, 10, 8, 6, 4, style_cap};
+        bool taken[2] = {false, false};
+        uint32_t pos[2] = {0, 0};
+        for (uint32_t bk = 0; bk <= 6; ++bk) {                    // FillBucket for the six capped buckets in order, then (bk == 6) the final sweep (Program.cs:670-680)
+            bool el0 = ok3[0] && !taken[0] && (bk == 6 || fl_bucket(r2[0].flags) == bk);
+            bool el1 = ok3[1] && !taken[1] && (bk == 6 || fl_bucket(r2[1].flags) == bk);
+            uint64_t m0 = w.ballot(el0), m1 = nblk > 1 ? w.ballot(el1) : 0;
+            uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
+            uint32_t take = popc64(m0) + popc64(m1);
+            if (bk < 6 && take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
+            if (take > room) take = room;
+            uint32_t rank0 = w.rank(m0), rank1 = popc64(m0) + w.rank(m1);
+            if (el0 && rank0 < take) { taken[0] = true; pos[0] = nr + rank0; }
+            if (el1 && rank1 < take) { taken[1] = true; pos[1] = nr + rank1; }
+            nr += take;
+        }
+        // A file is on the settled-tags path when NormalizeTag leaves every selected tag alone and every selected tag's
+        // implied tags are settled leaves (FL_LEAF2): then flags and lengths of everything the final list can hold are known
+        // from records already loaded and from the rule cache, and the rest of the pipeline needs no further table lookups.
+        bool unsettled = false;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk)
+            if (taken[blk] && (r2[blk].next != t2[blk] || ((r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_LEAF2)))) unsettled = true;
+        settled = t.prefix_simple && nr >= 3 && nr <= 64 && !w.ballot(unsettled);
+        if (settled) { kid[0][lane] = NO_ID; kid[1][lane] = NO_ID; }
+        w.sync();
+        if (lane < t.n_prefix) { L.fin[lane] = t.prefix_ids[lane]; L.fattr[lane] = t.prefix_flags[lane]; L.flen[lane] = t.prefix_len[lane]; }
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+            if (taken[blk]) {
+                const uint32_t p = pos[blk];
+                L.fin[p] = t3[blk];
+                L.fattr[p] = r2[blk].flags;
+                L.flen[p] = r2[blk].len;
+                if (settled && (r2[blk].flags & FL_EDGE)) {          // its implied tags, for the one closure round of S9
+                    if (r2[blk].step_cnt > 0) { kid[0][p] = r2[blk].step0; kid_attr[0][p] = r2[blk].s0_flags; kid_len[0][p] = r2[blk].s0_len; }
+                    if (r2[blk].step_cnt > 1) { kid[1][p] = r2[blk].step1; kid_attr[1][p] = r2[blk].s1_flags; kid_len[1][p] = r2[blk].s1_len; }
+                }
+            }
+        }
+        w.sync();
+    }
+    const uint32_t n_selected = nr;
+
+    // ---- S8: evidence closure (Program.cs:301-302) -> literal bitset, count, feet/penis; the back half runs it after the
+    // coverage step, as the reference does ---------------------------------------------------------------------------------
+    auto evidence = [&](uint32_t& n_evidence, bool& ev_feet, bool& ev_penis) -> bool {
+    for (uint32_t k = lane; k < t.lit_words; k += 64) L.ebits[k] = 0;
+    w.sync();
+    n_evidence = 0;
+    ev_feet = false; ev_penis = false;
+    {
+        uint64_t m_edge = 0;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+            m_edge |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE));
+            if (ev_seed[blk]) {
+                uint32_t li = r2[blk].lit;
+                if (li != NO_ID) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                ev_feet |= (r2[blk].flags & FL_NFEET) != 0;         // HasTag(evidenceTags, ...), Program.cs:309, 719
+                ev_penis |= (r2[blk].flags & FL_NPENIS) != 0;
+            }
+        }
+        uint64_t m_far = 0;                                        // seeds whose closure reaches beyond their own two steps
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) m_far |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_REACH2));
+        const bool count = fired != nullptr;                       // the size of the evidence set is a detail output: it takes the set to count
+        if (!m_edge) {
+            n_evidence = popc64(w.ballot(ev_seed[0])) + (nblk > 1 ? popc64(w.ballot(ev_seed[1])) : 0);
+        } else if (!count && !m_far) {
+            // literals and the two probes of the seeds' implied tags straight from the seeds' records
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
+                    const uint32_t i0 = r2[blk].step_cnt > 0 ? r2[blk].s0_info : 0xFFFFFFu, i1 = r2[blk].step_cnt > 1 ? r2[blk].s1_info : 0xFFFFFFu;
+                    if ((i0 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i0 & 0xFFFFFFu) >> 5], 1u << (i0 & 31));
+                    if ((i1 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i1 & 0xFFFFFFu) >> 5], 1u << (i1 & 31));
+                    ev_feet |= ((i0 | i1) >> 24) & 1u;
+                    ev_penis |= ((i0 | i1) >> 25) & 1u;
+                }
+            }
+        } else {
+            if (m_far && !t.closure_tables) return false;
+            set_clear(w, L);
+            uint32_t made = 0;
+            bool full = false;
+            for (int blk = 0; blk < 2; ++blk) {
+                if (ev_seed[blk]) {
+                    bool created;
+                    if (set_put(w, L, t2[blk], 0, created) == NO_ID) full = true;
+                    made += created;
+                }
+            }
+            w.sync();
+            auto add = [&](uint32_t id, uint32_t info) {            // one member of a seed's closure
+                bool created;
+                if (set_put(w, L, id, 0, created) == NO_ID) { full = true; return; }
+                if (created) {
+                    ++made;
+                    const uint32_t li = info & 0xFFFFFFu;
+                    if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                }
+                ev_feet |= (info >> 24) & 1u;
+                ev_penis |= (info >> 25) & 1u;
+            };
+            for (int blk = 0; blk < 2; ++blk) {
+                if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
+                    if (r2[blk].flags & FL_REACH2) {                // the usual case: the record itself lists the closure
+                        if (r2[blk].step_cnt > 0) add(r2[blk].step0, r2[blk].s0_info);
+                        if (r2[blk].step_cnt > 1) add(r2[blk].step1, r2[blk].s1_info);
+                    } else {
+                        for (uint32_t m = t.reach_off[t2[blk]]; m < t.reach_off[t2[blk] + 1] && !full; ++m) add(t.reach_ent[2 * m], t.reach_ent[2 * m + 1]);
+                    }
+                }
+            }
+            if (w.ballot(full)) return false;
+            n_evidence = w.sum(made);
+            if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
+        }
+        if (!count) n_evidence = 0xFFFF;
+        ev_feet = w.ballot(ev_feet) != 0;
+        ev_penis = w.ballot(ev_penis) != 0;
+        w.sync();
+    }
+    return true;
+    };
+
+    TailIn ti;
+    ti.nr = nr; ti.n = n; ti.n_selected = n_selected; ti.n_dropped = n_dropped;
+    ti.settled = settled; ti.rejected = rejected; ti.kid = kid;
+    return fast_tail<NF>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice);
 }
 
 }  // namespace tp
