@@ -71,7 +71,7 @@ struct tp_ctx {
     HostTables ht;
     DevTables dt;
     std::vector<void*> table_mem;
-    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list1, scalars, workspace;
+    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list1, slow_list2, scalars, workspace;
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
     std::vector<hipEvent_t> events;
@@ -83,7 +83,7 @@ struct tp_ctx {
     ~tp_ctx() {
         (void)hipSetDevice(device);
         for (void* p : table_mem) (void)hipFree(p);
-        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list1, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
+        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -132,19 +132,24 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         c->fin32.need(n * fast_fin_stride() * 4);
         c->slow_list.need(n * 4);
         c->slow_list1.need(n * 4);
+        c->slow_list2.need(n * 4);
         uint32_t* d_slow_count1 = d_slow_count + 1;
-        HIP_OK(hipMemsetAsync(d_slow_count, 0, 8, s));
+        uint32_t* d_slow_count2 = d_slow_count + 2;
+        HIP_OK(hipMemsetAsync(d_slow_count, 0, 12, s));
         FastArgs fa{};
         fa.arena = io.arena; fa.offsets = io.offsets; fa.file0 = f0; fa.file_end = f1;
         fa.verdicts = io.verdicts; fa.n_final = n_final; fa.cap_len = cap_len; fa.fin32 = c->fin32.as<uint32_t>(); fa.slot_of = slot_of;
         fa.fired = io.fired; fa.facet_choice = io.facet_choice;
         hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
         HIP_OK(hipEventRecord(p0, s));
-        // first stage: one element per lane; what it declines goes through the second stage (two per lane), and what that
-        // declines to the general kernel.  The second launch learns its item count on the device.
-        fa.slow_list = c->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1; fa.item_list = nullptr; fa.item_count = nullptr;
+        // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
+        // through the long-file stage, and what is left to the general kernel.  Later stages learn their item counts on the device.
+        fa.stage = 1; fa.slow_list = c->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1; fa.item_list = nullptr; fa.item_count = nullptr;
         HIP_OK(launch_fast(c->dt, fa, s));
-        fa.item_list = c->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
+        fa.stage = 2; fa.item_list = c->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
+        fa.slow_list = c->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
+        HIP_OK(launch_fast(c->dt, fa, s));
+        fa.stage = 3; fa.item_list = c->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
         fa.slow_list = c->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
         HIP_OK(launch_fast(c->dt, fa, s));
         HIP_OK(hipEventRecord(p1, s));

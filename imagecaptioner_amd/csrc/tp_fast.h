@@ -1156,4 +1156,185 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     return fast_tail<NF>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice);
 }
 
+// ================================================================================================================
+// Long files: up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes.  The candidates live in LDS arrays indexed by token and
+// are walked 64 at a time; the back half is the same as for short files.  Taken only when NormalizeTag leaves every
+// candidate alone (otherwise two candidates may merge, which this path does not follow): everything else goes to the
+// general kernel.
+// ================================================================================================================
+constexpr uint32_t LONG_LINE_MAX = 8192;
+constexpr uint32_t LONG_TOK_MAX = 1024;
+constexpr uint32_t LONG_SET_SLOTS = 2048;
+
+struct alignas(16) LongLds : LineLds<LONG_LINE_MAX, LONG_TOK_MAX> {
+    uint32_t big_key[LONG_SET_SLOTS];    // token ids, for the first-occurrence filter (Distinct, Program.cs:602)
+    uint32_t big_min[LONG_SET_SLOTS];    // ... smallest token index per id
+    uint32_t c_id[LONG_TOK_MAX];         // per token: the id NormalizeTag gives it, NO_ID when it is no candidate (any more)
+    uint32_t c_fl[LONG_TOK_MAX];         // that string's flags
+    uint16_t c_len[LONG_TOK_MAX];        // its byte length
+    uint16_t c_slot[LONG_TOK_MAX];       // its slot in the big set
+};
+
+template <class W>
+TP_HD uint32_t big_put(W& w, LongLds& L, uint32_t key, uint32_t order) {
+    uint32_t s = (key * 2654435761u) >> 21;                        // 11 bits
+    for (uint32_t probe = 0; probe < LONG_SET_SLOTS; ++probe) {
+        uint32_t old = w.lds_cas(&L.big_key[s], NO_ID, key);
+        if (old == NO_ID || old == key) { w.lds_min(&L.big_min[s], order); return s; }
+        s = (s + 1) & (LONG_SET_SLOTS - 1);
+    }
+    return NO_ID;
+}
+
+template <class W>
+TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
+                     uint32_t* fired, uint16_t* facet_choice) {
+    const uint32_t lane = w.lane();
+    Scan sc;
+    if (!scan_line(w, L, cls, text, len, sc)) return false;
+    const uint8_t* s = sc.s;
+    const uint32_t T = sc.ncomma + 1;
+    if (T > LONG_TOK_MAX) return false;
+    static_assert(LONG_SET_SLOTS == 2048, "32 words per lane and array");
+    for (uint32_t k = 0; k < 8; ++k) { w.fill16(&L.big_key[256 * k + 4 * lane], 0xFFFFFFFFu); w.fill16(&L.big_min[256 * k + 4 * lane], 0xFFFFFFFFu); }
+    w.sync();
+
+    // ---- tokens -> ids (Program.cs:598-602), 64 at a time -------------------------------------------------------------------
+    bool decline = false;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t tix = base + lane;
+        uint32_t cid = NO_ID;
+        if (tix < T && !sc.rejected) {
+            const uint32_t i = tix == 0 ? sc.a : (uint32_t)L.cpos[tix - 1] + 1;
+            const uint32_t j = tix == T - 1 ? sc.b : (uint32_t)L.cpos[tix];
+            uint32_t id = NO_ID, dlen = 0;
+            bool vdyn = false;
+            const bool special = (L.tspec[tix >> 5] >> (tix & 31)) & 1u, high = (L.thigh[tix >> 5] >> (tix & 31)) & 1u;
+            Rec rr;
+            const int kind = fast_token(t, s, i, j, special, high, id, rr, vdyn, dlen);
+            if (kind == 1) {
+                if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) {
+                    if (rr.next != id) decline = true;             // NormalizeTag would change it again
+                    const uint32_t slot = big_put(w, L, id, tix);
+                    if (slot == NO_ID) decline = true;
+                    cid = id;
+                    L.c_fl[tix] = rr.flags;
+                    L.c_len[tix] = (uint16_t)rr.len;
+                    L.c_slot[tix] = (uint16_t)slot;
+                    if (rr.len > 0xFFFFu) decline = true;
+                }
+            } else if (kind == 3) {
+                decline = true;
+            } else if (kind == 2) {
+                if (!t.drop_unknown && dlen >= 2 && vdyn) decline = true;   // a string outside the tables would survive
+            }
+        }
+        if (tix < LONG_TOK_MAX) L.c_id[tix] = cid;
+    }
+    if (w.ballot(decline)) return false;
+    w.sync();
+
+    // ---- candidates in order: first occurrences; dropped-tag count, style cap, evidence (Program.cs:625-655, 702-710, 721-729) ---
+    const bool count = fired != nullptr;
+    for (uint32_t k = lane; k < t.lit_words; k += 64) L.ebits[k] = 0;
+    set_clear(w, L);                                               // the evidence set, when it is to be counted
+    uint32_t n = 0, n_dropped = 0, style_n = 0, made = 0;
+    bool ev_feet = false, ev_penis = false, full = false, far_no_table = false;
+    uint64_t any_edge = 0;
+    for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t tix = base + lane;
+        const uint32_t id = tix < T ? L.c_id[tix] : NO_ID;
+        const bool act = id != NO_ID && L.big_min[L.c_slot[tix]] == tix;
+        const uint32_t f = act ? L.c_fl[tix] : (uint32_t)FL_BLANK;
+        const uint64_t m = w.ballot(act);
+        const uint32_t ci = n + w.rank(m);
+        n += popc64(m);
+        const bool nonblank = act && !(f & FL_BLANK);
+        const bool bad = nonblank && (!(f & FL_VALID) || (f & FL_DROP));
+        n_dropped += popc64(w.ballot(bad));
+        style_n += popc64(w.ballot(act && fl_bucket(f) == B_STYLE && ci < t.style_ci_limit));
+        const bool ok = nonblank && !bad && !(f & FL_PREFIX);      // AddOne's tests; prefix tags are already in
+        if (tix < T && !ok) L.c_id[tix] = NO_ID;                  // from here on c_id holds what the bucket fills may take
+        const bool seed = nonblank && ci < t.seed_ci_limit;        // !(score < 0.28), Program.cs:724
+        const uint64_t m_seed = w.ballot(seed);
+        if (m_seed) {
+            Rec r;
+            r.flags = 0; r.lit = NO_ID; r.step_cnt = 0;
+            if (seed) r = t.rec[id];
+            if (seed) {
+                if (r.lit != NO_ID) w.lds_or(&L.ebits[r.lit >> 5], 1u << (r.lit & 31));
+                ev_feet |= (r.flags & FL_NFEET) != 0;
+                ev_penis |= (r.flags & FL_NPENIS) != 0;
+            }
+            const bool edge = seed && (r.flags & FL_EDGE);
+            any_edge |= w.ballot(edge);
+            auto add = [&](uint32_t x, uint32_t info) {            // one member of a seed's closure
+                bool created = true;
+                if (count) { if (set_put(w, L, x, 0, created) == NO_ID) { full = true; return; } }
+                if (created) {
+                    ++made;
+                    const uint32_t li = info & 0xFFFFFFu;
+                    if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                }
+                ev_feet |= (info >> 24) & 1u;
+                ev_penis |= (info >> 25) & 1u;
+            };
+            if (count && seed) { bool created; if (set_put(w, L, id, 0, created) == NO_ID) full = true; made += created; }
+            w.sync();
+            if (edge) {
+                if (r.flags & FL_REACH2) {
+                    if (r.step_cnt > 0) add(r.step0, r.s0_info);
+                    if (r.step_cnt > 1) add(r.step1, r.s1_info);
+                } else if (!t.closure_tables) {
+                    far_no_table = true;
+                } else {
+                    for (uint32_t q = t.reach_off[id]; q < t.reach_off[id + 1] && !full; ++q) add(t.reach_ent[2 * q], t.reach_ent[2 * q + 1]);
+                }
+            }
+        }
+    }
+    if (w.ballot(full || far_no_table)) return false;
+    uint32_t n_evidence = 0xFFFF;
+    if (count) {
+        n_evidence = w.sum(made);
+        if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
+    }
+    ev_feet = w.ballot(ev_feet) != 0;
+    ev_penis = w.ballot(ev_penis) != 0;
+    w.sync();
+
+    // ---- bucket fills (Program.cs:661-699): every bucket walks the candidates in order -------------------------------------------
+    const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
+    const int caps[6] = {3, 10, 8, 6, 4, style_cap};
+    uint32_t nr = t.n_prefix;
+    if (lane < t.n_prefix) { L.fin[lane] = t.prefix_ids[lane]; L.fattr[lane] = t.prefix_flags[lane]; L.flen[lane] = t.prefix_len[lane]; }
+    for (uint32_t bk = 0; bk <= 6; ++bk) {
+        uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
+        uint32_t rem = bk < 6 ? ((uint32_t)caps[bk] < room ? (uint32_t)caps[bk] : room) : room;
+        for (uint32_t base = 0; base < T && rem; base += 64) {
+            const uint32_t tix = base + lane;
+            const uint32_t id = tix < T ? L.c_id[tix] : NO_ID;
+            const uint32_t f = id != NO_ID ? L.c_fl[tix] : 0;
+            const bool el = id != NO_ID && (bk == 6 || fl_bucket(f) == bk);
+            const uint64_t m = w.ballot(el);
+            const uint32_t avail = popc64(m), take = avail < rem ? avail : rem;
+            const uint32_t rank = w.rank(m);
+            if (el && rank < take) {
+                const uint32_t p = nr + rank;
+                L.fin[p] = id; L.fattr[p] = f; L.flen[p] = L.c_len[tix];
+                L.c_id[tix] = NO_ID;                               // taken
+            }
+            nr += take;
+            rem -= take;
+        }
+    }
+    w.sync();
+
+    auto evidence = [&](uint32_t& ne, bool& feet, bool& penis) -> bool { ne = n_evidence; feet = ev_feet; penis = ev_penis; return true; };
+    TailIn ti;
+    ti.nr = nr; ti.n = n; ti.n_selected = nr; ti.n_dropped = n_dropped;
+    ti.settled = false; ti.rejected = sc.rejected; ti.kid = nullptr;
+    return fast_tail<2>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice);
+}
+
 }  // namespace tp

@@ -135,6 +135,41 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
 }
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t, FastArgs a) { fast_body<2>(t, a); }
 
+// Third stage: the files the second declined, up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes; one wavefront per block.
+__global__ __launch_bounds__(64) void k_long(DevTables t, FastArgs a) {
+    __shared__ LongLds L;
+    __shared__ uint8_t cls[256];
+    extern __shared__ uint32_t rc_lds[];
+    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
+    __syncthreads();
+    DevWave w;
+    const uint64_t n_items = (uint64_t)*a.item_count;
+    for (uint64_t i = blockIdx.x; i < n_items; i += gridDim.x) {
+        const uint64_t f = a.file0 + a.item_list[i];
+        uint64_t o = a.offsets[f];
+        uint64_t len64 = a.offsets[f + 1] - o;
+        bool done = false;
+        FastOut out;
+        if (len64 <= LONG_LINE_MAX) {
+            done = long_file(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
+                             a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+        }
+        if (w.lane() == 0) {
+            if (done) {
+                a.verdicts[f] = out.verdict;
+                a.n_final[f] = out.n_final;
+                a.cap_len[f] = out.caption_len;
+                a.slot_of[f] = SLOT_FAST;
+            } else {
+                uint32_t k = atomicAdd(a.slow_count, 1u);
+                a.slow_list[k] = (uint32_t)(f - a.file0);
+            }
+        }
+        w.sync();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_wave_sizes
 // ------------------------------------------------------------------------------------------------
@@ -482,7 +517,8 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint64_t want = (n + FAST_WAVES_PER_BLOCK - 1) / FAST_WAVES_PER_BLOCK;
     unsigned blocks = (unsigned)(want < 256 * 8 ? want : 256 * 8);    // up to 8 blocks per CU, wavefronts stride over the files
-    if (a.item_list) hipLaunchKernelGGL(k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    if (a.stage == 3) hipLaunchKernelGGL(k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
+    else if (a.stage == 2) hipLaunchKernelGGL(k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     return hipGetLastError();
 }

@@ -22,8 +22,9 @@ struct FastArgs {
     uint32_t* slot_of;            // per file: SLOT_FAST, or (set later) its position in the general kernel's item list
     uint32_t* slow_list;          // files (relative to file0) this launch declines, in no particular order
     uint32_t* slow_count;
-    const uint32_t* item_list;    // null: first stage over the whole range; else the files (relative to file0) the first stage declined:
-    const uint32_t* item_count;   //   second stage (two elements per lane) over *item_count of them
+    const uint32_t* item_list;    // null: first stage over the whole range; else the files (relative to file0) the stage before declined:
+    const uint32_t* item_count;   //   *item_count of them (read on the device)
+    int stage;                    // 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)
     uint32_t* fired;
     uint16_t* facet_choice;
 };

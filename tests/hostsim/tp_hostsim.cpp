@@ -186,6 +186,7 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
         const uint8_t* text = arena + offsets[f];
         uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
         bool ok = t.fast_ok && len <= FAST_LINE_MAX;
+        bool try_long = t.fast_ok && len <= LONG_LINE_MAX;
         if (ok) {
             // first stage (one element per lane), then the second (two per lane) for what the first declines
             for (int stage = 1; stage <= 2; ++stage) {
@@ -200,6 +201,17 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
                 for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the fast-path verdict"; }
                 if (done[0]) break;
             }
+            ok = done[0];
+        }
+        if (!ok && try_long) {                                       // third stage: long files
+            static LongLds big;
+            std::memset((void*)&big, 0xCD, sizeof big);
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                done[lane] = long_file(w, t, big, t.rc, cls_table(), text, len, outs[lane], fin32.data(), o->fired.data() + f * t.fired_words,
+                                       t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
+            });
+            for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the long-file verdict"; }
             ok = done[0];
         }
         size_t before = o->captions.size();

@@ -94,6 +94,21 @@ def test_non_ascii_is_reported_not_guessed():
     assert r.caption(1) == b"" and r.caption(2) == b"" and r.counters["unsupported"] == 2
 
 
+def test_long_files():
+    from test_pipeline_logic_cpu import long_lines
+    cfg = shipped_config()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    lines = long_lines(7, 200)
+    got, want = p.run_texts(lines), o.run_texts(lines)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "long lines")
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus("c5", 3000, seed=5)
+    cfg = Config(**c.config_kwargs)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    got, want = p.run_lines(c.arena, c.offsets), o.run_lines(c.arena, c.offsets, threads=8)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "c5")
+
+
 def test_known_non_ascii_tags_pass_through_the_wave_kernel():
     cfg = non_ascii_config()
     check_non_ascii(pipe_for(cfg).run_texts, Oracle(cfg))

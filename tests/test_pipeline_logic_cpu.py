@@ -4,6 +4,7 @@ tests/hostsim compiles imagecaptioner_amd/csrc/tp_pipeline.h and the table compi
 the product library never does) and runs files through the same lane-interleaved workspace layout the kernel
 uses.  Results must be bit-identical to the oracle's.
 """
+import os
 import random
 
 import numpy as np
@@ -112,6 +113,37 @@ def test_non_ascii_is_reported_not_guessed():
     assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
     assert r.caption(1) == b"" and r.caption(2) == b""
     assert r.counters["unsupported"] == 2
+
+
+def long_lines(seed, count):
+    """Lines of 65 .. 1025 tokens from the shipped vocabulary, with repeats, unknown tags, upper case and odd spacing."""
+    import random
+    vocab = [l.strip() for l in open(os.path.join(DATA, "top_tags.txt"), encoding="utf-8") if l.strip()]
+    rng = random.Random(seed)
+    lines = []
+    for _ in range(count):
+        n = rng.choice([65, 100, 129, 200, 400, 700, 1000, 1024, 1025])
+        toks = []
+        for _i in range(n):
+            r = rng.random()
+            if r < 0.85: tok = rng.choice(vocab[:3000])
+            elif r < 0.92: tok = rng.choice(toks) if toks else "smile"
+            elif r < 0.96: tok = "zz_unknown_%d" % rng.randrange(50)
+            else: tok = rng.choice(vocab).upper()
+            toks.append(tok)
+        lines.append(rng.choice([", ", ",", " , ", ",  "]).join(toks) + rng.choice(["", "\n", "  \n"]))
+    return lines
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict"])
+def test_long_files_take_the_long_wave_stage(name):
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    lines = long_lines(3, 60)
+    want, got = o.run_texts(lines), s.run_texts_fast(lines)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name + " long")
+    if name == "shipped":
+        assert got.n_general < len(lines) // 2      # most of them fit the long-file stage
 
 
 def test_known_non_ascii_tags_pass_through_the_wave_kernel():

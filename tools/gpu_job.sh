@@ -6,3 +6,5 @@ timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 echo tests-done
 timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo bench-done
+timeout -k 10 300 python3 bench.py --config c5 --files 200000 --steps 5 --warmup 1 --cpu-sample 0 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err
+echo c5-done
