@@ -312,9 +312,9 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
 // ------------------------------------------------------------------------------------------------
 // k_emit
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t HOT_IDS = 24576;    // ids below this are counted in LDS (96 KB: global atomics are what this kernel can least afford);
-                                       // the table compiler gives the frequent tags the low ids
-constexpr int EMIT_WAVES = 16;          // wavefronts (files in flight) per block of the staged emit kernel, one block per CU
+constexpr int EMIT_WAVES = 4;           // wavefronts (files in flight) per block of the staged emit kernel
+constexpr uint32_t HIST_IDS = 65536;    // ids one histogram pass counts in LDS: 16-bit counters, two to a word (128 KB)
+constexpr uint32_t HIST_FILES_PER_FLUSH = 60000;   // files a block counts before its 16-bit counters are flushed
 constexpr uint32_t EMIT_STAGE = FAST_CAPTION_MAX;   // captions are put together in LDS and stored 16 bytes per lane
 
 struct EmitCounts {
@@ -341,16 +341,12 @@ struct EmitCounts {
 // One wavefront per file.  The caption is put together in LDS at the same 16-byte phase as its place in the output,
 // then stored with aligned 16-byte stores.  Two files ahead the wave loads a file's sizes and tag ids, one file ahead
 // the tags' string offsets, so that the dependent loads of three files are in flight at once.
-__global__ __launch_bounds__(64 * EMIT_WAVES) void k_emit(DevTables t, EmitArgs a) {
-    __shared__ uint32_t hot[HOT_IDS];
+__global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_emit(DevTables t, EmitArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[EMIT_WAVES][EMIT_STAGE + 32];
-    for (uint32_t i = threadIdx.x; i < HOT_IDS; i += blockDim.x) hot[i] = 0;
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     uint8_t* stage = stage_all[threadIdx.x >> 6];
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint32_t hot_n = t.n_strings < HOT_IDS ? t.n_strings : HOT_IDS;
     EmitCounts cnt;
 
     struct Meta { uint32_t nfin, total, slot, fl; uint64_t out0; uint32_t id[2]; };
@@ -424,10 +420,6 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void k_emit(DevTables t, EmitArgs 
             }
             for (uint32_t done = 32; done < n; ++done) dst[done] = sp[done];
             if (seg[blk] != len[blk]) { dst[n] = ','; dst[n + 1] = ' '; }
-            if (len[blk] && a.histogram) {
-                if (m0.id[blk] < hot_n) atomicAdd(&hot[m0.id[blk]], 1u);
-                else atomicAdd((unsigned long long*)&a.histogram[m0.id[blk]], 1ull);
-            }
         }
         if (lane < t.newline_len) stage[head + total - t.newline_len + lane] = t.newline[lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staging area is this wave's own: no wait for global traffic
@@ -446,13 +438,46 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) void k_emit(DevTables t, EmitArgs 
         }
         __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next file's are written
     }
-    __syncthreads();
-    if (a.histogram)
-        for (uint32_t i = threadIdx.x; i < hot_n; i += blockDim.x) {
-            uint32_t c = hot[i];
-            if (c) atomicAdd((unsigned long long*)&a.histogram[i], (unsigned long long)c);
-        }
     if (a.counters && lane == 0) cnt.flush(a.counters);
+}
+
+// Tag histogram of the wave-kernel files: ids id0 .. id0 + HIST_IDS are counted in LDS (a tag occurs at most once per file,
+// so a block's 16-bit counters cannot overflow before HIST_FILES_PER_FLUSH files), then added to the global histogram.
+// Wider id ranges take further launches.  One wavefront per file, two files per step so that their loads overlap.
+__global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t id0) {
+    __shared__ uint32_t bins[HIST_IDS / 2];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const uint32_t span = t.n_strings - id0 < HIST_IDS ? t.n_strings - id0 : HIST_IDS;
+    const uint64_t n = a.file_end - a.file0;
+    const uint64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t b0 = a.file0 + per_block * blockIdx.x, b1 = b0 + per_block < a.file_end ? b0 + per_block : a.file_end;
+    for (uint64_t c0 = b0; c0 < b1; c0 += HIST_FILES_PER_FLUSH) {
+        const uint64_t c1 = c0 + HIST_FILES_PER_FLUSH < b1 ? c0 + HIST_FILES_PER_FLUSH : b1;
+        for (uint32_t i = threadIdx.x; i < HIST_IDS / 2; i += blockDim.x) bins[i] = 0;
+        __syncthreads();
+        for (uint64_t f = c0 + wave; f < c1; f += 2 * waves) {
+            const uint64_t g = f + waves;
+            const bool two = g < c1;
+            const uint32_t nf0 = a.n_final[f], nf1 = two ? a.n_final[g] : 0;
+            const bool fast0 = a.slot_of[f] == SLOT_FAST, fast1 = two && a.slot_of[g] == SLOT_FAST;
+            const uint32_t* i0 = a.fin32 + (f - a.file0) * FAST_FIN_MAX;
+            const uint32_t* i1 = a.fin32 + ((two ? g : f) - a.file0) * FAST_FIN_MAX;
+            const uint32_t x0 = i0[lane], x1 = i0[lane + 64], y0 = i1[lane], y1 = i1[lane + 64];
+            auto count = [&](uint32_t id, bool live) {
+                const uint32_t k = id - id0;
+                if (live && k < span) atomicAdd(&bins[k >> 1], 1u << (16 * (k & 1)));
+            };
+            count(x0, fast0 && lane < nf0); count(x1, fast0 && lane + 64 < nf0);
+            count(y0, fast1 && lane < nf1); count(y1, fast1 && lane + 64 < nf1);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (span + 1) / 2; i += blockDim.x) {
+            const uint32_t v = bins[i];
+            if (v & 0xFFFFu) atomicAdd((unsigned long long*)&a.histogram[id0 + 2 * i], (unsigned long long)(v & 0xFFFFu));
+            if (v >> 16) atomicAdd((unsigned long long*)&a.histogram[id0 + 2 * i + 1], (unsigned long long)(v >> 16));
+        }
+        __syncthreads();
+    }
 }
 
 // Files of the general kernel (a.item_list, or every file of the range when it is null): tags may be strings outside the
@@ -545,8 +570,13 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
     if (a.fin32) {                                          // the wave-per-file kernel ran: its files first
+        if (a.histogram) {
+            uint64_t hb = (n + 1023) / 1024;                      // a block is worth launching for a thousand files
+            unsigned hblocks = (unsigned)(hb < 256 ? hb : 256);   // one per CU: the counters take most of its LDS
+            for (uint32_t id0 = 0; id0 < t.n_strings; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0);
+        }
         uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
-        unsigned blocks = (unsigned)(want < 256 ? want : 256);   // one block per CU
+        unsigned blocks = (unsigned)(want < 256 * 5 ? want : 256 * 5);   // five blocks (twenty wavefronts) per CU
         hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
