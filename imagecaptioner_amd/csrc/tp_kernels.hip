@@ -13,6 +13,7 @@
 //                  tag histogram (block-private LDS counters for the low, frequent ids; global atomics for the tail),
 //                  batch counters.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "tp_fast.h"
 #include "tp_launch.h"
@@ -541,7 +542,11 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
     uint64_t want = (n + FAST_WAVES_PER_BLOCK - 1) / FAST_WAVES_PER_BLOCK;
-    unsigned blocks = (unsigned)(want < 256 * 8 ? want : 256 * 8);    // up to 8 blocks per CU, wavefronts stride over the files
+    // Wavefronts stride over the files.  Many more blocks than fit at once (measured best around 80 per CU): blocks that
+    // finish early make room for others, which evens out the files' different costs.  Later stages usually find little to do.
+    static const unsigned max_blocks = [] { const char* e = getenv("TAGPIPE_FAST_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
+    const unsigned cap = a.stage == 1 ? max_blocks : 256u * 8u;
+    unsigned blocks = (unsigned)(want < cap ? want : cap);
     if (a.stage == 3) hipLaunchKernelGGL(k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 2) hipLaunchKernelGGL(k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
