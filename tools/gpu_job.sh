@@ -2,7 +2,9 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/gputests.log 2>&1
-echo tests-done
-timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/bench.json 2> gpurun_out/bench.err
-echo bench-done
+rm -f gpurun_out/blocks.txt
+for b in 1280 2560 5120 10240 20480 40960; do
+TAGPIPE_EMIT_BLOCKS=$b timeout -k 10 200 python3 tools/prof_sections.py c2 1000000 > gpurun_out/sections_b.txt 2>&1
+echo "$b $(grep 'no hist' gpurun_out/sections_b.txt | cut -c1-160)" >> gpurun_out/blocks.txt
+done
+echo done
