@@ -120,7 +120,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     uint64_t* d_total = c->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
     uint32_t* d_status = (uint32_t*)(d_total + 2);
     uint32_t* d_slow_count = d_status + 1;
-    const bool use_fast = c->dt.fast_ok && !io.tag_begin && io.mode == 0 && !c->no_fast;
+    const bool use_fast = c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast;
 
     c->cap_len.need(n * 4); c->n_final.need(n * 4); c->slot_of.need(n * 4);
     uint32_t* cap_len = c->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
@@ -139,7 +139,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         FastArgs fa{};
         fa.arena = io.arena; fa.offsets = io.offsets; fa.file0 = f0; fa.file_end = f1;
         fa.verdicts = io.verdicts; fa.n_final = n_final; fa.cap_len = cap_len; fa.fin32 = c->fin32.as<uint32_t>(); fa.slot_of = slot_of;
-        fa.fired = io.fired; fa.facet_choice = io.facet_choice;
+        fa.fired = io.fired; fa.facet_choice = io.facet_choice; fa.triage = io.mode == 2 ? 1 : 0;
         hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
         HIP_OK(hipEventRecord(p0, s));
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
@@ -510,6 +510,37 @@ int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uin
     if (!ctx || !out || !offsets || (n_files && offsets[n_files] && !arena)) return fail(TP_E_INVALID_ARG, "null argument");
     for (uint64_t i = 0; i < n_files; ++i) if (offsets[i + 1] < offsets[i]) return fail(TP_E_INVALID_ARG, "offsets must be non-decreasing");
     return guarded([&]() { return run_host(ctx, arena, offsets[n_files], offsets, n_files + 1, nullptr, nullptr, nullptr, 0, n_files, out); });
+}
+
+// Existing-caption triage (Program.cs:203-210): the line-ingest front of the pipeline only, one byte per file back.
+static int triage_host(tp_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint64_t n_files, uint8_t* bad) {
+    HIP_OK(hipSetDevice(c->device));
+    hipStream_t s = nullptr;
+    if (n_files == 0) return TP_OK;
+    const uint64_t arena_bytes = offsets[n_files];
+    c->in_arena.need(arena_bytes + 64);
+    c->in_offsets.need((n_files + 1) * 8);
+    if (arena_bytes) HIP_OK(hipMemcpyAsync(c->in_arena.p, arena, arena_bytes, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(c->in_offsets.p, offsets, (n_files + 1) * 8, hipMemcpyHostToDevice, s));
+    c->out_offsets.need((n_files + 1) * 8);
+    c->out_verdicts.need(n_files * sizeof(tp_verdict));
+    RunIo io{};
+    io.arena = c->in_arena.as<uint8_t>(); io.offsets = c->in_offsets.as<uint64_t>();
+    io.n_files = n_files;
+    io.caption_offsets = c->out_offsets.as<uint64_t>(); io.verdicts = c->out_verdicts.as<tp_verdict>();
+    io.stream = s; io.mode = 2;
+    int rc = run_device(c, io, nullptr);
+    if (rc != TP_OK) return rc;
+    std::vector<tp_verdict> v(n_files);
+    HIP_OK(hipMemcpy(v.data(), c->out_verdicts.p, n_files * sizeof(tp_verdict), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n_files; ++i) bad[i] = (v[i].flags & TP_F_UNSUPPORTED) ? 2 : (v[i].flags & TP_F_TRIAGE_BAD) ? 1 : 0;
+    return TP_OK;
+}
+
+int tp_triage_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uint64_t n_files, uint8_t* bad) {
+    if (!ctx || !offsets || (n_files && !bad) || (n_files && offsets[n_files] && !arena)) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_files; ++i) if (offsets[i + 1] < offsets[i]) return fail(TP_E_INVALID_ARG, "offsets must be non-decreasing");
+    return guarded([&]() { return triage_host(ctx, arena, offsets, n_files, bad); });
 }
 
 int tp_run_scored(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const double* scores, const uint8_t* sources,

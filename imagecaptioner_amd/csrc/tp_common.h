@@ -55,6 +55,7 @@ enum : uint32_t {
     FL_NEXT_BLANK = 1u << 21,  // NormalizeTag(it) is blank
     FL_PREFIX = 1u << 22,      // it is one of the tags SelectTags adds before the candidates (trigger, 1girl, always-add)
     FL_REACH2 = 1u << 23,      // the closure of {it} holds nothing beyond its at most two steps; Rec::s0_info / s1_info describe them
+    FL_PHRASE = 1u << 25,      // holds one of the LooksBad phrases (Program.cs:56-58, 1144); only a force-allowed tag can and still be kept
     FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone and that has no steps of
                                // its own: one ExpandImpliedTags round settles it; Rec::s0_flags .. s1_len describe the steps
 };
@@ -122,7 +123,8 @@ struct alignas(64) Rec {
     uint32_t step_off, step_cnt, step0, step1;   // its ExpandImpliedTags step list (DevTables::step_ids), the first two entries inline
     uint32_t s0_info, s1_info;                   // with FL_REACH2: literal index (24 bits, 0xFFFFFF = none) | FL_NFEET-ness << 24 | FL_NPENIS-ness << 25 of step0 / step1
     uint32_t s0_flags, s0_len, s1_flags, s1_len; // with FL_LEAF2: flags and byte length of step0 / step1
-    uint32_t pad[2];
+    uint32_t len16;                              // length in UTF-16 code units (what string.Length counts)
+    uint32_t pad[1];
 };
 // One slot of the wave-per-file kernel's lookup table, two cache lines: a normalised token (key, up to 32 bytes inline) ->
 // the string NormalizeTag makes of it (val) and that string's record, so that a hit needs no second dependent load.

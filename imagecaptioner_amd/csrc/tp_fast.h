@@ -909,7 +909,7 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
 // fin32: where the caption's tag ids go (FAST_FIN_MAX entries); fired / facet_choice may be null.
 template <int NT, int NF, class W>
 TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice) {
+                     uint32_t* fired, uint16_t* facet_choice, bool triage = false) {
     static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
     constexpr uint32_t FIN_MAX = 64u * NF;
     const uint32_t lane = w.lane();
@@ -966,6 +966,22 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         if (!act[1]) { h1[1] = EMPTY_ID; r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID}; }
     }
 
+    if (triage) {
+        // Existing-caption triage stops here: LooksBad of the kept tags joined with ", " (Program.cs:206-207, 604, 1141-1147)
+        bool phrase = false;
+        uint32_t units = 0;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk)
+            if (act[blk]) { phrase = phrase || (r1[blk].flags & FL_PHRASE) != 0; units += r1[blk].len16; }
+        bool bad = rejected || n == 0 || w.ballot(phrase) != 0;
+        if (!bad && n <= 2) bad = w.sum(units) + 2 * (n - 1) > 40;   // fewer than two commas and more than 40 UTF-16 units
+        out.verdict = tp_verdict{};
+        out.verdict.flags = bad ? (uint8_t)TP_F_TRIAGE_BAD : (uint8_t)0;
+        out.verdict.n_candidates = (uint16_t)n;
+        out.verdict.safe_hit = -1;
+        out.n_final = 0;
+        out.caption_len = 0;
+        return true;
+    }
     w.tick(3);
     TP_STOP(3, h1[0] ^ h1[1] ^ r1[0].flags ^ r1[0].next ^ r1[1].flags ^ r1[0].lit ^ r1[0].step0 ^ ci[0] ^ ci[1] ^ n ^ (uint32_t)act[0] ^ (uint32_t)act[1])
     // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
@@ -1188,7 +1204,7 @@ TP_HD uint32_t big_put(W& w, LongLds& L, uint32_t key, uint32_t order) {
 
 template <class W>
 TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice) {
+                     uint32_t* fired, uint16_t* facet_choice, bool triage = false) {
     const uint32_t lane = w.lane();
     Scan sc;
     if (!scan_line(w, L, cls, text, len, sc)) return false;
@@ -1214,7 +1230,7 @@ TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, c
             const int kind = fast_token(t, s, i, j, special, high, id, rr, vdyn, dlen);
             if (kind == 1) {
                 if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) {
-                    if (rr.next != id) decline = true;             // NormalizeTag would change it again
+                    if (rr.next != id && !triage) decline = true;  // NormalizeTag would change it again
                     const uint32_t slot = big_put(w, L, id, tix);
                     if (slot == NO_ID) decline = true;
                     cid = id;
@@ -1233,6 +1249,28 @@ TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, c
     }
     if (w.ballot(decline)) return false;
     w.sync();
+    if (triage) {
+        // Existing-caption triage: LooksBad of the kept tags joined with ", " (Program.cs:206-207, 604, 1141-1147)
+        uint32_t k = 0, units = 0;
+        bool phrase = false;
+        for (uint32_t base = 0; base < T; base += 64) {
+            const uint32_t tix = base + lane;
+            const uint32_t id = tix < T ? L.c_id[tix] : NO_ID;
+            const bool act = id != NO_ID && L.big_min[L.c_slot[tix]] == tix;
+            k += popc64(w.ballot(act));
+            if (act) phrase = phrase || (L.c_fl[tix] & FL_PHRASE) != 0;
+            if (act && k <= 2) units += t.rec[id].len16;           // only matters for at most two tags (k never falls again)
+        }
+        bool bad = sc.rejected || k == 0 || w.ballot(phrase) != 0;
+        if (!bad && k <= 2) bad = w.sum(units) + 2 * (k - 1) > 40;
+        out.verdict = tp_verdict{};
+        out.verdict.flags = bad ? (uint8_t)TP_F_TRIAGE_BAD : (uint8_t)0;
+        out.verdict.n_candidates = (uint16_t)k;
+        out.verdict.safe_hit = -1;
+        out.n_final = 0;
+        out.caption_len = 0;
+        return true;
+    }
 
     // ---- candidates in order: first occurrences; dropped-tag count, style cap, evidence (Program.cs:625-655, 702-710, 721-729) ---
     const bool count = fired != nullptr;

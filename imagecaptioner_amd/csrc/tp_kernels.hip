@@ -88,7 +88,8 @@ constexpr int FAST_WAVES_PER_BLOCK = 4;
 // The first stage serves files of at most 64 tokens (and 128 final tags) over the whole range [file0, file_end); the second
 // serves the files the first declined (a.item_list, a.item_count entries on the device) with 128 tokens.  Files both decline
 // go to a.slow_list for the general kernel.
-template <int NT>
+// TR: existing-caption triage (a compile-time choice, so that the caption kernels carry none of it).
+template <int NT, bool TR>
 __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a) {
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
     __shared__ uint8_t cls[256];                                // byte classes of the line scan
@@ -109,7 +110,7 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
         FastOut out;
         if (len64 <= FAST_LINE_MAX) {
             done = fast_file<NT, 2>(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
-                                 a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+                                 a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR);
         }
         if (w.lane() == 0) {
             if (done) {
@@ -132,12 +133,15 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
 #define TP_FAST_WAVES_PER_SIMD 5
 #endif
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_FAST_WAVES_PER_SIMD))) void k_fast(DevTables t, FastArgs a) {
-    fast_body<1>(t, a);
+    fast_body<1, false>(t, a);
 }
-__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t, FastArgs a) { fast_body<2>(t, a); }
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t, FastArgs a) { fast_body<2, false>(t, a); }
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast_triage(DevTables t, FastArgs a) { fast_body<1, true>(t, a); }
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2_triage(DevTables t, FastArgs a) { fast_body<2, true>(t, a); }
 
 // Third stage: the files the second declined, up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes; one wavefront per block.
-__global__ __launch_bounds__(64) void k_long(DevTables t, FastArgs a) {
+template <bool TR>
+__device__ __forceinline__ void long_body(const DevTables& t, const FastArgs& a) {
     __shared__ LongLds L;
     __shared__ uint8_t cls[256];
     extern __shared__ uint32_t rc_lds[];
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(64) void k_long(DevTables t, FastArgs a) {
         FastOut out;
         if (len64 <= LONG_LINE_MAX) {
             done = long_file(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
-                             a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+                             a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR);
         }
         if (w.lane() == 0) {
             if (done) {
@@ -170,6 +174,8 @@ __global__ __launch_bounds__(64) void k_long(DevTables t, FastArgs a) {
         w.sync();
     }
 }
+__global__ __launch_bounds__(64) void k_long(DevTables t, FastArgs a) { long_body<false>(t, a); }
+__global__ __launch_bounds__(64) void k_long_triage(DevTables t, FastArgs a) { long_body<true>(t, a); }
 
 // ------------------------------------------------------------------------------------------------
 // k_wave_sizes
@@ -547,9 +553,10 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     static const unsigned max_blocks = [] { const char* e = getenv("TAGPIPE_FAST_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
     const unsigned cap = a.stage == 1 ? max_blocks : 256u * 8u;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
-    if (a.stage == 3) hipLaunchKernelGGL(k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
-    else if (a.stage == 2) hipLaunchKernelGGL(k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
-    else hipLaunchKernelGGL(k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    const bool tr = a.triage != 0;
+    if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
+    else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    else hipLaunchKernelGGL(tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     return hipGetLastError();
 }
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,

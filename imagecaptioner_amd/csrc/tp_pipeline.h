@@ -403,7 +403,8 @@ TP_HD bool has_refusal_phrase(const uint8_t* s, uint32_t a, uint32_t b) {
 }
 
 // ================================================================================================
-// The pipeline.  mode 0: whole span.  mode 1: stop after SelectTags and leave its result in ws.fin
+// The pipeline.  mode 0: whole span.  mode 2: existing-caption triage (line ingest only; stops after the candidates).
+// mode 1: stop after SelectTags and leave its result in ws.fin
 // (used once at load time to evaluate the minimal fallback line, Program.cs:298).
 // ================================================================================================
 TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOut& out, uint32_t* fired, uint16_t* facet_choice, int mode) {
@@ -507,6 +508,20 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             }
         }
         if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
+        if (mode == 2) {
+            // Existing-caption triage stops here: LooksBad of the kept tags joined with ", " (Program.cs:206-207, 604, 1141-1147)
+            bool bad = rejected || n == 0;
+            uint32_t units = 0;
+            for (uint32_t i = 0; i < n && !bad; ++i) {
+                H h = ws.hnd[i];
+                if (h_is_dyn(h)) units += h_len(h);                // ASCII: one UTF-16 unit per byte (a phrase would have dropped it)
+                else { if (t.flags[h_id(h)] & FL_PHRASE) bad = true; units += t.rec[h_id(h)].len16; }
+            }
+            if (!bad && n <= 2 && units + 2 * (n - 1) > 40) bad = true;
+            v.flags = bad ? (uint8_t)TP_F_TRIAGE_BAD : (uint8_t)0;
+            v.n_candidates = (uint16_t)(n > 0xFFFF ? 0xFFFF : n);
+            return;
+        }
         // ParseTagCandidatesFromLine scores, Program.cs:581-583
         for (uint32_t i = 0; i < n; ++i) {
             double base = fmax(0.05, 1.0 - (double)(int)i * 0.01);

@@ -355,13 +355,17 @@ struct Loader {
         return true;
     }
     static bool has(const W& s, const char* needle) { return s.find(widen(needle)) != W::npos; }
+    static bool has_looks_bad_phrase(const W& lower) {                            // DropTagsContains.Any(lower.Contains), Program.cs:56-58
+        for (auto s : {"negative:", "positive:", "sorry", "i can't", "i cannot", "cannot provide", "unable to", "as an ai", "i'm not able", "i won't"})
+            if (has(lower, s)) return true;
+        W w = widen("i won"); w.push_back(0x2019); w.push_back('t');
+        return lower.find(w) != W::npos;
+    }
     bool should_drop(const W& t) const {                                          // ShouldDropTag, Program.cs:1121-1133
         W lower = lowered(t);
         if (force_allow.contains(lower)) return false;
         if (!valid_tag(lower)) return true;
-        for (auto s : {"negative:", "positive:", "sorry", "i can't", "i cannot", "cannot provide", "unable to", "as an ai", "i'm not able", "i won't"})
-            if (has(lower, s)) return true;
-        { W w = widen("i won"); w.push_back(0x2019); w.push_back('t'); if (lower.find(w) != W::npos) return true; }
+        if (has_looks_bad_phrase(lower)) return true;
         if (lower.compare(0, 7, widen("rating:")) == 0) return true;
         if (builtin_deny.contains(lower) || banned.contains(lower) || deny.contains(lower)) return true;
         if (allow.size() > 0 && !allow.contains(lower) && (lower.compare(0, 6, widen("rating")) == 0 || has(lower, "watermark"))) return true;
@@ -790,6 +794,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         if (Loader::valid_tag(s)) f |= FL_VALID;
         if (ld.should_drop(s)) f |= FL_DROP;
         if (s.size() >= 2) f |= FL_LEN2;
+        if (Loader::has_looks_bad_phrase(lowered(s))) f |= FL_PHRASE;
         f |= ld.bucket_of(s, mask) << FL_BUCKET_SHIFT;
         if (mask & CM_HAIR) f |= FL_HAIR;
         if (mask & CM_EYES) f |= FL_EYES;
@@ -1038,6 +1043,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         uint32_t so = out.step_off[i], scnt = out.step_off[i + 1] - so;
         Rec r{};
         r.flags = out.flags[i]; r.next = out.next[i]; r.lit = out.lit[i]; r.len = out.str_off[i + 1] - out.str_off[i];
+        r.len16 = (uint32_t)in.text[i].size();
         r.step_off = so; r.step_cnt = scnt;
         r.step0 = scnt > 0 ? out.step_ids[so] : NO_ID;
         r.step1 = scnt > 1 ? out.step_ids[so + 1] : NO_ID;

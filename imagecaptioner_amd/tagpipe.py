@@ -19,6 +19,7 @@ _LIB = None
 EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_format_top_tags", "tp_get_last_timing",
+    "tp_triage_lines",
 )
 
 
@@ -54,6 +55,7 @@ def load_library():
     L.tp_run_lines_device.argtypes = [C.c_void_p, C.POINTER(tp_device_io), C.POINTER(C.c_uint64)]
     L.tp_format_top_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tp_get_last_timing.argtypes = [C.c_void_p, C.POINTER(tp_timing)]
+    L.tp_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     _LIB = L
     return L
 
@@ -185,6 +187,24 @@ class TagPipe:
             offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
         arena = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
         return self.run_lines(arena, offsets)
+
+    def triage_lines(self, arena, offsets):
+        """tp_triage_lines: which existing captions the reference would delete and redo (Program.cs:203-210).
+        Returns a uint8 array: 1 bad, 0 keep, 2 outside what the device code handles."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        bad = np.zeros(len(offsets) - 1, dtype=np.uint8)
+        self._check(self._L.tp_triage_lines(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, len(offsets) - 1,
+                                            bad.ctypes.data if bad.size else None))
+        return bad
+
+    def triage_texts(self, texts):
+        bs = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
+        offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        arena = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+        return self.triage_lines(arena, offsets)
 
     def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
         arena = np.ascontiguousarray(arena, dtype=np.uint8)

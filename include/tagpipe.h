@@ -47,6 +47,7 @@ extern "C" {
                                      that normalisation leaves alone (such tags need Unicode case mapping and white-space rules), or a per-file
                                      list that outgrew its workspace; nothing is written for the file */
 #define TP_F_SAFE_REJECT   0x40u  /* DetectSafeModeRejectReason hit, Program.cs:329, 942-945 */
+#define TP_F_TRIAGE_BAD    0x80u  /* tp_triage_lines only: LooksBad(NormalizeRawTagLine(text)), Program.cs:206-207 */
 
 /* Candidate sources and their SourceRank (Program.cs:398, 712-717). */
 #define TP_SRC_PRIMARY_JOY   0
@@ -228,6 +229,14 @@ typedef struct tp_device_io {
     void*           stream;
 } tp_device_io;
 int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes);
+
+/*
+ * Existing-caption triage (Program.cs:203-210 with --reprocess-bad-existing): for every file's text, would the
+ * reference regenerate the caption?  bad[i] = 1 when LooksBad(NormalizeRawTagLine(text_i)) (the file is deleted and the
+ * image captioned again, Program.cs:207-209), 0 when the existing caption is kept (the image is skipped), 2 when the text
+ * is something this build does not process (see TP_F_UNSUPPORTED).  Host pointers; bad has n_files entries.
+ */
+int tp_triage_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uint64_t n_files, uint8_t* bad);
 
 /*
  * Corpus-wide tag table in the format the reference reads as top_tags.txt

@@ -63,6 +63,7 @@ def lib():
         L.orc_should_drop_tag.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_normalize_raw_tag_line.restype = C.c_char_p
         L.orc_normalize_raw_tag_line.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.orc_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_infer_action_tags.restype = C.c_char_p
         L.orc_infer_action_tags.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.orc_format_caption.restype = C.c_char_p
@@ -142,6 +143,17 @@ class Oracle:
     def normalize_raw_tag_line(self, s):
         b = s.encode("utf-8") if isinstance(s, str) else s
         return self._L.orc_normalize_raw_tag_line(self._h, b, len(b)).decode("utf-8")
+
+    def triage_texts(self, texts):
+        """LooksBad(NormalizeRawTagLine(text)) per text (Program.cs:205-207) as a uint8 array."""
+        bs = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
+        offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        arena = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy()
+        bad = np.zeros(len(bs), dtype=np.uint8)
+        self._L.orc_triage_lines(self._h, arena.ctypes.data, offsets.ctypes.data, len(bs), bad.ctypes.data)
+        return bad
 
     def infer_action_tags(self, final_tags, evidence):
         r = self._L.orc_infer_action_tags(self._h, "\n".join(final_tags).encode(), "\n".join(evidence).encode()).decode()

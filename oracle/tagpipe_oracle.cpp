@@ -1378,6 +1378,13 @@ const char* orc_normalize_raw_tag_line(void* ctx, const uint8_t* s, uint64_t n) 
     g_tmp = to8(((Ctx*)ctx)->eng.NormalizeRawTagLine(utf8_to_16(s, (size_t)n)));
     return g_tmp.c_str();
 }
+// Existing-caption triage, Program.cs:205-207: bad[i] = LooksBad(NormalizeRawTagLine(text of file i)).
+int orc_triage_lines(void* ctx, const uint8_t* arena, const uint64_t* offsets, uint64_t n, uint8_t* bad) {
+    Ctx* cx = (Ctx*)ctx;
+    for (uint64_t i = 0; i < n; ++i)
+        bad[i] = Engine::LooksBad(cx->eng.NormalizeRawTagLine(utf8_to_16(arena + offsets[i], (size_t)(offsets[i + 1] - offsets[i])))) ? 1 : 0;
+    return 0;
+}
 // InferActionTags on explicit lists (self-check items 5-8): tags separated by '\n'; returns the inferred list, '\n'-joined.
 const char* orc_infer_action_tags(void* ctx, const char* final_tags, const char* evidence_tags) {
     Ctx* cx = (Ctx*)ctx;

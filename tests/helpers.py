@@ -52,6 +52,7 @@ def sim_lib():
         L.sim_run_scored.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
         L.sim_run_lines_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result), C.POINTER(C.c_uint64)]
         L.sim_release.argtypes = [C.POINTER(sim_result)]
+        L.sim_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         _SIM = L
     return _SIM
 
@@ -132,6 +133,20 @@ class HostSim:
     def run_texts_fast(self, texts):
         a, o = pack_lines(texts)
         return self.run_lines_fast(a, o)
+
+    def triage_texts(self, texts, general_only=False):
+        """(bad, n_general): the triage flow on the emulated wavefront; general_only runs the thread-per-file code alone."""
+        bs = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
+        offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        arena = np.frombuffer(b"".join(bs) + b"\0" * 16, dtype=np.uint8).copy()
+        bad = np.zeros(len(bs), dtype=np.uint8)
+        ng = C.c_uint64()
+        rc = self._L.sim_triage_lines(self._h, arena.ctypes.data, offsets.ctypes.data, len(bs), int(general_only), bad.ctypes.data, C.byref(ng))
+        if rc != 0:
+            raise RuntimeError(self._L.sim_last_error().decode())
+        return bad, ng.value
 
     def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
         arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
@@ -258,3 +273,37 @@ def check_non_ascii(run_fast, oracle):
         else:
             assert got.verdicts["flags"][i] & 0x20 and got.caption(i) == b"", text
     assert got.counters["unsupported"] == sum(1 for _, taken in NON_ASCII_LINES if not taken)
+
+
+def triage_lines(seed, n):
+    """Existing-caption texts for the triage entry point: well-formed captions, one- and two-tag lines around the 40-unit limit,
+    refusals, blanks, repeated tags (which collapse below three tags), fenced and prefixed replies."""
+    import random
+    rng = random.Random(seed)
+    vocab = [l.strip() for l in open(os.path.join(DATA, "top_tags.txt"), encoding="utf-8") if l.strip()]
+    longs = [v for v in vocab if len(v) >= 18] or vocab
+    out = ["", " ", "\n", ",", ", ,", "1girl", "1girl, smile", "1girl, smile, dress", "sorry, I can't help with that", "POSITIVE: 1girl, smile, dress\nNEGATIVE: blurry",
+           "```\n1girl, smile, dress\n```", "smile, smile, smile, smile", "SMILE, smile, Smile, x", "a, b, c", "watermark, text, signature",
+           "zz_unknown_tag_that_is_rather_long_indeed, smile", "zz unknown tag that is rather long indeed and more", "1girl," + " " * 60 + "smile"]
+    while len(out) < n:
+        r = rng.random()
+        if r < 0.35:
+            k = rng.randint(3, 40)
+            toks = [rng.choice(vocab[:2000]) for _ in range(k)]
+        elif r < 0.75:
+            k = rng.choice([1, 1, 2, 2, 2, 3])
+            src = longs if rng.random() < 0.7 else vocab[:500]
+            toks = [rng.choice(src) for _ in range(k)]
+            if rng.random() < 0.3:
+                toks.append(toks[0].upper())
+            if rng.random() < 0.2:
+                toks.append("zz_" + "x" * rng.randint(0, 30))
+        elif r < 0.85:
+            toks = [rng.choice(["sorry", "i cannot", "as an ai", "unable to comply", "watermark", "text", "a", "", " "]) for _ in range(rng.randint(1, 4))]
+        else:
+            toks = [rng.choice(vocab[:300]).replace("_", " ") for _ in range(rng.randint(1, 5))]
+        line = rng.choice([", ", ",", " , "]).join(toks)
+        if rng.random() < 0.1:
+            line = rng.choice(["POSITIVE: ", "```\n", " ", "NEGATIVE: "]) + line + rng.choice(["", "\n```", "\nNEGATIVE: bad", "\r\n"])
+        out.append(line)
+    return out

@@ -249,6 +249,62 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
     return finish(o, n, r);
 }
 
+// Existing-caption triage in the GPU flow: the three wave stages in triage mode, then the general pipeline in mode 2.
+// which: 0 the flow as the library runs it, 1 general pipeline only.  bad[i]: 1 bad, 0 keep, 2 unsupported.
+int sim_triage_lines(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, int which, uint8_t* bad, uint64_t* n_general) {
+    g_err.clear();
+    Sim& s = *(Sim*)h;
+    const DevTables& t = s.dt;
+    std::vector<uint8_t> padded((size_t)offsets[n] + 128, 0);
+    uint8_t* arena = padded.data() + 64;
+    std::memcpy(arena, arena_in, (size_t)offsets[n]);
+    uint64_t slow = 0;
+    emu::Shared sh;
+    for (uint64_t f = 0; f < n; ++f) {
+        static FastLds lds;
+        std::vector<uint32_t> fin32(FAST_FIN_MAX, 0xDEADBEEF);
+        bool done[64];
+        FastOut outs[64];
+        const uint8_t* text = arena + offsets[f];
+        uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
+        bool ok = false;
+        if (which == 0 && t.fast_ok && len <= FAST_LINE_MAX) {
+            for (int stage = 1; stage <= 2 && !ok; ++stage) {
+                std::memset(&lds, 0xCD, sizeof lds);
+                sh.run([&](int lane) {
+                    emu::Wave w{&sh, (uint32_t)lane};
+                    done[lane] = stage == 1 ? fast_file<1, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), nullptr, nullptr, true)
+                                            : fast_file<2, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), nullptr, nullptr, true);
+                });
+                for (int l = 1; l < 64; ++l) if (done[l] != done[0] || outs[l].verdict.flags != outs[0].verdict.flags) g_err = "lanes disagree in triage";
+                ok = done[0];
+            }
+        }
+        if (which == 0 && !ok && t.fast_ok && len <= LONG_LINE_MAX) {
+            static LongLds big;
+            std::memset((void*)&big, 0xCD, sizeof big);
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                done[lane] = long_file(w, t, big, t.rc, cls_table(), text, len, outs[lane], fin32.data(), nullptr, nullptr, true);
+            });
+            for (int l = 1; l < 64; ++l) if (done[l] != done[0] || outs[l].verdict.flags != outs[0].verdict.flags) g_err = "lanes disagree in long-file triage";
+            ok = done[0];
+        }
+        uint8_t fl;
+        if (ok) fl = outs[0].verdict.flags;
+        else {
+            ++slow;
+            uint64_t offs2[2] = {0, len};
+            SimOut one;
+            run(s, text, offs2, nullptr, nullptr, nullptr, 1, 2, one, nullptr);
+            fl = one.verdicts[0].flags;
+        }
+        bad[f] = (fl & TP_F_UNSUPPORTED) ? 2 : (fl & TP_F_TRIAGE_BAD) ? 1 : 0;
+    }
+    if (n_general) *n_general = slow;
+    return g_err.empty() ? 0 : -1;
+}
+
 void sim_release(sim_result* r) { delete (SimOut*)r->opaque; r->opaque = nullptr; }
 
 }  // extern "C"

@@ -114,6 +114,37 @@ def test_known_non_ascii_tags_pass_through_the_wave_kernel():
     check_non_ascii(pipe_for(cfg).run_texts, Oracle(cfg))
 
 
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_existing_caption_triage(name):
+    """tp_triage_lines against LooksBad(NormalizeRawTagLine(text)) of the oracle (Program.cs:203-210)."""
+    from helpers import triage_lines
+    from test_pipeline_logic_cpu import long_lines
+    cfg = CONFIGS[name]()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    lines = triage_lines(5, 4000) + fuzz_lines(31, 1500) + EDGE_LINES + long_lines(9, 40)
+    got, want = p.triage_texts(lines), o.triage_texts(lines)
+    assert not (got == 2).any()
+    diff = np.nonzero(got != want)[0]
+    assert diff.size == 0, [(lines[i], int(got[i]), int(want[i])) for i in diff[:5]]
+    assert 0 < want.sum() < len(lines)
+    assert p.triage_texts([]).size == 0
+
+
+def test_triage_of_the_pipelines_own_captions():
+    """What the pipeline writes is what a later run finds on disk: triage of those captions agrees with the oracle, and a
+    caption of three or more tags is never called bad."""
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus("c2", 20000, seed=13)
+    cfg = Config(**c.config_kwargs)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    r = p.run_lines(c.arena, c.offsets)
+    got = p.triage_lines(r.captions, r.caption_offsets)
+    texts = [r.caption(i) for i in range(20000)]
+    want = o.triage_texts(texts)
+    assert np.array_equal(got, want)
+    assert not got[r.verdicts["n_tags"] >= 3].any()
+
+
 def test_workspace_chunking_gives_identical_results(monkeypatch):
     from imagecaptioner_amd.corpus import make_corpus
     c = make_corpus("c2", 5000, seed=31)
