@@ -6,7 +6,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from imagecaptioner_amd import Config  # noqa: E402, TagPipe
+from imagecaptioner_amd import Config, TagPipe  # noqa: E402
 from imagecaptioner_amd.corpus import make_corpus  # noqa: E402
 
 name, n = sys.argv[1], int(sys.argv[2])
@@ -20,4 +20,4 @@ for what, arena, offs in (("input lines", c.arena, c.offsets), ("own captions", 
         wall = time.time() - t0
         tm = p.last_timing()
     print("%s %s: bad %d of %d, unsupported %d; device %.3f ms (wave stages %.3f, general %.3f on %d files), wall %.1f ms" % (
-        name, what, int((bad == 1).sum()), n, int((bad == 2).sum()), tm.total_ms, tm.select_ms, tm.general_ms, tm.general_files, wall * 1e3))
+        name, what, int((bad == 1).sum()), n, int((bad == 2).sum()), tm["total_ms"], tm["select_ms"], tm["general_ms"], tm["general_files"], wall * 1e3))
