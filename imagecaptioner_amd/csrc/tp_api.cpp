@@ -72,7 +72,7 @@ struct tp_ctx {
     DevTables dt;
     std::vector<void*> table_mem;
     DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list1, slow_list2, scalars, workspace;
-    DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources;           // host-pointer entry points stage their inputs here
+    DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
     std::vector<hipEvent_t> events;
     tp_timing timing{};
@@ -84,7 +84,7 @@ struct tp_ctx {
         (void)hipSetDevice(device);
         for (void* p : table_mem) (void)hipFree(p);
         for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
-                          &in_scores, &in_sources, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets})
+                          &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
@@ -98,6 +98,7 @@ namespace {
 
 struct RunIo {
     const uint8_t* arena; const uint64_t* offsets; const uint64_t* tag_begin; const double* scores; const uint8_t* sources;
+    const uint64_t* secondary_begin; int secondary_cap;
     uint64_t n_files;
     uint8_t* captions; uint64_t caption_capacity; bool grow_captions;   // grow_captions: captions live in ctx->out_captions and may be reallocated
     uint64_t* caption_offsets; tp_verdict* verdicts; uint64_t* histogram; tp_counters* counters; uint32_t* fired; uint16_t* facet_choice;
@@ -182,6 +183,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         c->workspace.need(ws_bytes);
         PipelineArgs pa{};
         pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
+        pa.secondary_begin = io.secondary_begin; pa.secondary_cap = io.secondary_cap;
         pa.item_list = item_list; pa.file0 = f0; pa.n_items = n_slow;
         pa.wave_T = c->wave_T.as<uint32_t>(); pa.wave_LB = c->wave_LB.as<uint32_t>(); pa.wave_off = c->wave_off.as<uint64_t>();
         pa.workspace = c->workspace.as<uint8_t>();
@@ -280,7 +282,8 @@ int guarded(F&& body) {
 
 // Host-pointer run shared by tp_run_lines and tp_run_scored.
 int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64_t* offsets, uint64_t n_offsets, const uint64_t* tag_begin,
-             const double* scores, const uint8_t* sources, uint64_t n_tags, uint64_t n_files, tp_result* out) {
+             const double* scores, const uint8_t* sources, uint64_t n_tags, uint64_t n_files, tp_result* out,
+             const uint64_t* secondary_begin = nullptr, int secondary_cap = 0) {
     HIP_OK(hipSetDevice(c->device));
     hipStream_t s = nullptr;
     const DevTables& t = c->dt;
@@ -293,7 +296,11 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
         HIP_OK(hipMemcpyAsync(c->in_tag_begin.p, tag_begin, (n_files + 1) * 8, hipMemcpyHostToDevice, s));
         if (n_tags) {
             HIP_OK(hipMemcpyAsync(c->in_scores.p, scores, n_tags * 8, hipMemcpyHostToDevice, s));
-            HIP_OK(hipMemcpyAsync(c->in_sources.p, sources, n_tags, hipMemcpyHostToDevice, s));
+            if (sources) HIP_OK(hipMemcpyAsync(c->in_sources.p, sources, n_tags, hipMemcpyHostToDevice, s));
+        }
+        if (secondary_begin) {
+            c->in_secondary.need(std::max<uint64_t>(n_files, 1) * 8);
+            if (n_files) HIP_OK(hipMemcpyAsync(c->in_secondary.p, secondary_begin, n_files * 8, hipMemcpyHostToDevice, s));
         }
     }
     const size_t hist_n = (size_t)t.n_strings + 1;
@@ -312,6 +319,7 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     io.tag_begin = tag_begin ? c->in_tag_begin.as<uint64_t>() : nullptr;
     io.scores = tag_begin ? c->in_scores.as<double>() : nullptr;
     io.sources = tag_begin ? c->in_sources.as<uint8_t>() : nullptr;
+    io.secondary_begin = secondary_begin ? c->in_secondary.as<uint64_t>() : nullptr; io.secondary_cap = secondary_cap;
     io.n_files = n_files;
     io.captions = c->out_captions.as<uint8_t>(); io.caption_capacity = c->out_captions.cap; io.grow_captions = true;
     io.caption_offsets = c->out_offsets.as<uint64_t>(); io.verdicts = c->out_verdicts.as<tp_verdict>();
@@ -510,6 +518,26 @@ int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uin
     if (!ctx || !out || !offsets || (n_files && offsets[n_files] && !arena)) return fail(TP_E_INVALID_ARG, "null argument");
     for (uint64_t i = 0; i < n_files; ++i) if (offsets[i + 1] < offsets[i]) return fail(TP_E_INVALID_ARG, "offsets must be non-decreasing");
     return guarded([&]() { return run_host(ctx, arena, offsets[n_files], offsets, n_files + 1, nullptr, nullptr, nullptr, 0, n_files, out); });
+}
+
+int tp_run_merged(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin,
+                  const double* scores, int secondary_cap, uint64_t n_files, tp_result* out) {
+    if (!ctx || !out || !tag_offsets || !tag_begin || (n_files && !secondary_begin)) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_files; ++i) {
+        if (tag_begin[i + 1] < tag_begin[i]) return fail(TP_E_INVALID_ARG, "tag_begin must be non-decreasing");
+        if (secondary_begin[i] < tag_begin[i] || secondary_begin[i] > tag_begin[i + 1]) return fail(TP_E_INVALID_ARG, "secondary_begin must lie within the file's tags");
+    }
+    uint64_t n_tags = tag_begin[n_files];
+    if (n_tags && !scores) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_tags; ++i) {
+        if (tag_offsets[i + 1] < tag_offsets[i]) return fail(TP_E_INVALID_ARG, "tag_offsets must be non-decreasing");
+        if (!(scores[i] == scores[i]) || scores[i] - scores[i] != 0.0) return fail(TP_E_INVALID_ARG, "scores must be finite");
+    }
+    uint64_t arena_bytes = tag_offsets[n_tags];
+    if (arena_bytes && !arena) return fail(TP_E_INVALID_ARG, "null argument");
+    static const uint64_t none = 0;
+    return guarded([&]() { return run_host(ctx, arena, arena_bytes, tag_offsets, n_tags + 1, tag_begin, scores, nullptr, n_tags, n_files, out,
+                                           n_files ? secondary_begin : &none, secondary_cap); });
 }
 
 // Existing-caption triage (Program.cs:203-210): the line-ingest front of the pipeline only, one byte per file back.

@@ -38,6 +38,8 @@ struct PipelineArgs {
     const uint64_t* tag_begin;    // scored ingest only
     const double* scores;
     const uint8_t* sources;
+    const uint64_t* secondary_begin;   // scored ingest of two tagger replies: first secondary tag of every file (else null)
+    int secondary_cap;
     const uint32_t* item_list;    // may be null
     uint64_t file0;
     uint64_t n_items;

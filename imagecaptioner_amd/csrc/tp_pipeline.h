@@ -92,6 +92,10 @@ struct FileIn {
     uint64_t tag_lo, tag_hi;
     const double* scores;
     const uint8_t* sources;
+    // two tagger replies to merge (Program.cs:214-221): [tag_lo, tag_mid) primary, [tag_mid, tag_hi) secondary; sources is not read
+    bool merged;
+    uint64_t tag_mid;
+    int secondary_cap;
 };
 struct FileOut {
     tp_verdict verdict;
@@ -531,27 +535,91 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         }
     } else {
         // ---------------- scored ingest, shaped like ParseJoyTags (Program.cs:473-487) ----------------
-        uint32_t order = 0;
-        for (uint64_t k = in.tag_lo; k < in.tag_hi; ++k) {
-            const uint8_t* s = in.arena + in.tag_offsets[k];
-            uint32_t len = (uint32_t)(in.tag_offsets[k + 1] - in.tag_offsets[k]);
-            for (uint32_t p = 0; p < len; ++p) if (s[p] >= 0x80) unsupported = true;
-            if (unsupported) break;
-            H h;
-            bool nonempty = make_token(t, ws, norm_used, s, 0, len, true, h, unsupported);
-            if (unsupported) break;
-            if (!nonempty) h = t.alias1[EMPTY_ID];                // NormalizeTag("") still goes through the alias lookup
-            if (hflags(t, h) & FL_BLANK) continue;
-            if (n >= ws.cap_t) { unsupported = true; break; }
-            // insertion by (score descending, order ascending): OrderByDescending(Score).ThenBy(Order), Program.cs:487
-            double sc = in.scores[k];
-            uint32_t pos = n;
-            while (pos > 0 && ws.score[pos - 1] < sc) {
-                ws.hnd[pos] = ws.hnd[pos - 1]; ws.score[pos] = ws.score[pos - 1]; ws.order[pos] = ws.order[pos - 1]; ws.src[pos] = ws.src[pos - 1];
-                --pos;
+        // One tagger reply: tags [lo, hi) become entries g0 .. of the candidate arrays, ordered by (score descending, order ascending).
+        auto ingest = [&](uint64_t lo, uint64_t hi, uint32_t g0, int fixed_source) -> uint32_t {
+            uint32_t order = 0, m = 0;
+            for (uint64_t k = lo; k < hi; ++k) {
+                const uint8_t* s = in.arena + in.tag_offsets[k];
+                uint32_t len = (uint32_t)(in.tag_offsets[k + 1] - in.tag_offsets[k]);
+                for (uint32_t p = 0; p < len; ++p) if (s[p] >= 0x80) unsupported = true;
+                if (unsupported) break;
+                H h;
+                bool nonempty = make_token(t, ws, norm_used, s, 0, len, true, h, unsupported);
+                if (unsupported) break;
+                if (!nonempty) h = t.alias1[EMPTY_ID];                // NormalizeTag("") still goes through the alias lookup
+                if (hflags(t, h) & FL_BLANK) continue;
+                if (g0 + m >= ws.cap_t) { unsupported = true; break; }
+                // insertion by (score descending, order ascending): OrderByDescending(Score).ThenBy(Order), Program.cs:487
+                double sc = in.scores[k];
+                uint32_t pos = g0 + m;
+                while (pos > g0 && ws.score[pos - 1] < sc) {
+                    ws.hnd[pos] = ws.hnd[pos - 1]; ws.score[pos] = ws.score[pos - 1]; ws.order[pos] = ws.order[pos - 1]; ws.src[pos] = ws.src[pos - 1];
+                    --pos;
+                }
+                ws.hnd[pos] = h; ws.score[pos] = sc; ws.order[pos] = order++; ws.src[pos] = fixed_source >= 0 ? (uint8_t)fixed_source : in.sources[k];
+                ++m;
             }
-            ws.hnd[pos] = h; ws.score[pos] = sc; ws.order[pos] = order++; ws.src[pos] = in.sources[k];
-            ++n;
+            return m;
+        };
+        if (!in.merged) n = ingest(in.tag_lo, in.tag_hi, 0, -1);
+        else {
+            const uint32_t np = ingest(in.tag_lo, in.tag_mid, 0, TP_SRC_PRIMARY_JOY);
+            const uint32_t ns = unsupported ? 0 : ingest(in.tag_mid, in.tag_hi, np, TP_SRC_SECONDARY_JOY);
+            if (!unsupported) {
+                // MergeCandidateTags (Program.cs:442-461) over the primary reply followed by what LimitSecondaryTags
+                // (Program.cs:801-815) lets through of the secondary one.  The map's values sit in insertion order in
+                // entries 0 .. nm of the same arrays: entry nm is written only after entry i >= nm has been read.
+                uint32_t nm = 0, nm_primary = 0;
+                auto feed = [&](uint32_t i, uint32_t limit_to) -> bool {          // limit_to: entries searched for the tag
+                    H h = ws.hnd[i]; double sc = ws.score[i]; uint32_t od = ws.order[i]; uint32_t sr = ws.src[i];
+                    uint32_t j = 0;
+                    for (; j < limit_to; ++j) if (heq(ws, ws.hnd[j], h)) break;
+                    if (j == limit_to) return false;
+                    double osc = ws.score[j];
+                    uint32_t osr = ws.src[j];
+                    // PreferSource (Program.cs:796-799) on (old, new): far-apart scores are both replaced by the better one
+                    // before the call (Program.cs:452), so its own distance test sees them equal or close either way
+                    bool close = fabs(osc - sc) <= 0.03;
+                    double best = sc > osc ? sc : osc;
+                    double sa = close ? osc : best, sb = close ? sc : best;
+                    uint32_t source = fabs(sa - sb) > 0.03 ? (sa >= sb ? osr : sr) : (source_rank(osr) <= source_rank(sr) ? osr : sr);
+                    ws.score[j] = best;                                   // Math.Max
+                    if (od < ws.order[j]) ws.order[j] = od;               // Math.Min
+                    ws.src[j] = (uint8_t)source;
+                    return true;
+                };
+                auto append = [&](uint32_t i) {
+                    ws.hnd[nm] = ws.hnd[i]; ws.score[nm] = ws.score[i]; ws.order[nm] = ws.order[i]; ws.src[nm] = ws.src[i];
+                    ++nm;
+                };
+                for (uint32_t i = 0; i < np; ++i) if (!feed(i, nm)) append(i);
+                nm_primary = nm;
+                int cap = in.secondary_cap;
+                if (cap > 0) {
+                    for (uint32_t i = np; i < np + ns; ++i) {
+                        bool in_primary = false;
+                        for (uint32_t j = 0; j < nm_primary && !in_primary; ++j) in_primary = heq(ws, ws.hnd[j], ws.hnd[i]);
+                        if (!in_primary) { if (cap == 0) continue; --cap; }
+                        if (!feed(i, nm)) append(i);
+                    }
+                }
+                // OrderByDescending(Score).ThenBy(SourceRank).ThenBy(Order), stable (Program.cs:460)
+                for (uint32_t k = 1; k < nm; ++k) {
+                    H h = ws.hnd[k]; double sc = ws.score[k]; uint32_t od = ws.order[k]; uint32_t sr = ws.src[k];
+                    int rk = source_rank(sr);
+                    uint32_t pos = k;
+                    while (pos > 0) {
+                        double qs = ws.score[pos - 1];
+                        int qr = source_rank(ws.src[pos - 1]);
+                        bool q_first = (qs > sc) || (qs == sc && (qr < rk || (qr == rk && ws.order[pos - 1] <= od)));
+                        if (q_first) break;
+                        ws.hnd[pos] = ws.hnd[pos - 1]; ws.score[pos] = ws.score[pos - 1]; ws.order[pos] = ws.order[pos - 1]; ws.src[pos] = ws.src[pos - 1];
+                        --pos;
+                    }
+                    ws.hnd[pos] = h; ws.score[pos] = sc; ws.order[pos] = od; ws.src[pos] = (uint8_t)sr;
+                }
+                n = nm;
+            }
         }
         if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
     }
@@ -609,7 +677,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     }
     v.n_dropped = (uint16_t)(ndl > 0xFFFF ? 0xFFFF : ndl);
 
-    // OrderByDescending(Score).ThenBy(SourceRank).ThenBy(Order), Program.cs:651-655.  Orders are distinct, so the key is total.
+    // OrderByDescending(Score).ThenBy(SourceRank).ThenBy(Order), Program.cs:651-655, stable: merged replies can tie on the whole key.
     for (uint32_t k = 0; k < nu; ++k) {
         double sc = ws.score[k];
         int rk = source_rank(ws.src[k] & 0xF);
@@ -619,7 +687,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             uint32_t q = ws.sorted[pos - 1];
             double qs = ws.score[q];
             int qr = source_rank(ws.src[q] & 0xF);
-            bool q_first = (qs > sc) || (qs == sc && (qr < rk || (qr == rk && ws.order[q] < od)));
+            bool q_first = (qs > sc) || (qs == sc && (qr < rk || (qr == rk && ws.order[q] <= od)));
             if (q_first) break;
             ws.sorted[pos] = q;
             --pos;

@@ -19,7 +19,7 @@ _LIB = None
 EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_format_top_tags", "tp_get_last_timing",
-    "tp_triage_lines",
+    "tp_triage_lines", "tp_run_merged",
 )
 
 
@@ -55,6 +55,7 @@ def load_library():
     L.tp_run_lines_device.argtypes = [C.c_void_p, C.POINTER(tp_device_io), C.POINTER(C.c_uint64)]
     L.tp_format_top_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tp_get_last_timing.argtypes = [C.c_void_p, C.POINTER(tp_timing)]
+    L.tp_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(tp_result)]
     L.tp_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     _LIB = L
     return L
@@ -216,6 +217,19 @@ class TagPipe:
         self._check(self._L.tp_run_scored(self._h, arena.ctypes.data if arena.size else None, tag_offsets.ctypes.data, tag_begin.ctypes.data,
                                           scores.ctypes.data if scores.size else None, sources.ctypes.data if sources.size else None,
                                           len(tag_begin) - 1, C.byref(res)))
+        return self._collect(res)
+
+    def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap=15):
+        """tp_run_merged: primary and secondary tagger replies per file, merged as Program.cs:214-221 does."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
+        tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
+        secondary_begin = np.ascontiguousarray(secondary_begin, dtype=np.uint64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        res = tp_result()
+        self._check(self._L.tp_run_merged(self._h, arena.ctypes.data if arena.size else None, tag_offsets.ctypes.data, tag_begin.ctypes.data,
+                                          secondary_begin.ctypes.data if secondary_begin.size else None, scores.ctypes.data if scores.size else None,
+                                          int(secondary_cap), len(tag_begin) - 1, C.byref(res)))
         return self._collect(res)
 
     # ---- device-resident run ---------------------------------------------------------------------

@@ -201,6 +201,21 @@ int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uin
 int tp_run_scored(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin,
                   const double* scores, const uint8_t* sources, uint64_t n_files, tp_result* out);
 
+/*
+ * Scored ingest of the two tagger replies the reference asks for per image
+ * (Program.cs:214-221: primary threshold, then --joy-threshold-secondary):
+ * file i owns tags tag_begin[i] .. tag_begin[i+1], of which those below
+ * secondary_begin[i] are the primary reply (TP_SRC_PRIMARY_JOY) and the rest
+ * the secondary one (TP_SRC_SECONDARY_JOY); tag_begin[i] <= secondary_begin[i]
+ * <= tag_begin[i+1].  Each reply is parsed like ParseJoyTags (Program.cs:463-489),
+ * the secondary one is cut down by LimitSecondaryTags with secondary_cap new
+ * tags (Program.cs:801-815; the reference's default is 15, <= 0 drops the
+ * whole reply), MergeCandidateTags (Program.cs:442-461) joins them, and the
+ * merged list goes through the pipeline.
+ */
+int tp_run_merged(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin,
+                  const uint64_t* secondary_begin, const double* scores, int secondary_cap, uint64_t n_files, tp_result* out);
+
 void tp_release(tp_ctx* ctx, tp_result* res);
 
 /*

@@ -63,6 +63,8 @@ def lib():
         L.orc_should_drop_tag.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_normalize_raw_tag_line.restype = C.c_char_p
         L.orc_normalize_raw_tag_line.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.orc_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                     C.POINTER(orc_result)]
         L.orc_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_infer_action_tags.restype = C.c_char_p
         L.orc_infer_action_tags.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
@@ -221,6 +223,21 @@ class Oracle:
         res = orc_result()
         rc = self._L.orc_run_scored(self._h, arena.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data,
                                     scores.ctypes.data, sources.ctypes.data, n, threads, int(detail), C.byref(res))
+        if rc != 0:
+            raise OracleError(self._L.orc_last_error().decode("utf-8", "replace"))
+        return self._collect(res, n, detail)
+
+    def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap, threads=1, detail=False):
+        """Two tagger replies per file, merged as Program.cs:214-221 does, then the pipeline."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
+        tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
+        secondary_begin = np.ascontiguousarray(secondary_begin, dtype=np.uint64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        n = len(tag_begin) - 1
+        res = orc_result()
+        rc = self._L.orc_run_merged(self._h, arena.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data, secondary_begin.ctypes.data,
+                                    scores.ctypes.data, int(secondary_cap), n, threads, int(detail), C.byref(res))
         if rc != 0:
             raise OracleError(self._L.orc_last_error().decode("utf-8", "replace"))
         return self._collect(res, n, detail)

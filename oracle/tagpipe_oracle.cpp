@@ -490,6 +490,55 @@ struct Engine {
     }
     // ---- Program.cs:712-717 ---------------------------------------------------------------
     static int SourceRank(int source) { return source == 0 ? 0 : source == 1 ? 1 : source == 2 ? 2 : 3; }
+    // ---- Program.cs:796-799 ---------------------------------------------------------------
+    static int PreferSource(int a, int b, double scoreA, double scoreB) {
+        if (std::fabs(scoreA - scoreB) > 0.03) return scoreA >= scoreB ? a : b;
+        return SourceRank(a) <= SourceRank(b) ? a : b;
+    }
+    // ---- Program.cs:442-461 ---------------------------------------------------------------
+    static std::vector<Candidate> MergeCandidateTags(const std::vector<Candidate>& a, const std::vector<Candidate>& b) {
+        IMap<Candidate> map;
+        auto feed = [&](const Candidate& c) {
+            Candidate* old = map.find(c.tag);
+            if (!old) { map.set(c.tag, c); return; }
+            const Candidate& bestScore = c.score > old->score ? c : *old;
+            int earliestOrder = std::min(old->order, c.order);
+            bool close = std::fabs(old->score - c.score) <= 0.03;
+            int source = PreferSource(old->source, c.source, close ? old->score : bestScore.score, close ? c.score : bestScore.score);
+            Candidate merged{bestScore.tag, std::max(old->score, c.score), earliestOrder, source};
+            *old = merged;
+        };
+        for (auto& c : a) feed(c);
+        for (auto& c : b) feed(c);
+        std::vector<Candidate> out;
+        for (auto& kv : map.items) out.push_back(kv.second);
+        std::stable_sort(out.begin(), out.end(), [](const Candidate& x, const Candidate& y) {
+            if (x.score != y.score) return x.score > y.score;
+            int rx = SourceRank(x.source), ry = SourceRank(y.source);
+            if (rx != ry) return rx < ry;
+            return x.order < y.order;
+        });
+        return out;
+    }
+    // ---- Program.cs:801-815 ---------------------------------------------------------------
+    static std::vector<Candidate> LimitSecondaryTags(const std::vector<Candidate>& primary, const std::vector<Candidate>& secondary, int cap) {
+        std::vector<Candidate> accepted;
+        if (cap <= 0 || secondary.empty()) return accepted;
+        ISet primarySet;
+        for (auto& c : primary) primarySet.add(c.tag);
+        std::vector<Candidate> sorted = secondary;
+        std::stable_sort(sorted.begin(), sorted.end(), [](const Candidate& x, const Candidate& y) {
+            if (x.score != y.score) return x.score > y.score;
+            return x.order < y.order;
+        });
+        for (auto& c : sorted) {
+            if (primarySet.has(c.tag)) { accepted.push_back(c); continue; }
+            if (cap == 0) continue;
+            accepted.push_back(c);
+            cap--;
+        }
+        return accepted;
+    }
     // ---- Program.cs:702-710 ---------------------------------------------------------------
     int DetermineStyleQualityCap(const std::vector<Candidate>& candidates) const {
         ISet strong;
@@ -1172,7 +1221,10 @@ struct Ctx {
 
 static thread_local std::string g_err;
 
-struct ScoredInput { const uint8_t* arena; const uint64_t* tagOffsets; const uint64_t* tagBegin; const double* scores; const uint8_t* sources; };
+// secondaryBegin != nullptr: tags [tagBegin[i], secondaryBegin[i]) are the primary tagger reply, [secondaryBegin[i], tagBegin[i+1]) the
+// secondary one, merged as Program.cs:214-221 does (sources is not read then).
+struct ScoredInput { const uint8_t* arena; const uint64_t* tagOffsets; const uint64_t* tagBegin; const double* scores; const uint8_t* sources;
+                     const uint64_t* secondaryBegin; int secondaryCap; };
 
 static void run_batch(const Ctx& cx, const uint8_t* arena, const uint64_t* offsets, const ScoredInput* scored, uint64_t n, bool wantDetail, int threads,
                       Batch& b, tp_counters& ctr) {
@@ -1193,16 +1245,27 @@ static void run_batch(const Ctx& cx, const uint8_t* arena, const uint64_t* offse
                 cands = e.ParseTagCandidatesFromLine(raw, nullptr, e.lineWeight, e.lineSource, &rejected);
             } else {
                 // ParseJoyTags, object-shaped entries (Program.cs:473-487)
-                int order = 0;
-                for (uint64_t t = scored->tagBegin[i]; t < scored->tagBegin[i + 1]; ++t) {
-                    S raw = utf8_to_16(scored->arena + scored->tagOffsets[t], (size_t)(scored->tagOffsets[t + 1] - scored->tagOffsets[t]));
-                    S nn = e.NormalizeTag(raw);
-                    if (!is_blank(nn)) cands.push_back(Candidate{nn, scored->scores[t], order++, scored->sources[t]});
+                auto parse = [&](uint64_t lo, uint64_t hi, int fixedSource) {
+                    std::vector<Candidate> list;
+                    int order = 0;
+                    for (uint64_t t = lo; t < hi; ++t) {
+                        S raw = utf8_to_16(scored->arena + scored->tagOffsets[t], (size_t)(scored->tagOffsets[t + 1] - scored->tagOffsets[t]));
+                        S nn = e.NormalizeTag(raw);
+                        if (!is_blank(nn)) list.push_back(Candidate{nn, scored->scores[t], order++, fixedSource >= 0 ? fixedSource : (int)scored->sources[t]});
+                    }
+                    std::stable_sort(list.begin(), list.end(), [](const Candidate& a, const Candidate& c) {
+                        if (a.score != c.score) return a.score > c.score;
+                        return a.order < c.order;
+                    });
+                    return list;
+                };
+                if (!scored->secondaryBegin) cands = parse(scored->tagBegin[i], scored->tagBegin[i + 1], -1);
+                else {
+                    // the two tagger calls and their merge, Program.cs:214-221
+                    std::vector<Candidate> primary = parse(scored->tagBegin[i], scored->secondaryBegin[i], TP_SRC_PRIMARY_JOY);
+                    std::vector<Candidate> secondary = parse(scored->secondaryBegin[i], scored->tagBegin[i + 1], TP_SRC_SECONDARY_JOY);
+                    cands = Engine::MergeCandidateTags(primary, Engine::LimitSecondaryTags(primary, secondary, scored->secondaryCap));
                 }
-                std::stable_sort(cands.begin(), cands.end(), [](const Candidate& a, const Candidate& c) {
-                    if (a.score != c.score) return a.score > c.score;
-                    return a.order < c.order;
-                });
             }
             e.run_candidates(cands, rejected, caps[i], b.verdicts[i], wantDetail ? &b.details[i] : nullptr,
                              cx.firedWords ? &b.fired[i * cx.firedWords] : nullptr, cx.firedWords, nf ? &b.facetChoice[i * nf] : nullptr, &ctags[i]);
@@ -1327,7 +1390,20 @@ int orc_run_scored(void* ctx, const uint8_t* arena, const uint64_t* tag_offsets,
         if (!cx || !out) { g_err = "invalid argument"; return TP_E_INVALID_ARG; }
         std::unique_ptr<Batch> b(new Batch());
         tp_counters ctr;
-        ScoredInput si{arena, tag_offsets, tag_begin, scores, sources};
+        ScoredInput si{arena, tag_offsets, tag_begin, scores, sources, nullptr, 0};
+        run_batch(*cx, nullptr, nullptr, &si, n, detail != 0, threads, *b, ctr);
+        return finish(b.release(), n, ctr, out);
+    } catch (const std::exception& ex) { g_err = ex.what(); return TP_E_INVALID_ARG; }
+}
+
+int orc_run_merged(void* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin,
+                   const double* scores, int secondary_cap, uint64_t n, int threads, int detail, orc_result* out) {
+    try {
+        Ctx* cx = (Ctx*)ctx;
+        if (!cx || !out || !secondary_begin) { g_err = "invalid argument"; return TP_E_INVALID_ARG; }
+        std::unique_ptr<Batch> b(new Batch());
+        tp_counters ctr;
+        ScoredInput si{arena, tag_offsets, tag_begin, scores, nullptr, secondary_begin, secondary_cap};
         run_batch(*cx, nullptr, nullptr, &si, n, detail != 0, threads, *b, ctr);
         return finish(b.release(), n, ctr, out);
     } catch (const std::exception& ex) { g_err = ex.what(); return TP_E_INVALID_ARG; }

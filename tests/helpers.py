@@ -52,6 +52,7 @@ def sim_lib():
         L.sim_run_scored.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
         L.sim_run_lines_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result), C.POINTER(C.c_uint64)]
         L.sim_release.argtypes = [C.POINTER(sim_result)]
+        L.sim_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(sim_result)]
         L.sim_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         _SIM = L
     return _SIM
@@ -133,6 +134,18 @@ class HostSim:
     def run_texts_fast(self, texts):
         a, o = pack_lines(texts)
         return self.run_lines_fast(a, o)
+
+    def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap):
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        pad = np.concatenate([arena, np.zeros(16, np.uint8)])
+        tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
+        tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
+        secondary_begin = np.ascontiguousarray(secondary_begin, dtype=np.uint64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        res = sim_result()
+        rc = self._L.sim_run_merged(self._h, pad.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data, secondary_begin.ctypes.data,
+                                    scores.ctypes.data, int(secondary_cap), len(tag_begin) - 1, C.byref(res))
+        return self._collect(res, rc)
 
     def triage_texts(self, texts, general_only=False):
         """(bad, n_general): the triage flow on the emulated wavefront; general_only runs the thread-per-file code alone."""

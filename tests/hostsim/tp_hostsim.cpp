@@ -43,7 +43,7 @@ uint32_t commas(const uint8_t* p, uint64_t n) { uint32_t c = 0; for (uint64_t i 
 
 // Runs files [0,n) wave by wave; `emit` receives each file's final handle list.
 void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const double* scores, const uint8_t* sources, uint64_t n,
-         int mode, SimOut& o, std::vector<std::vector<H>>* fin_lists) {
+         int mode, SimOut& o, std::vector<std::vector<H>>* fin_lists, const uint64_t* secondary_begin = nullptr, int secondary_cap = 0) {
     const DevTables& t = s.dt;
     o.offsets.assign(n + 1, 0);
     o.verdicts.assign(n, tp_verdict{});
@@ -66,7 +66,8 @@ void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint
         for (uint64_t f = w0; f < w1; ++f) {
             FileWs ws = ws_bind(wsmem.data(), L, (uint32_t)(f & 63));
             FileIn in{};
-            if (tag_begin) { in.arena = arena; in.tag_offsets = offsets; in.tag_lo = tag_begin[f]; in.tag_hi = tag_begin[f + 1]; in.scores = scores; in.sources = sources; }
+            if (tag_begin) { in.arena = arena; in.tag_offsets = offsets; in.tag_lo = tag_begin[f]; in.tag_hi = tag_begin[f + 1]; in.scores = scores; in.sources = sources;
+                             in.merged = secondary_begin != nullptr; in.tag_mid = secondary_begin ? secondary_begin[f] : in.tag_hi; in.secondary_cap = secondary_cap; }
             else { in.text = arena + offsets[f]; in.len = (uint32_t)(offsets[f + 1] - offsets[f]); }
             FileOut fo;
             process_file(t, in, ws, fo, o.fired.data() + f * t.fired_words, t.n_facets ? &o.facets[f * t.n_facets] : nullptr, mode);
@@ -155,6 +156,13 @@ int sim_run_scored(void* h, const uint8_t* arena, const uint64_t* tag_offsets, c
     g_err.clear();
     SimOut* o = new SimOut();
     run(*(Sim*)h, arena, tag_offsets, tag_begin, scores, sources, n, 0, *o, nullptr);
+    return finish(o, n, r);
+}
+int sim_run_merged(void* h, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin, const double* scores,
+                   int secondary_cap, uint64_t n, sim_result* r) {
+    g_err.clear();
+    SimOut* o = new SimOut();
+    run(*(Sim*)h, arena, tag_offsets, tag_begin, scores, nullptr, n, 0, *o, nullptr, secondary_begin, secondary_cap);
     return finish(o, n, r);
 }
 // The GPU flow: every file first goes through the wave-per-file kernel body (tp_fast.h) on an emulated wavefront;

@@ -77,6 +77,20 @@ def test_scored_ingest(name):
     assert_same_results(got, want, p.histogram_dict(got.histogram), name + " scored")
 
 
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict", "builtin"])
+@pytest.mark.parametrize("cap", [15, 2, 0])
+def test_merged_tagger_replies(name, cap):
+    """tp_run_merged against MergeCandidateTags(primary, LimitSecondaryTags(...)) of the oracle (Program.cs:214-221)."""
+    from test_merged_cpu import merged_inputs
+    cfg = CONFIGS[name]()
+    args = merged_inputs(41 + cap, 1500)
+    p = pipe_for(cfg)
+    got, want = p.run_merged(*args, cap), Oracle(cfg).run_merged(*args, cap, threads=8)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "%s merged cap %d" % (name, cap))
+    empty = np.zeros(1, np.uint64)
+    assert p.run_merged(np.zeros(0, np.uint8), empty, empty, np.zeros(0, np.uint64), np.zeros(0), cap).caption_offsets.tolist() == [0]
+
+
 def test_empty_and_ragged_batches():
     cfg = shipped_config()
     p, o = pipe_for(cfg), Oracle(cfg)

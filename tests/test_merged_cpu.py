@@ -1,0 +1,74 @@
+"""Two tagger replies per file (primary and secondary threshold) merged as Program.cs:214-221 does: the general kernel body
+against the oracle, without a GPU."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import DATA, HostSim, Oracle, assert_same_results
+from test_pipeline_logic_cpu import CONFIGS
+
+
+def merged_inputs(seed, n_files):
+    """(arena, tag_offsets, tag_begin, secondary_begin, scores).  The secondary reply repeats most of the primary one (a lower
+    threshold on the same image) with equal, close (<= 0.03) and distant scores, adds new tags beyond any cap, and both
+    replies hold duplicates after normalisation, score ties and blanks."""
+    rng = random.Random(seed)
+    vocab = [l.strip() for l in open(DATA + "/top_tags.txt") if l.strip()][:500] + ["foot", "fingers", "Pedal Stimulation", "zz_unknown", "x'.", "", " ", "a",
+                                                                                      "feet", "penis", "footjob", "soles", "toes", "barefoot"]
+    tags, begin, mid, scores = [], [0], [], []
+    for _ in range(n_files):
+        kp = rng.choice([0, 1, 3, 10, 30, 60])
+        prim = [(rng.choice(vocab), rng.choice([round(rng.random(), 2), 0.5, 0.6, 0.28, 0.47])) for _ in range(kp)]
+        if prim and rng.random() < 0.3:
+            prim.append((prim[0][0].upper(), prim[0][1] + rng.choice([0.0, 0.02, 0.04, -0.02])))   # duplicate after normalisation
+        sec = []
+        if rng.random() < 0.85:
+            for t, s in prim:
+                if rng.random() < 0.8:
+                    sec.append((t, s + rng.choice([0.0, 0.0, 0.01, -0.01, 0.03, -0.03, 0.031, 0.05, -0.2, 0.3])))
+            for _ in range(rng.choice([0, 2, 10, 25])):
+                sec.append((rng.choice(vocab), rng.choice([round(0.35 * rng.random(), 2), 0.3, 0.5])))
+            rng.shuffle(sec)
+        for t, s in prim:
+            tags.append(t); scores.append(s)
+        mid.append(len(tags))
+        for t, s in sec:
+            tags.append(t); scores.append(s)
+        begin.append(len(tags))
+    enc = [t.encode() for t in tags]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs[1:] = np.cumsum([len(b) for b in enc])
+    arena = np.frombuffer(b"".join(enc), dtype=np.uint8).copy() if enc else np.zeros(0, np.uint8)
+    return arena, offs, np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64), np.array(scores, dtype=np.float64)
+
+
+def test_oracle_merge_known_answers():
+    """Hand-derived: cap, primary-set pass-through, score/order/source of a merged entry."""
+    from helpers import shipped_config
+    o = Oracle(shipped_config(safe_mode=False))
+    #            primary                  secondary
+    tags = ["1girl", "smile", "dress",   "smile", "long_hair", "blush", "hat"]
+    scores = [0.9, 0.5, 0.4,             0.52, 0.34, 0.33, 0.32]
+    enc = [t.encode() for t in tags]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in enc])
+    arena = np.frombuffer(b"".join(enc), dtype=np.uint8).copy()
+    begin, mid = np.array([0, 7], dtype=np.uint64), np.array([3], dtype=np.uint64)
+    cap2 = o.run_merged(arena, offs, begin, mid, scores, 2).caption(0).decode()
+    cap0 = o.run_merged(arena, offs, begin, mid, scores, 0).caption(0).decode()
+    only_primary = o.run_scored(arena[:int(offs[3])], offs[:4], np.array([0, 3], dtype=np.uint64), scores[:3], np.zeros(3, np.uint8)).caption(0).decode()
+    assert "long_hair" in cap2 and "blush" in cap2 and "hat" not in cap2          # two new tags, best scores first
+    assert cap0 == only_primary                                                  # cap <= 0: the secondary reply is ignored altogether
+    assert "hat" in o.run_merged(arena, offs, begin, mid, scores, 15).caption(0).decode()
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict", "builtin"])
+@pytest.mark.parametrize("cap", [15, 3, 0])
+def test_merged_ingest(name, cap):
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    args = merged_inputs(17 + cap, 400)
+    want, got = o.run_merged(*args, cap), s.run_merged(*args, cap)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "%s merged cap %d" % (name, cap))

@@ -2,7 +2,5 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 200 python3 tools/triage_timing.py c2 1000000 > gpurun_out/triage.txt 2>&1
-cat gpurun_out/triage.txt
-timeout -k 10 300 python3 bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
-cat gpurun_out/bench.json
+timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.txt 2>&1 || { tail -30 gpurun_out/gpu_tests.txt; exit 1; }
+tail -3 gpurun_out/gpu_tests.txt
