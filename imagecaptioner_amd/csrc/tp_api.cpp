@@ -506,6 +506,7 @@ int tp_get_name(const tp_ctx* ctx, int kind, uint32_t index, const char** utf8, 
             if (f < h.facet_rule_tags.size() && r < h.facet_rule_tags[f].size()) s = &h.facet_rule_tags[f][r];
             break;
         }
+        case TP_NAME_SAFE_TAG: if (index < h.safe_tags.size()) s = &h.safe_tags[index]; break;
         default: break;
     }
     if (!s) return fail(TP_E_INVALID_ARG, "name index out of range");
@@ -619,6 +620,84 @@ int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* ou
         uint64_t o = 0;
         for (uint32_t i : ids) { std::memcpy(out + o, h.strings[i].data(), h.strings[i].size()); o += h.strings[i].size(); out[o++] = '\n'; }
         return TP_OK;
+    });
+}
+
+int tp_format_fired_rules(const tp_ctx* ctx, const uint32_t* fired, const uint16_t* facet_choice, uint64_t n_files, uint8_t* out, uint64_t capacity,
+                          uint64_t* out_offsets, uint64_t* needed) {
+    if (!ctx || !out_offsets || !needed) return fail(TP_E_INVALID_ARG, "null argument");
+    const HostTables& h = ctx->ht;
+    const uint32_t n_rules = ctx->dt.n_rules, n_facets = ctx->dt.n_facets, fw = ctx->dt.fired_words;
+    if (n_files && ((fw && !fired) || (n_facets && !facet_choice))) return fail(TP_E_INVALID_ARG, "null argument");
+    return guarded([&]() {
+        std::string text;
+        // two passes over the same generator: sizes first, then the bytes
+        for (int pass = 0; pass < 2; ++pass) {
+            uint64_t pos = 0;
+            for (uint64_t i = 0; i < n_files; ++i) {
+                if (pass == 0) out_offsets[i] = pos;
+                bool first = true;
+                auto put = [&](const std::string& s) {
+                    uint64_t n = s.size() + (first ? 0 : 1);
+                    if (pass == 1) { if (!first) out[pos] = ';'; std::memcpy(out + pos + (first ? 0 : 1), s.data(), s.size()); }
+                    pos += n;
+                    first = false;
+                };
+                const uint32_t* fb = fired + i * fw;
+                auto bit = [&](uint32_t b) { return (fb[b >> 5] >> (b & 31)) & 1u; };
+                for (uint32_t r = 0; r < n_rules; ++r) {
+                    if (!bit(r)) continue;
+                    put("action:" + h.rule_names[r]);
+                    for (uint32_t s = h.rules[r].sub_off; s < h.rules[r].sub_off + h.rules[r].sub_cnt; ++s)
+                        if (bit(n_rules + s)) put("subtype:" + h.sub_names[s]);
+                }
+                for (uint32_t f = 0; f < n_facets; ++f) {
+                    uint16_t c = facet_choice[i * n_facets + f];
+                    const std::string& selected = c == 0xFFFF ? h.facet_defaults[f] : h.facet_rule_tags[f].at(c);
+                    if (c != 0xFFFF) put("facet:" + h.facet_names[f] + ":" + selected);
+                    if (selected == h.facet_defaults[f]) put("facet:" + h.facet_names[f] + ":" + h.facet_defaults[f] + ":default");
+                }
+            }
+            if (pass == 0) {
+                out_offsets[n_files] = pos;
+                *needed = pos;
+                if (pos == 0) return (int)TP_OK;
+                if (!out || capacity < pos) return fail(TP_E_CAPACITY, "output buffer too small");
+            }
+        }
+        return (int)TP_OK;
+    });
+}
+
+const char* tp_needtag_text(void) { return "low tags; short caption or missing core; check later"; }   // Program.cs:323
+
+int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t n_files, int keep_needtag, uint8_t* needtag, uint8_t* reject,
+                         uint64_t capacity, uint64_t* reject_offsets, uint64_t* needed) {
+    if (!ctx || !reject_offsets || !needed || (n_files && (!verdicts || !needtag))) return fail(TP_E_INVALID_ARG, "null argument");
+    const HostTables& h = ctx->ht;
+    const std::string nl((const char*)ctx->dt.newline, ctx->dt.newline_len);
+    return guarded([&]() {
+        uint64_t pos = 0;
+        for (uint64_t i = 0; i < n_files; ++i) {
+            const tp_verdict& v = verdicts[i];
+            reject_offsets[i] = pos;
+            if (v.flags & TP_F_UNSUPPORTED) { needtag[i] = TP_NEEDTAG_LEAVE; continue; }
+            needtag[i] = (v.flags & TP_F_LOW) ? (keep_needtag ? TP_NEEDTAG_WRITE : TP_NEEDTAG_LEAVE) : TP_NEEDTAG_DELETE;   // Program.cs:320-326
+            if (v.flags & TP_F_SAFE_REJECT) {
+                if (v.safe_hit < 0 || (size_t)v.safe_hit >= h.safe_tags.size()) return fail(TP_E_INVALID_ARG, "verdict with a safe-mode hit out of range");
+                pos += 10 + h.safe_tags[v.safe_hit].size() + nl.size();      // "safe_mode:" + tag + newline, Program.cs:944, 955
+            }
+        }
+        reject_offsets[n_files] = pos;
+        *needed = pos;
+        if (pos == 0) return (int)TP_OK;
+        if (!reject || capacity < pos) return fail(TP_E_CAPACITY, "output buffer too small");
+        for (uint64_t i = 0; i < n_files; ++i) {
+            if (reject_offsets[i + 1] == reject_offsets[i]) continue;
+            std::string s = "safe_mode:" + h.safe_tags[verdicts[i].safe_hit] + nl;
+            std::memcpy(reject + reject_offsets[i], s.data(), s.size());
+        }
+        return (int)TP_OK;
     });
 }
 

@@ -838,6 +838,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         }
     };
     out.pool.clear(); out.rules.clear(); out.subs.clear(); out.facets.clear(); out.facet_rules.clear();
+    out.safe_tags.assign(std::begin(kSafeList), std::end(kSafeList));
     out.rule_names.clear(); out.sub_names.clear(); out.facet_names.clear(); out.facet_defaults.clear(); out.facet_rule_tags.clear();
     for (auto& a : ld.actions) {
         DRule r{};

@@ -41,6 +41,7 @@ struct HostTables {
     std::vector<std::string> sub_names;     // "parent:tag" per subtype (global index)
     std::vector<std::string> facet_names, facet_defaults;
     std::vector<std::vector<std::string>> facet_rule_tags;
+    std::vector<std::string> safe_tags;     // SafeModeRejectTags in the order tp_verdict.safe_hit indexes
     std::vector<uint8_t> fallback_line;     // the minimal fallback line (Program.cs:165), UTF-8
     uint32_t n_known = 0;
     bool strict = false, known_found = false;

@@ -19,7 +19,7 @@ _LIB = None
 EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_format_top_tags", "tp_get_last_timing",
-    "tp_triage_lines", "tp_run_merged",
+    "tp_triage_lines", "tp_run_merged", "tp_format_fired_rules", "tp_needtag_text", "tp_format_side_files",
 )
 
 
@@ -56,6 +56,9 @@ def load_library():
     L.tp_format_top_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tp_get_last_timing.argtypes = [C.c_void_p, C.POINTER(tp_timing)]
     L.tp_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(tp_result)]
+    L.tp_format_fired_rules.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.tp_needtag_text.restype = C.c_char_p
+    L.tp_format_side_files.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     L.tp_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     _LIB = L
     return L
@@ -151,6 +154,47 @@ class TagPipe:
         if need.value:
             self._check(self._L.tp_format_top_tags(self._h, hist.ctypes.data, buf.ctypes.data, need.value, C.byref(need)))
         return bytes(buf[:need.value])
+
+    def fired_rules(self, result):
+        """tp_format_fired_rules: per file the ';'-joined firedRules string of the audit row (Program.cs:334, 966)."""
+        n = len(result.verdicts)
+        fired = np.ascontiguousarray(result.fired, dtype=np.uint32)
+        fc = np.ascontiguousarray(result.facet_choice, dtype=np.uint16)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        need = C.c_uint64()
+        rc = self._L.tp_format_fired_rules(self._h, fired.ctypes.data if fired.size else None, fc.ctypes.data if fc.size else None, n, None, 0,
+                                           offs.ctypes.data, C.byref(need))
+        buf = np.zeros(max(need.value, 1), dtype=np.uint8)
+        if need.value:
+            assert rc == TP_E_CAPACITY, rc
+            self._check(self._L.tp_format_fired_rules(self._h, fired.ctypes.data if fired.size else None, fc.ctypes.data if fc.size else None, n,
+                                                      buf.ctypes.data, need.value, offs.ctypes.data, C.byref(need)))
+        else:
+            self._check(rc)
+        raw = buf.tobytes()
+        return [raw[int(offs[i]):int(offs[i + 1])].decode("utf-8") for i in range(n)]
+
+    def side_files(self, verdicts, keep_needtag):
+        """tp_format_side_files: (needtag action per file, reject text per file) as the loop writes them (Program.cs:319-332)."""
+        v = np.ascontiguousarray(verdicts)
+        n = len(v)
+        act = np.zeros(n, dtype=np.uint8)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        need = C.c_uint64()
+        rc = self._L.tp_format_side_files(self._h, v.ctypes.data if n else None, n, int(keep_needtag), act.ctypes.data if n else None, None, 0,
+                                          offs.ctypes.data, C.byref(need))
+        buf = np.zeros(max(need.value, 1), dtype=np.uint8)
+        if need.value:
+            assert rc == TP_E_CAPACITY, rc
+            self._check(self._L.tp_format_side_files(self._h, v.ctypes.data, n, int(keep_needtag), act.ctypes.data, buf.ctypes.data, need.value,
+                                                     offs.ctypes.data, C.byref(need)))
+        else:
+            self._check(rc)
+        raw = buf.tobytes()
+        return act, [raw[int(offs[i]):int(offs[i + 1])] for i in range(n)]
+
+    def needtag_text(self):
+        return self._L.tp_needtag_text()
 
     def last_timing(self):
         t = tp_timing()

@@ -161,6 +161,7 @@ int tp_get_string(const tp_ctx* ctx, uint32_t id, const char** utf8, uint32_t* l
 #define TP_NAME_FACET          2  /* index = facet          -> Name */
 #define TP_NAME_FACET_DEFAULT  3  /* index = facet          -> DefaultTag */
 #define TP_NAME_FACET_RULE     4  /* index = facet << 16 | rule -> rule Tag */
+#define TP_NAME_SAFE_TAG       5  /* index = tp_verdict.safe_hit -> the SafeModeRejectTags entry (Program.cs:43-45) */
 int tp_get_name(const tp_ctx* ctx, int kind, uint32_t index, const char** utf8, uint32_t* len);
 
 /*
@@ -272,6 +273,38 @@ typedef struct tp_timing {
     float other_ms;     /* sizing, scans, host round trips between kernels */
     uint64_t general_files; /* how many files took the thread-per-file kernel */
 } tp_timing;
+/*
+ * firedRules of every file as AppendAudit joins them (Program.cs:334, 966:
+ * string.Join(";", firedRules), before Csv()): "action:{parent}" and
+ * "subtype:{parent}:{tag}" in rule order (Program.cs:735-749), then per facet
+ * "facet:{name}:{tag}" for the chosen rule and "facet:{name}:{default}:default"
+ * when the chosen tag is the default tag (Program.cs:760-772).  fired and
+ * facet_choice are tp_result's detail arrays (host pointers).  File i's text is
+ * out[out_offsets[i] .. out_offsets[i+1]).  *needed receives the total size;
+ * TP_E_CAPACITY when capacity is smaller (nothing is written to out then).
+ */
+int tp_format_fired_rules(const tp_ctx* ctx, const uint32_t* fired, const uint16_t* facet_choice, uint64_t n_files,
+                          uint8_t* out, uint64_t capacity, uint64_t* out_offsets, uint64_t* needed);
+
+/*
+ * What the loop writes beside a caption (Program.cs:319-332, 947-956), from
+ * the verdicts (host pointer).  needtag[i]: TP_NEEDTAG_WRITE = write
+ * tp_needtag_text() + the configured newline to <image>.needtag (low caption
+ * and --keep-needtag), TP_NEEDTAG_DELETE = TryDelete it (not low),
+ * TP_NEEDTAG_LEAVE = neither (low without --keep-needtag, or a file the device
+ * code did not process).  reject[reject_offsets[i] .. reject_offsets[i+1]) is
+ * the content of <image>.reject.txt, "safe_mode:{tag}" + newline, for files
+ * with TP_F_SAFE_REJECT and empty for the others; the tag is spelled as in
+ * SafeModeRejectTags (the reference prints the final tag's own spelling, which
+ * differs only when a rule file writes such a tag with capitals).
+ */
+#define TP_NEEDTAG_DELETE 0
+#define TP_NEEDTAG_WRITE  1
+#define TP_NEEDTAG_LEAVE  2
+const char* tp_needtag_text(void);
+int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t n_files, int keep_needtag, uint8_t* needtag,
+                         uint8_t* reject, uint64_t capacity, uint64_t* reject_offsets, uint64_t* needed);
+
 int tp_get_last_timing(const tp_ctx* ctx, tp_timing* out);
 
 #ifdef __cplusplus

@@ -91,6 +91,50 @@ def test_merged_tagger_replies(name, cap):
     assert p.run_merged(np.zeros(0, np.uint8), empty, empty, np.zeros(0, np.uint64), np.zeros(0), cap).caption_offsets.tolist() == [0]
 
 
+@pytest.mark.parametrize("name", ["shipped", "novocab_w07_crlf", "c5"])
+def test_audit_strings_and_side_files(name):
+    """firedRules text, .needtag decision and .reject.txt content (Program.cs:319-334, 947-956) against the oracle's own lists."""
+    if name == "c5":
+        from imagecaptioner_amd.corpus import make_corpus
+        c = make_corpus("c5", 1500, seed=3)
+        cfg = Config(**c.config_kwargs)
+        arena, offsets = c.arena, c.offsets
+    else:
+        cfg = CONFIGS[name]() if name != "shipped" else shipped_config(safe_mode=True)
+        lines = EDGE_LINES + fuzz_lines(57, 1500) + ["1girl, nude, smile, dress, long_hair", "1girl, smile, dress, penis, feet, barefoot, soles, toes, footjob"]
+        arena, offsets = pack_lines(lines)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    got, want = p.run_lines(arena, offsets), o.run_lines(arena, offsets, threads=8, detail=True)
+    n = len(want.verdicts)
+    fired = p.fired_rules(got)
+    for i in range(n):
+        if got.verdicts["flags"][i] & 0x20:
+            continue
+        assert fired[i] == ";".join(want.details[i]["fired"]), (i, fired[i], want.details[i]["fired"])
+    assert any(fired)
+    nl = (cfg.newline if isinstance(cfg.newline, bytes) else cfg.newline.encode()) if getattr(cfg, "newline", None) else None
+    for keep in (0, 1):
+        act, rej = p.side_files(got.verdicts, keep)
+        for i in range(n):
+            fl = int(want.verdicts["flags"][i])
+            if got.verdicts["flags"][i] & 0x20:
+                assert act[i] == 2 and rej[i] == b""
+                continue
+            assert act[i] == ((1 if keep else 2) if fl & 0x01 else 0)
+            reason = want.details[i]["reject_reason"]
+            if reason:
+                assert rej[i].startswith(reason.encode()) and rej[i][len(reason):] in (b"\n", b"\r\n"), (rej[i], reason)
+                if nl:
+                    assert rej[i] == reason.encode() + nl
+            else:
+                assert rej[i] == b""
+    if name == "shipped":
+        assert any(rej)
+    assert p.needtag_text() == b"low tags; short caption or missing core; check later"
+    act, rej = p.side_files(got.verdicts[:0], 1)
+    assert len(act) == 0 and rej == []
+
+
 def test_empty_and_ragged_batches():
     cfg = shipped_config()
     p, o = pipe_for(cfg), Oracle(cfg)
