@@ -1,7 +1,7 @@
 """ctypes mirror of include/tagpipe.h (struct layouts and constants only).
 
-This is what a host-language binding of the C ABI looks like; the C# P/Invoke
-declarations in INTEGRATION.md are the same layouts.
+This is what a host-language binding of the C ABI looks like: a C# P/Invoke
+binding declares the same layouts.
 """
 import ctypes as C
 
