@@ -888,7 +888,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
 
     // ---- hash table over the strings' bytes ----
     uint32_t slots = 16;
-    while (slots < N * 2u + 2u) slots <<= 1;
+    while (slots < N * 8u + 8u) slots <<= 1;   // at most an eighth full: a wavefront probes until its slowest lane is done (measured: 7 % off the first wave stage against half full)
     out.ht_hash.assign(slots, 0);
     out.ht_id.assign(slots, NO_ID);
     uint64_t probe_sum = 0;
