@@ -171,7 +171,11 @@ TP_HD void set_clear(W& w, BackLds& L) {
 // Returns the slot, or NO_ID when the table is full.  `created` is true for exactly one caller per key.
 template <class W>
 TP_HD uint32_t set_put(W& w, BackLds& L, uint32_t key, uint32_t order, bool& created) {
-    uint32_t s = (key * 2654435761u) >> 24;
+    // Double hashing: the wavefront stays in this loop until its slowest lane is done, and an odd step that differs from
+    // key to key keeps the longest probe sequence short where a step of one would let keys pile up behind one another.
+    const uint32_t hsh = key * 2654435761u;
+    uint32_t s = hsh >> 24;
+    const uint32_t step = ((hsh >> 15) & 0xFEu) | 1u;
     created = false;
     for (uint32_t probe = 0; probe < FAST_SET_SLOTS; ++probe) {
         uint32_t old = w.lds_cas(&L.set_key[s], NO_ID, key);
@@ -180,7 +184,7 @@ TP_HD uint32_t set_put(W& w, BackLds& L, uint32_t key, uint32_t order, bool& cre
             w.lds_min(&L.set_min[s], order);
             return s;
         }
-        s = (s + 1) & (FAST_SET_SLOTS - 1);
+        s = (s + step) & (FAST_SET_SLOTS - 1);
     }
     return NO_ID;
 }
