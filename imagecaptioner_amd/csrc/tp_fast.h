@@ -264,6 +264,9 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
             uint32_t kflags = 0;
             uint32_t id = slot_find32(t, hash_finish(h, n), n, w0, w1, w2, w3, rec, kflags);
             if (id != NO_ID && (!high || (kflags & SLOT_KEY_BASIC))) { out = id; return 1; }
+            // These bytes are the normalised string, and every interned string of up to 32 bytes is a key of the slots: a miss
+            // means the tag is in no table.  Under strict vocabulary it is dropped whatever it looks like (Program.cs:1121-1133).
+            if (id == NO_ID && !high && t.drop_unknown) { valid_dyn = false; dyn_len = n; return 2; }
         }
         if (high) return 3;
     }
