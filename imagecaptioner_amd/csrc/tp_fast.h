@@ -130,6 +130,14 @@ TP_HD uint32_t keep4(uint32_t p, uint32_t limit) {
     nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
     return nv == 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1u);
 }
+// The same on eight bytes.
+constexpr uint64_t REP8_01 = 0x0101010101010101ull, REP8_7F = 0x7F7F7F7F7F7F7F7Full, REP8_80 = 0x8080808080808080ull, REP8_US = REP8_01 * (uint64_t)'_';
+TP_HD uint64_t eq8(uint64_t x, uint64_t pat) { uint64_t y = x ^ pat; return ~(((y & REP8_7F) + REP8_7F) | y | REP8_7F); }
+TP_HD uint64_t ge8(uint64_t x, uint32_t k) { return (x + REP8_01 * (0x80u - k)) & REP8_80; }                                    // bytes of x below 0x80 only
+TP_HD uint64_t ws8(uint64_t x) { return eq8(x, REP8_01 * 0x20u) | (ge8(x, 9) & ~ge8(x, 14)); }
+TP_HD uint64_t lower8w(uint64_t x) { uint64_t up = ((x + REP8_01 * 0x3Fu) & ~(x + REP8_01 * 0x25u)) & REP8_80; return x | (up >> 2); }   // bytes below 0x80 only
+// '_' in the bytes that flags (0x80 per byte) marks
+TP_HD uint64_t to_us8(uint64_t x, uint64_t flags) { uint64_t m = (flags - (flags >> 7)) | flags; return (x & ~m) | (REP8_US & m); }
 TP_HD uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }   // x != 0
 TP_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }   // x != 0
 // Byte classes of the line scan, one table byte per input byte (the table sits in LDS: DevTables-independent).
@@ -253,31 +261,59 @@ TP_HD uint32_t slot_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_
 TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, bool special, bool high, uint32_t& out, Rec& rec, bool& valid_dyn,
                      uint32_t& dyn_len) {
     if (high && special) return 3;
+    // Up to 32 bytes that are, or with a few byte-wise changes become, the normalised string: hashed straight from the line.
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    uint32_t n = 0;
+    bool have_words = false;
     if (!special) {
         const uint32_t i1 = i + ((uint32_t)(i < j) & ws32(s[i]));
-        const uint32_t n = j - i1;
+        n = j - i1;
         if (n == 0) return 0;
         if (n <= 32) {
-            const uint64_t w0 = ld64u(s + i1) & word_mask(n, 0), w1 = ld64u(s + i1 + 8) & word_mask(n, 1), w2 = ld64u(s + i1 + 16) & word_mask(n, 2),
-                           w3 = ld64u(s + i1 + 24) & word_mask(n, 3);
-            const uint64_t h = hash_word(hash_word(hash_word(hash_word(HASH_SEED, w0, 0), w1, 1), w2, 2), w3, 3);   // absent words are zero
-            uint32_t kflags = 0;
-            uint32_t id = slot_find32(t, hash_finish(h, n), n, w0, w1, w2, w3, rec, kflags);
-            if (id != NO_ID && (!high || (kflags & SLOT_KEY_BASIC))) { out = id; return 1; }
-            // These bytes are the normalised string, and every interned string of up to 32 bytes is a key of the slots: a miss
-            // means the tag is in no table.  Under strict vocabulary it is dropped whatever it looks like (Program.cs:1121-1133).
-            if (id == NO_ID && !high && t.drop_unknown) { valid_dyn = false; dyn_len = n; return 2; }
+            w0 = ld64u(s + i1) & word_mask(n, 0); w1 = ld64u(s + i1 + 8) & word_mask(n, 1); w2 = ld64u(s + i1 + 16) & word_mask(n, 2);
+            w3 = ld64u(s + i1 + 24) & word_mask(n, 3);
+            have_words = true;
         }
-        if (high) return 3;
+    } else {
+        // Capital letters and single white-space characters inside the tag are the common case ("Long hair"): without quotes at
+        // the ends, trailing ';' or '.', and runs of white space and underscores, NormalizeTag (Program.cs:1150-1154) maps byte
+        // to byte: lower case, white space to '_'.
+        while (i < j && ws32(s[i])) ++i;
+        while (j > i && ws32(s[j - 1])) --j;
+        if (i == j) return 0;
+        n = j - i;
+        if (n <= 32 && !is_quote8(s[i]) && !is_quote8(s[j - 1]) && !is_punct8(s[j - 1])) {
+            w0 = ld64u(s + i) & word_mask(n, 0); w1 = ld64u(s + i + 8) & word_mask(n, 1); w2 = ld64u(s + i + 16) & word_mask(n, 2);
+            w3 = ld64u(s + i + 24) & word_mask(n, 3);
+            const uint64_t f0 = ws8(w0), f1 = ws8(w1), f2 = ws8(w2), f3 = ws8(w3);                     // 0x80 in the white-space bytes
+            const uint64_t u0 = f0 | eq8(w0, REP8_US), u1 = f1 | eq8(w1, REP8_US), u2 = f2 | eq8(w2, REP8_US), u3 = f3 | eq8(w3, REP8_US);
+            const uint64_t runs = (u0 & (u0 << 8)) | (u1 & ((u1 << 8) | (u0 >> 56))) | (u2 & ((u2 << 8) | (u1 >> 56))) | (u3 & ((u3 << 8) | (u2 >> 56)));
+            if (runs == 0) {
+                w0 = to_us8(lower8w(w0), f0); w1 = to_us8(lower8w(w1), f1); w2 = to_us8(lower8w(w2), f2); w3 = to_us8(lower8w(w3), f3);
+                have_words = true;
+            }
+        }
     }
+    if (have_words) {
+        const uint64_t h = hash_word(hash_word(hash_word(hash_word(HASH_SEED, w0, 0), w1, 1), w2, 2), w3, 3);   // absent words are zero
+        uint32_t kflags = 0;
+        uint32_t id = slot_find32(t, hash_finish(h, n), n, w0, w1, w2, w3, rec, kflags);
+        if (id != NO_ID && (!high || (kflags & SLOT_KEY_BASIC))) { out = id; return 1; }
+        // These bytes are the normalised string, and every interned string of up to 32 bytes is a key of the slots: a miss
+        // means the tag is in no table.  Under strict vocabulary it is dropped whatever it looks like (Program.cs:1121-1133).
+        if (id == NO_ID && !high && t.drop_unknown) { valid_dyn = false; dyn_len = n; return 2; }
+    }
+    if (high) return 3;
     while (i < j && ws32(s[i])) ++i;
     while (j > i && ws32(s[j - 1])) --j;
     if (i == j) return 0;
     while (i < j && is_quote8(s[i])) ++i;
     while (j > i && is_quote8(s[j - 1])) --j;
     while (j > i && is_punct8(s[j - 1])) --j;
-    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, cur = 0, h = HASH_SEED;
-    uint32_t n = 0, last_us = 0, valid = 1;
+    w0 = w1 = w2 = w3 = 0;
+    n = 0;
+    uint64_t cur = 0, h = HASH_SEED;
+    uint32_t last_us = 0, valid = 1;
     for (uint32_t p = i; p < j; ++p) {                       // \s+ -> "_", _+ -> "_", lower case (Program.cs:1152-1154)
         uint32_t c = s[p];
         const uint32_t us = ws32(c) | (uint32_t)(c == '_');

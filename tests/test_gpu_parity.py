@@ -167,6 +167,16 @@ def test_long_files():
     assert_same_results(got, want, p.histogram_dict(got.histogram), "c5")
 
 
+def test_common_spellings():
+    """Blanks for underscores, capitals, tabs, quotes and full stops around tags: the byte-to-byte route and the byte-wise normaliser."""
+    from test_pipeline_logic_cpu import spelling_variants
+    lines, cfg = spelling_variants(4000, seed=9)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    got, want = p.run_texts(lines), o.run_texts(lines, threads=8)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "spellings")
+    assert p.last_timing()["general_files"] == 0
+
+
 def test_known_non_ascii_tags_pass_through_the_wave_kernel():
     cfg = non_ascii_config()
     check_non_ascii(pipe_for(cfg).run_texts, Oracle(cfg))

@@ -170,3 +170,36 @@ def test_wave_kernel_benchmark_corpora(name, n):
     assert_same_results(got, want, s.histogram_dict(got.histogram), name + " wave kernel")
     if name in ("c2", "c3", "c4"):
         assert got.n_general <= n // 20, "the wave-per-file kernel should take nearly every file of %s (declined %d)" % (name, got.n_general)
+
+
+def spelling_variants(n, seed=3):
+    """c2 lines respelled the ways real tag files are: blanks for underscores, capitals, tabs, runs of blanks and underscores,
+    quotes and full stops at the ends of tags, blanks around them."""
+    c = make_corpus("c2", n, seed=seed)
+    a = bytes(c.arena)
+    base = [a[int(c.offsets[i]):int(c.offsets[i + 1])].rstrip(b"\n").decode() for i in range(n)]
+    rng = random.Random(seed)
+
+    def respell(tag):
+        r = rng.random()
+        if r < 0.25: return tag.replace("_", " ")
+        if r < 0.40: return tag.title()
+        if r < 0.50: return tag.replace("_", " ").upper()
+        if r < 0.55: return tag.replace("_", "  ")
+        if r < 0.60: return tag.replace("_", "\t")
+        if r < 0.65: return tag.replace("_", " _")
+        if r < 0.70: return "'" + tag.replace("_", " ") + "'"
+        if r < 0.75: return tag.replace("_", " ") + rng.choice([".", ";", "..", " ."])
+        if r < 0.80: return "  " + tag.replace("_", " ") + " "
+        if r < 0.83: return "_" + tag
+        if r < 0.86: return tag + "_"
+        return tag
+    return [", ".join(respell(t) for t in line.split(", ")) for line in base], Config(**c.config_kwargs)
+
+
+def test_wave_kernel_common_spellings():
+    lines, cfg = spelling_variants(300)
+    o, s = Oracle(cfg), HostSim(cfg)
+    want, got = o.run_texts(lines), s.run_texts_fast(lines)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "spellings")
+    assert got.n_general == 0
