@@ -5,8 +5,9 @@
 //
 // It takes the COMMON shape of a file and hands anything else to the general one-thread-per-file kernel
 // (tp_pipeline.h) by returning false (whatever it wrote by then is overwritten by that kernel):
-//   * ASCII line of at most FAST_LINE_MAX bytes, no ':' or '`' (so no POSITIVE:/NEGATIVE:/code-fence handling,
-//     Program.cs:592-595), no line break inside the trimmed text;
+//   * a line of at most FAST_LINE_MAX bytes (LONG_LINE_MAX in the long-file stage) without "positive:" / "negative:" and
+//     without '`' (so no POSITIVE:/NEGATIVE:/code-fence handling, Program.cs:592-595) and without a carriage return inside
+//     the trimmed text (line feeds there are the blanks they become, Program.cs:595);
 //   * at most FAST_TOK_MAX tokens, every kept token an interned string;
 //   * no two different candidates that NormalizeTag maps to one selected tag (their AddOne order would matter);
 //   * lists that fit their LDS capacities.
@@ -150,7 +151,7 @@ TP_HD uint8_t byte_class(uint32_t c) {
     if (c == '_') k |= CL_US;
     if (c >= 0x80) k |= CL_SPEC | CL_US;                                // both at once: a byte of a character outside ASCII
     if (c == ':') k |= CL_COLON;
-    if (c == '`' || c == '\n' || c == '\r') k |= CL_BAD;                 // a code fence, a line break: not for this kernel
+    if (c == '`' || c == '\r') k |= CL_BAD;                              // a code fence, a carriage return ("\r\n" shrinks to one character, Program.cs:591): not for this kernel
     if (c == 's' || c == 'S') k |= CL_S;
     if (c == 'o' || c == 'O') k |= CL_O;
     return (uint8_t)k;
@@ -222,7 +223,11 @@ TP_HD bool dedupe_first(W& w, BackLds& L, const uint32_t key[2], const bool vali
 
 TP_HD bool lds_match(const uint8_t* s, uint32_t pos, uint32_t end, const char* pat, uint32_t plen) {
     if (pos + plen > end) return false;
-    for (uint32_t k = 0; k < plen; ++k) if (lower8(s[pos + k]) != (uint8_t)pat[k]) return false;
+    for (uint32_t k = 0; k < plen; ++k) {
+        uint8_t c = s[pos + k];
+        if (c == '\n') c = ' ';                                    // LooksBad sees the line after Replace("\n", " "), Program.cs:595
+        if (lower8(c) != (uint8_t)pat[k]) return false;
+    }
     return true;
 }
 
@@ -531,7 +536,9 @@ TP_HD __attribute__((always_inline)) bool scan_line(W& w, LDS& L, const uint8_t*
         for (uint32_t base = a; base < b; base += 64) {
             const uint32_t p = base + lane;
             const bool inb = p < b;
-            const uint32_t q = lower4(ld32u(s + (inb ? p : b)));
+            uint32_t q = lower4(ld32u(s + (inb ? p : b)));
+            const uint32_t nl = eq4(q, rep4('\n'));                  // a line feed counts as the blank it becomes (Program.cs:595): 0x0A ^ 0x2A = 0x20
+            q ^= (nl >> 2) | (nl >> 4) | (nl >> 6);
             const bool pre = inb & ((q == c4('i', ' ', 'c', 'a')) | (q == c4('i', '\'', 'm', ' ')) | (q == c4('i', ' ', 'w', 'o')) | (q == c4('c', 'a', 'n', 'n')) |
                                     (q == c4('u', 'n', 'a', 'b')) | (q == c4('a', 's', ' ', 'a')));
             if (w.ballot(pre)) {

@@ -177,6 +177,17 @@ def test_common_spellings():
     assert p.last_timing()["general_files"] == 0
 
 
+def test_multi_line_texts():
+    """Line feeds inside the text are the blanks they become (Program.cs:595); carriage returns inside go to the general kernel."""
+    from test_pipeline_logic_cpu import multi_line_texts
+    lines, cfg = multi_line_texts(4000, seed=6)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    got, want = p.run_texts(lines), o.run_texts(lines, threads=8)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "multi-line")
+    assert p.last_timing()["general_files"] < 800
+    assert np.array_equal(p.triage_texts(lines), o.triage_texts(lines))
+
+
 def test_known_non_ascii_tags_pass_through_the_wave_kernel():
     cfg = non_ascii_config()
     check_non_ascii(pipe_for(cfg).run_texts, Oracle(cfg))

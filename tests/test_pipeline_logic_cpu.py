@@ -203,3 +203,35 @@ def test_wave_kernel_common_spellings():
     want, got = o.run_texts(lines), s.run_texts_fast(lines)
     assert_same_results(got, want, s.histogram_dict(got.histogram), "spellings")
     assert got.n_general == 0
+
+
+def multi_line_texts(n, seed=4):
+    """c2 lines broken over several lines (line feeds after commas, inside tags, doubled), refusals split by a line feed, and
+    texts with carriage returns inside (those are for the general kernel)."""
+    c = make_corpus("c2", n, seed=seed)
+    a = bytes(c.arena)
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        toks = a[int(c.offsets[i]):int(c.offsets[i + 1])].rstrip(b"\n").decode().split(", ")
+        r = rng.random()
+        if r < 0.3: text = ",\n".join(toks)
+        elif r < 0.5: text = ", ".join(t.replace("_", "\n", 1) for t in toks)
+        elif r < 0.6: text = ",\n\n".join(toks[:10]) + "\n" + ", ".join(toks[10:])
+        elif r < 0.7: text = "\n" + ",\n ".join(toks) + "\n\n"
+        elif r < 0.8: text = ",\r\n".join(toks)
+        elif r < 0.85: text = ", ".join(toks[:5]) + ", i\ncan't do that, " + ", ".join(toks[5:])
+        elif r < 0.9: text = ", ".join(toks[:5]) + ", as\nan\nai, " + ", ".join(toks[5:])
+        elif r < 0.95: text = "\n".join(toks[:2])
+        else: text = toks[0] + "\n" + "x" * 45
+        out.append(text)
+    return out, Config(**c.config_kwargs)
+
+
+def test_wave_kernel_multi_line_texts():
+    lines, cfg = multi_line_texts(300)
+    o, s = Oracle(cfg), HostSim(cfg)
+    want, got = o.run_texts(lines), s.run_texts_fast(lines)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "multi-line")
+    assert got.n_general < 60                                   # only the texts with carriage returns inside
+    assert (want.verdicts["flags"] & 0x10).any()                # the refusals split by a line feed are rejected

@@ -47,3 +47,13 @@ def test_triage_long_files():
     got, n_general = s.triage_texts(lines)
     assert list(got) == list(want)
     assert n_general < len(lines) // 2
+
+
+def test_triage_multi_line_texts():
+    from test_pipeline_logic_cpu import multi_line_texts
+    lines, cfg = multi_line_texts(300, seed=8)
+    o, s = Oracle(cfg), HostSim(cfg)
+    want = o.triage_texts(lines)
+    got, n_general = s.triage_texts(lines)
+    assert list(got) == list(want)
+    assert n_general < 60 and 0 < want.sum() < len(lines)
