@@ -2,7 +2,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.txt 2>&1 || { tail -30 gpurun_out/gpu_tests.txt; exit 1; }
-tail -3 gpurun_out/gpu_tests.txt
-timeout -k 10 300 python3 bench.py --cpu-sample 0 > gpurun_out/bench.json 2> gpurun_out/bench.err
-cut -c1-700 gpurun_out/bench.json
+echo start
+timeout -k 10 900 python3 bench.py --files 10000000 --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/bench_10m.json 2> gpurun_out/bench_10m.err
+cut -c1-800 gpurun_out/bench_10m.json
+timeout -k 10 120 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"

@@ -1,0 +1,38 @@
+"""Device time of the scored entry points (tp_run_scored, tp_run_merged) on the tags of a corpus config with made-up scores."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagecaptioner_amd import Config, TagPipe  # noqa: E402
+from imagecaptioner_amd.corpus import make_corpus  # noqa: E402
+
+name, n = sys.argv[1], int(sys.argv[2])
+c = make_corpus(name, n, seed=1)
+a = bytes(c.arena)
+rng = np.random.default_rng(3)
+tags, begin, mid = [], [0], []
+for i in range(n):
+    toks = a[int(c.offsets[i]):int(c.offsets[i + 1])].rstrip(b"\n").split(b", ")
+    k = max(1, (2 * len(toks)) // 3)                       # the primary reply holds two thirds of the tags, the secondary one all of them
+    tags += toks[:k]
+    mid.append(len(tags))
+    tags += toks
+    begin.append(len(tags))
+offs = np.zeros(len(tags) + 1, dtype=np.uint64)
+offs[1:] = np.cumsum([len(t) for t in tags])
+arena = np.frombuffer(b"".join(tags), dtype=np.uint8).copy()
+scores = np.round(rng.random(len(tags)) * 0.65 + 0.35, 3)
+begin, mid = np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64)
+p = TagPipe(Config(**c.config_kwargs))
+for _ in range(2):
+    r = p.run_scored(arena, offs, begin, scores, np.zeros(len(tags), np.uint8))
+    tm = p.last_timing()
+print("%s scored: %d files, %.1f tags/file in: device %.2f ms (general kernel %.2f ms, emit %.2f ms) = %.2f M files/s; mean caption tags %.1f" % (
+    name, n, len(tags) / n, tm["total_ms"], tm["general_ms"], tm["emit_ms"], n / tm["total_ms"] / 1e3, float(r.verdicts["n_tags"].mean())))
+for _ in range(2):
+    r = p.run_merged(arena, offs, begin, mid, scores, 15)
+    tm = p.last_timing()
+print("%s merged: %d files: device %.2f ms (general kernel %.2f ms, emit %.2f ms) = %.2f M files/s; mean caption tags %.1f" % (
+    name, n, tm["total_ms"], tm["general_ms"], tm["emit_ms"], n / tm["total_ms"] / 1e3, float(r.verdicts["n_tags"].mean())))
