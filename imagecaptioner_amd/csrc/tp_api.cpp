@@ -121,7 +121,8 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     uint64_t* d_total = c->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
     uint32_t* d_status = (uint32_t*)(d_total + 2);
     uint32_t* d_slow_count = d_status + 1;
-    const bool use_fast = c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast;
+    const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast;   // tagger replies: the wave kernel's scored front
+    const bool use_fast = use_scored || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast);
 
     c->cap_len.need(n * 4); c->n_final.need(n * 4); c->slot_of.need(n * 4);
     uint32_t* cap_len = c->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
@@ -143,6 +144,11 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         fa.fired = io.fired; fa.facet_choice = io.facet_choice; fa.triage = io.mode == 2 ? 1 : 0;
         hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
         HIP_OK(hipEventRecord(p0, s));
+        if (use_scored) {
+            fa.tag_begin = io.tag_begin; fa.scores = io.scores; fa.sources = io.sources; fa.secondary_begin = io.secondary_begin; fa.secondary_cap = io.secondary_cap;
+            fa.stage = 4; fa.slow_list = c->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.item_list = nullptr; fa.item_count = nullptr;
+            HIP_OK(launch_fast(c->dt, fa, s));
+        } else {
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
         // through the long-file stage, and what is left to the general kernel.  Later stages learn their item counts on the device.
         fa.stage = 1; fa.slow_list = c->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1; fa.item_list = nullptr; fa.item_count = nullptr;
@@ -153,6 +159,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         fa.stage = 3; fa.item_list = c->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
         fa.slow_list = c->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
         HIP_OK(launch_fast(c->dt, fa, s));
+        }
         HIP_OK(hipEventRecord(p1, s));
         st.fast_ev.emplace_back(p0, p1);
         HIP_OK(hipMemcpyAsync(&n_slow, d_slow_count, 4, hipMemcpyDeviceToHost, s));

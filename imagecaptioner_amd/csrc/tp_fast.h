@@ -957,17 +957,32 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
 // Fewer per lane means fewer registers and less work per wavefront.
 // rc: the rule cache (DevTables::rc, or a copy of it in faster memory); cls: byte_class() of 0..255 as a table.
 // fin32: where the caption's tag ids go (FAST_FIN_MAX entries); fired / facet_choice may be null.
-template <int NT, int NF, class W>
+// Front: LineFront (the candidates come from the line `text`, as above) or a type with `scored == true` whose run() puts
+// scored candidates on the lanes in the order SelectTags sorts them into (ScoredFront below); text / len / cls / triage
+// are not used then.
+struct LineFront { static constexpr bool scored = false; };
+template <int NT, int NF, class W, class Front = LineFront>
 TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice, bool triage = false) {
+                     uint32_t* fired, uint16_t* facet_choice, bool triage = false, Front* front = nullptr) {
     static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
     constexpr uint32_t FIN_MAX = 64u * NF;
     const uint32_t lane = w.lane();
+    int nblk = 1;
+    uint32_t n = 0;
+    bool act[2] = {false, false};
+    uint32_t h1[2] = {EMPTY_ID, EMPTY_ID}, ci[2] = {0, 0};
+    Rec r1[2];
+    r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
+    bool rejected = false;
+    bool seed_in[2] = {false, false}, strong_in[2] = {false, false};   // scored candidates: !(score < 0.28), score >= 0.60
+    if constexpr (Front::scored) {
+        if (!front->run(w, t, L, nblk, n, act, h1, r1, seed_in, strong_in)) return false;
+    } else {
     Scan sc;
     if (!scan_line(w, L, cls, text, len, sc)) return false;
     const uint8_t* s = sc.s;
     const uint32_t a = sc.a, b = sc.b, ncomma = sc.ncomma;
-    const bool rejected = sc.rejected;
+    rejected = sc.rejected;
     const uint32_t T = ncomma + 1;
     if (T > 64u * NT) return false;
     w.tick(2);
@@ -975,12 +990,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
 
     // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
     // A token's lane stays its candidate's lane: candidate index = number of kept tokens before it.
-    const int nblk = NT == 1 ? 1 : (T > 64 ? 2 : 1);              // tokens (and so candidates) sit two per lane only in long lines
-    uint32_t n = 0;
-    bool act[2] = {false, false};
-    uint32_t h1[2] = {EMPTY_ID, EMPTY_ID}, ci[2] = {0, 0};
-    Rec r1[2];
-    r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
+    nblk = NT == 1 ? 1 : (T > 64 ? 2 : 1);                        // tokens (and so candidates) sit two per lane only in long lines
     {
         bool keep[2] = {false, false};
         bool dyn_survivor = false;
@@ -1032,6 +1042,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         out.caption_len = 0;
         return true;
     }
+    }
     w.tick(3);
     TP_STOP(3, h1[0] ^ h1[1] ^ r1[0].flags ^ r1[0].next ^ r1[1].flags ^ r1[0].lit ^ r1[0].step0 ^ ci[0] ^ ci[1] ^ n ^ (uint32_t)act[0] ^ (uint32_t)act[1])
     // ---- S5: SelectTags first half, candidates on lanes (Program.cs:625-655); evidence seeds (Program.cs:721-729) ----------
@@ -1049,15 +1060,17 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         uint64_t mh = w.ballot(hop);
         m_hop2 |= mh;
         if (mh && hop) r2[blk] = t.rec[t2[blk]];
-        style_n += popc64(w.ballot(act[blk] && fl_bucket(r1[blk].flags) == B_STYLE && ci[blk] < t.style_ci_limit));   // DetermineStyleQualityCap, Program.cs:702-710
+        style_n += popc64(w.ballot(act[blk] && fl_bucket(r1[blk].flags) == B_STYLE && (Front::scored ? strong_in[blk] : ci[blk] < t.style_ci_limit)));   // DetermineStyleQualityCap, Program.cs:702-710
         nonblank2[blk] = act[blk] && !(r2[blk].flags & FL_BLANK);
         first2[blk] = nonblank2[blk];
         bad2[blk] = nonblank2[blk] && (!(r2[blk].flags & FL_VALID) || (r2[blk].flags & FL_DROP));
-        ev_seed[blk] = ci[blk] < t.seed_ci_limit;                  // !(score < 0.28), Program.cs:724
+        ev_seed[blk] = Front::scored ? seed_in[blk] : ci[blk] < t.seed_ci_limit;   // !(score < 0.28), Program.cs:724
     }
     const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
     if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences
         if (!dedupe_first(w, L, t2, nonblank2, first2, nblk)) return false;
+        // With scores of their own the merged score, order and source may move the tag in the sorted order (Program.cs:636-655): not followed here
+        if (Front::scored && w.ballot((nonblank2[0] && !first2[0]) || (nonblank2[1] && !first2[1]))) return false;
     }
     uint32_t n_dropped = 0;
     TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
@@ -1221,6 +1234,206 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     ti.settled = settled; ti.rejected = rejected; ti.kid = kid;
     return fast_tail<NF>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice);
 }
+
+// ================================================================================================================
+// Scored candidates: the tagger replies of one file as (text, score) pairs (ParseJoyTags, Program.cs:463-489), one reply or
+// the primary and the secondary one merged as the per-image loop does (Program.cs:214-221, 442-461, 801-815).  run() leaves
+// the candidates on the lanes in the order SelectTags sorts them into.  Files it does not take (more than 128 tags or
+// FAST_LINE_MAX bytes of text, bytes outside ASCII, a line feed, a tag in no table, two tags of one reply that NormalizeTag
+// maps to one string, candidates that tie in score, source and order) go to the general kernel.
+// ================================================================================================================
+struct ScoredIn {
+    const uint8_t* arena;
+    const uint64_t* tag_offsets;
+    uint64_t lo, mid, hi;          // tags [lo, hi); merged: [lo, mid) primary reply, [mid, hi) secondary reply
+    const double* scores;
+    const uint8_t* sources;        // per tag (not read when merged)
+    bool merged;
+    int cap;                       // LimitSecondaryTags' cap on tags the primary reply does not hold
+};
+
+template <class W>
+struct ScoredFront {
+    static constexpr bool scored = true;
+    ScoredIn in;
+
+    // double -> key that sorts ascending where the score sorts descending (finite scores; -0.0 counts as 0.0)
+    static TP_HD uint64_t desc_key(double sc) {
+        sc = sc + 0.0;
+        uint64_t b;
+        __builtin_memcpy(&b, &sc, 8);
+        const uint64_t asc = b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+        return ~asc;
+    }
+
+    TP_HD bool run(W& w, const DevTables& t, FastLds& L, int& nblk, uint32_t& n, bool (&act)[2], uint32_t (&h1)[2], Rec (&r1)[2], bool (&seed)[2], bool (&strong)[2]) {
+        const uint32_t lane = w.lane();
+        const uint64_t M64 = in.hi - in.lo;
+        if (M64 > 128) return false;
+        const uint32_t M = (uint32_t)M64, P = in.merged ? (uint32_t)(in.mid - in.lo) : M;
+        nblk = 1; n = 0;
+        if (M == 0) return true;
+        const uint64_t base = in.tag_offsets[in.lo];
+        const uint64_t bytes64 = in.tag_offsets[in.hi] - base;
+        if (bytes64 > FAST_LINE_MAX) return false;
+        // ---- the tags' text -> LDS, as S1 of scan_line does with a line ----
+        const uint8_t* text = in.arena + base;
+        const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
+        const uint32_t pieces = (shift + (uint32_t)bytes64 + 15) >> 4;
+        for (uint32_t c = lane; c < pieces; c += 64) w.copy16(L.line + 16 + 16 * c, text - shift + 16 * c);
+        w.sync();
+        bool odd = false;                                          // a byte outside ASCII, a line feed (Program.cs:1151's `$` also matches before one)
+        for (uint32_t c = lane; c < pieces; c += 64)
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t x = ld32u(L.line + 16 + 16 * c + 4 * k); odd = odd || (x & 0x80808080u) != 0 || eq4(x, rep4('\n')) != 0; }
+        if (w.ballot(odd)) return false;
+        const uint8_t* s = L.line + 16 + shift;
+        const int mblk = M > 64 ? 2 : 1;
+        // ---- ParseJoyTags: NormalizeTag of every tag, blank ones skipped (Program.cs:473-487) ----
+        uint32_t id[2] = {NO_ID, NO_ID}, src[2] = {0, 0};
+        uint64_t K[2] = {~0ull, ~0ull};
+        bool valid[2] = {false, false}, decline = false;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) {
+            const uint32_t e = (uint32_t)blk * 64 + lane;
+            if (e < M) {
+                const uint32_t i = (uint32_t)(in.tag_offsets[in.lo + e] - base), j = (uint32_t)(in.tag_offsets[in.lo + e + 1] - base);
+                K[blk] = desc_key(in.scores[in.lo + e]);
+                src[blk] = in.merged ? (e < P ? (uint32_t)TP_SRC_PRIMARY_JOY : (uint32_t)TP_SRC_SECONDARY_JOY) : (uint32_t)in.sources[in.lo + e];
+                uint32_t dlen = 0;
+                bool vdyn = false;
+                Rec rr;
+                const int kind = j < i ? 3 : fast_token(t, s, i, j, true, false, id[blk], rr, vdyn, dlen);
+                if (kind == 0) { id[blk] = t.alias1[EMPTY_ID]; rr = t.rec[id[blk]]; }      // NormalizeTag("") still goes through the alias lookup
+                if (kind >= 2) decline = true;                    // a tag in no table stays a candidate here (it counts as dropped and as evidence): general kernel
+                else valid[blk] = !(rr.flags & FL_BLANK);
+            }
+        }
+        if (w.ballot(decline)) return false;
+        // order: the running index among the reply's kept tags (Program.cs:474, 486)
+        uint32_t order[2] = {0, 0};
+        {
+            const uint64_t lowP = P >= 64 ? ~0ull : ((1ull << P) - 1), lowP1 = P <= 64 ? 0ull : (P >= 128 ? ~0ull : ((1ull << (P - 64)) - 1));
+            const uint64_t v0 = w.ballot(valid[0]), v1 = mblk > 1 ? w.ballot(valid[1]) : 0;
+            const uint64_t p0 = v0 & lowP, p1 = v1 & lowP1, s0 = v0 & ~lowP, s1 = v1 & ~lowP1;   // kept tags of the primary / secondary reply
+            const uint32_t np0 = popc64(p0), ns0 = popc64(s0);
+            order[0] = lane < P ? w.rank(p0) : w.rank(s0);
+            order[1] = lane + 64 < P ? np0 + w.rank(p1) : ns0 + w.rank(s1);
+        }
+        // Two kept tags of one reply with one normalised string would merge in ParseJoyTags' consumer (Program.cs:444-458, 636-649): not followed here
+        bool alive[2] = {valid[0], valid[1]};
+        if (!in.merged) {
+            bool first[2];
+            if (!dedupe_first(w, L, id, valid, first, mblk)) return false;
+            if (w.ballot((valid[0] && !first[0]) || (valid[1] && !first[1]))) return false;
+        } else {
+            const bool isP[2] = {lane < P, lane + 64 < P};
+            const bool vp[2] = {valid[0] && isP[0], valid[1] && isP[1]}, vs[2] = {valid[0] && !isP[0], valid[1] && !isP[1]};
+            bool first[2];
+            if (!dedupe_first(w, L, id, vs, first, mblk)) return false;
+            if (w.ballot((vs[0] && !first[0]) || (vs[1] && !first[1]))) return false;
+            // the primary reply's tags into the set, each with its element index; the secondary reply's tags look themselves up
+            set_clear(w, L);
+            bool dup = false, full = false;
+            uint32_t slot[2] = {NO_ID, NO_ID};
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
+                if (vp[blk]) { bool created; slot[blk] = set_put(w, L, id[blk], (uint32_t)blk * 64 + lane, created); dup = dup || !created; full = full || slot[blk] == NO_ID; }
+            w.sync();
+            if (w.ballot(dup || full)) return false;
+            bool twin[2] = {false, false};
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
+                if (vs[blk]) { bool created; slot[blk] = set_put(w, L, id[blk], 0xFFFFFFFEu, created); twin[blk] = !created; full = full || slot[blk] == NO_ID; }
+            w.sync();
+            if (w.ballot(full)) return false;
+            // LimitSecondaryTags (Program.cs:801-815): tags the primary reply holds pass; of the others the `cap` best by (score, order)
+            uint64_t* twK = (uint64_t*)L.line;                     // the text is not read any more: per element of the primary reply, its twin's key ...
+            uint32_t* twO = (uint32_t*)(L.line + 1024);            // ... and order, 0xFFFFFFFF without a twin
+            uint32_t* k2q = (uint32_t*)(L.line + 1536);
+            if (lane < 64) { twO[lane] = 0xFFFFFFFFu; twO[lane + 64] = 0xFFFFFFFFu; }
+            const bool sonly[2] = {vs[0] && !twin[0], vs[1] && !twin[1]};
+            const uint32_t n_sonly = popc64(w.ballot(sonly[0])) + (mblk > 1 ? popc64(w.ballot(sonly[1])) : 0);
+            bool accept[2] = {vs[0], vs[1]};
+            if (in.cap <= 0) { accept[0] = accept[1] = false; }   // "if (cap <= 0 ...) return []": then not even the tags of the primary reply pass
+            else if (n_sonly > (uint32_t)in.cap) {
+                w.sync();
+                // rank of every secondary-only tag among them, by (score descending, order): keys through LDS
+                uint64_t* rk = (uint64_t*)L.line;
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) { const uint32_t e = (uint32_t)blk * 64 + lane; if (e < M) { rk[e] = K[blk]; k2q[e] = sonly[blk] ? order[blk] : 0xFFFFFFFFu; } }
+                w.sync();
+                uint32_t before[2] = {0, 0};
+                for (uint32_t f = P; f < M; ++f) {
+                    const uint32_t of = k2q[f];
+                    if (of == 0xFFFFFFFFu) continue;
+                    const uint64_t kf = rk[f];
+                    TP_UNROLL for (int blk = 0; blk < 2; ++blk) before[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && of < order[blk]));
+                }
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (sonly[blk] && before[blk] >= (uint32_t)in.cap) accept[blk] = false;
+                w.sync();
+                if (lane < 64) { twO[lane] = 0xFFFFFFFFu; twO[lane + 64] = 0xFFFFFFFFu; }
+            }
+            w.sync();
+            // MergeCandidateTags (Program.cs:442-461): a tag of both replies keeps the better score, the earlier order and, the
+            // scores compared as PreferSource is called there, the source of lower rank: the primary reply's
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
+                if (accept[blk] && twin[blk]) { const uint32_t pe = L.set_min[slot[blk]]; twK[pe] = K[blk]; twO[pe] = order[blk]; }
+            w.sync();
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) {
+                const uint32_t e = (uint32_t)blk * 64 + lane;
+                if (vp[blk] && twO[e] != 0xFFFFFFFFu) { const uint64_t k = twK[e]; K[blk] = k < K[blk] ? k : K[blk]; order[blk] = twO[e] < order[blk] ? twO[e] : order[blk]; }
+                alive[blk] = vp[blk] || (accept[blk] && !twin[blk]);
+            }
+            w.sync();
+        }
+        // ---- the order SelectTags works in: score descending, source rank, order (Program.cs:460, 651-655) ----
+        uint64_t* Kq = (uint64_t*)L.line;
+        uint32_t* k2q = (uint32_t*)(L.line + 1024);
+        uint32_t* idq = (uint32_t*)(L.line + 1536);
+        uint32_t k2[2];
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
+            k2[blk] = alive[blk] ? ((uint32_t)source_rank(src[blk]) << 16) | order[blk] : 0xFFFFFFFFu;
+            const uint32_t e = (uint32_t)blk * 64 + lane;
+            if (blk < mblk && e < M) { Kq[e] = K[blk]; k2q[e] = k2[blk]; }
+        }
+        w.sync();
+        uint32_t before[2] = {0, 0};
+        bool tie = false;
+        for (uint32_t f = 0; f < M; ++f) {
+            const uint32_t kf2 = k2q[f];
+            if (kf2 == 0xFFFFFFFFu) continue;
+            const uint64_t kf = Kq[f];
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
+                before[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && kf2 < k2[blk]));
+                tie = tie || (alive[blk] && kf == K[blk] && kf2 == k2[blk] && f != (uint32_t)blk * 64 + lane);
+            }
+        }
+        if (w.ballot(tie)) return false;                           // the insertion order of the merge decides between them: general kernel
+        n = popc64(w.ballot(alive[0])) + (mblk > 1 ? popc64(w.ballot(alive[1])) : 0);
+        w.sync();
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
+            if (alive[blk]) {
+                idq[before[blk]] = id[blk];
+                // !(score < 0.28) and score >= 0.60 of the merged score, read back from its key
+                const uint64_t asc = ~K[blk];
+                const uint64_t b = asc ^ ((asc >> 63) ? 0x8000000000000000ull : ~0ull);
+                double merged_score;
+                __builtin_memcpy(&merged_score, &b, 8);
+                k2q[before[blk]] = (uint32_t)(!(merged_score < 0.28)) | ((uint32_t)(merged_score >= 0.60) << 1);
+            }
+        w.sync();
+        nblk = n > 64 ? 2 : 1;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
+            const uint32_t p = (uint32_t)blk * 64 + lane;
+            act[blk] = blk < nblk && p < n;
+            if (act[blk]) {
+                h1[blk] = idq[p];
+                const uint32_t fl = k2q[p];
+                seed[blk] = (fl & 1u) != 0;
+                strong[blk] = (fl & 2u) != 0;
+                r1[blk] = t.rec[h1[blk]];
+            }
+        }
+        w.sync();
+        return true;
+    }
+};
 
 // ================================================================================================================
 // Long files: up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes.  The candidates live in LDS arrays indexed by token and

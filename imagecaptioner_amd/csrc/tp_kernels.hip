@@ -139,6 +139,43 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast_triage(DevTables t, FastArgs a) { fast_body<1, true>(t, a); }
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2_triage(DevTables t, FastArgs a) { fast_body<2, true>(t, a); }
 
+// Scored candidates (tagger replies as text and score per tag) through the wave kernel's scored front, two candidates per lane.
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables t, FastArgs a) {
+    __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
+    __shared__ uint8_t cls[256];
+    extern __shared__ uint32_t rc_lds[];
+    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
+    __syncthreads();
+    FastLds& L = lds[threadIdx.x >> 6];
+    DevWave w;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_items = a.file_end - a.file0;
+    for (uint64_t i = wave_global; i < n_items; i += n_waves) {
+        const uint64_t f = a.file0 + i;
+        ScoredFront<DevWave> front;
+        const uint64_t lo = a.tag_begin[f], hi = a.tag_begin[f + 1];
+        front.in = ScoredIn{a.arena, a.offsets, lo, a.secondary_begin ? a.secondary_begin[f] : hi, hi, a.scores, a.sources, a.secondary_begin != nullptr, a.secondary_cap};
+        FastOut out;
+        const bool done = fast_file<2, 2, DevWave, ScoredFront<DevWave>>(w, t, L, rc_lds, cls, nullptr, 0, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
+                                                                         a.fired ? a.fired + f * t.fired_words : nullptr,
+                                                                         a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, false, &front);
+        if (w.lane() == 0) {
+            if (done) {
+                a.verdicts[f] = out.verdict;
+                a.n_final[f] = out.n_final;
+                a.cap_len[f] = out.caption_len;
+                a.slot_of[f] = SLOT_FAST;
+            } else {
+                uint32_t k = atomicAdd(a.slow_count, 1u);
+                a.slow_list[k] = (uint32_t)(f - a.file0);
+            }
+        }
+        w.sync();
+    }
+}
+
 // Third stage: the files the second declined, up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes; one wavefront per block.
 template <bool TR>
 __device__ __forceinline__ void long_body(const DevTables& t, const FastArgs& a) {
@@ -556,7 +593,8 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     const unsigned cap = a.stage == 1 ? max_blocks : 256u * 8u;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     const bool tr = a.triage != 0;
-    if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
+    if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     return hipGetLastError();

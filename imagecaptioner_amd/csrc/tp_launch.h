@@ -24,6 +24,12 @@ struct FastArgs {
     uint32_t* slow_count;
     const uint32_t* item_list;    // null: first stage over the whole range; else the files (relative to file0) the stage before declined:
     const uint32_t* item_count;   //   *item_count of them (read on the device)
+    // scored candidates (stage 4): offsets are tag offsets; the tags of file f are tag_begin[f] .. tag_begin[f + 1]
+    const uint64_t* tag_begin;
+    const double* scores;
+    const uint8_t* sources;
+    const uint64_t* secondary_begin;   // two replies per file to merge: first tag of the secondary reply (else null)
+    int secondary_cap;
     int triage;                   // 1: existing-caption triage: stop after the candidates, verdict flags carry TP_F_TRIAGE_BAD
     int stage;                    // 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)
     uint32_t* fired;

@@ -52,6 +52,8 @@ def sim_lib():
         L.sim_run_scored.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
         L.sim_run_lines_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result), C.POINTER(C.c_uint64)]
         L.sim_release.argtypes = [C.POINTER(sim_result)]
+        L.sim_run_scored_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64,
+                                          C.POINTER(sim_result), C.POINTER(C.c_uint64)]
         L.sim_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(sim_result)]
         L.sim_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         _SIM = L
@@ -146,6 +148,22 @@ class HostSim:
         rc = self._L.sim_run_merged(self._h, pad.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data, secondary_begin.ctypes.data,
                                     scores.ctypes.data, int(secondary_cap), len(tag_begin) - 1, C.byref(res))
         return self._collect(res, rc)
+
+    def run_scored_fast(self, arena, tag_offsets, tag_begin, scores, sources=None, secondary_begin=None, secondary_cap=0):
+        """The scored entry points as the library runs them: wave kernel with the scored front, general pipeline for the rest."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
+        tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        sources = np.ascontiguousarray(sources if sources is not None else np.zeros(len(scores), np.uint8), dtype=np.uint8)
+        sb = np.ascontiguousarray(secondary_begin, dtype=np.uint64) if secondary_begin is not None else None
+        res = sim_result()
+        ng = C.c_uint64()
+        rc = self._L.sim_run_scored_fast(self._h, arena.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data, sb.ctypes.data if sb is not None else None,
+                                         scores.ctypes.data, sources.ctypes.data, int(secondary_cap), len(tag_begin) - 1, C.byref(res), C.byref(ng))
+        out = self._collect(res, rc)
+        out.n_general = ng.value
+        return out
 
     def triage_texts(self, texts, general_only=False):
         """(bad, n_general): the triage flow on the emulated wavefront; general_only runs the thread-per-file code alone."""

@@ -257,6 +257,79 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
     return finish(o, n, r);
 }
 
+// The GPU flow for scored candidates: the wave-per-file kernel body with the scored front on an emulated wavefront, the
+// general pipeline for the files it declines.  secondary_begin == nullptr: one reply per file with per-tag sources.
+int sim_run_scored_fast(void* h, const uint8_t* arena_in, const uint64_t* tag_offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin,
+                        const double* scores, const uint8_t* sources, int secondary_cap, uint64_t n, sim_result* r, uint64_t* n_general) {
+    g_err.clear();
+    Sim& s = *(Sim*)h;
+    const DevTables& t = s.dt;
+    SimOut* o = new SimOut();
+    const uint64_t n_tags = tag_begin[n];
+    std::vector<uint8_t> padded((size_t)tag_offsets[n_tags] + 128, 0);
+    uint8_t* arena = padded.data() + 64;
+    std::memcpy(arena, arena_in, (size_t)tag_offsets[n_tags]);
+    o->offsets.assign(n + 1, 0);
+    o->verdicts.assign(n, tp_verdict{});
+    o->fired.assign(std::max<size_t>(n * t.fired_words, 1), 0);
+    o->facets.assign(n * t.n_facets, 0xFFFF);
+    o->hist.assign((size_t)t.n_strings + 1, 0);
+    uint64_t slow = 0;
+    emu::Shared sh;
+    for (uint64_t f = 0; f < n; ++f) {
+        static FastLds lds;
+        std::memset(&lds, 0xCD, sizeof lds);
+        std::vector<uint32_t> fin32(FAST_FIN_MAX, 0xDEADBEEF);
+        bool done[64];
+        FastOut outs[64];
+        bool ok = t.fast_ok;
+        if (ok) {
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                ScoredFront<emu::Wave> front;
+                front.in = ScoredIn{arena, tag_offsets, tag_begin[f], secondary_begin ? secondary_begin[f] : tag_begin[f + 1], tag_begin[f + 1], scores, sources,
+                                    secondary_begin != nullptr, secondary_cap};
+                done[lane] = fast_file<2, 2, emu::Wave, ScoredFront<emu::Wave>>(w, t, lds, t.rc, cls_table(), nullptr, 0, outs[lane], fin32.data(),
+                                                                                 o->fired.data() + f * t.fired_words, t.n_facets ? &o->facets[f * t.n_facets] : nullptr,
+                                                                                 false, &front);
+            });
+            for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the scored fast-path verdict"; }
+            ok = done[0];
+        }
+        size_t before = o->captions.size();
+        if (ok) {
+            const FastOut& fo = outs[0];
+            o->verdicts[f] = fo.verdict;
+            for (uint32_t k = 0; k < fo.n_final; ++k) {
+                uint32_t id = fin32[k];
+                if (k) { o->captions.push_back(','); o->captions.push_back(' '); }
+                const uint8_t* p = str_ptr(t, id);
+                o->captions.insert(o->captions.end(), p, p + str_len(t, id));
+                o->hist[id]++;
+            }
+            o->captions.insert(o->captions.end(), t.newline, t.newline + t.newline_len);
+            if (o->captions.size() - before != fo.caption_len) g_err = "fast caption_len mismatch";
+        } else {
+            ++slow;
+            SimOut one;
+            run(s, arena, tag_offsets, tag_begin + f, scores, sources, 1, 0, one, nullptr, secondary_begin ? secondary_begin + f : nullptr, secondary_cap);
+            o->verdicts[f] = one.verdicts[0];
+            for (uint32_t k = 0; k < t.fired_words; ++k) o->fired[f * t.fired_words + k] = one.fired[k];
+            for (uint32_t k = 0; k < t.n_facets; ++k) o->facets[f * t.n_facets + k] = one.facets[k];
+            o->captions.insert(o->captions.end(), one.captions.begin(), one.captions.end());
+            for (size_t k = 0; k < one.hist.size(); ++k) o->hist[k] += one.hist[k];
+        }
+        o->offsets[f + 1] = o->captions.size();
+        uint8_t fl = o->verdicts[f].flags;
+        o->ctr.files++;
+        o->ctr.low += (fl & TP_F_LOW) != 0; o->ctr.action_eligible += (fl & TP_F_ELIGIBLE) != 0; o->ctr.action_footjob += (fl & TP_F_FOOTJOB) != 0;
+        o->ctr.fallback += (fl & TP_F_FALLBACK) != 0; o->ctr.line_rejected += (fl & TP_F_LINE_REJECTED) != 0; o->ctr.unsupported += (fl & TP_F_UNSUPPORTED) != 0;
+        o->ctr.safe_rejected += (fl & TP_F_SAFE_REJECT) != 0;
+    }
+    if (n_general) *n_general = slow;
+    return finish(o, n, r);
+}
+
 // Existing-caption triage in the GPU flow: the three wave stages in triage mode, then the general pipeline in mode 2.
 // which: 0 the flow as the library runs it, 1 general pipeline only.  bad[i]: 1 bad, 0 keep, 2 unsupported.
 int sim_triage_lines(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, int which, uint8_t* bad, uint64_t* n_general) {

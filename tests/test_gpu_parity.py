@@ -135,6 +135,22 @@ def test_audit_strings_and_side_files(name):
     assert len(act) == 0 and rej == []
 
 
+@pytest.mark.parametrize("merged", [False, True])
+def test_tagger_replies_take_the_wave_kernel(merged):
+    """Replies as a tagger sends them (known tags, each once) stay in the wave kernel's scored front; results equal the oracle's."""
+    from test_merged_cpu import clean_replies
+    cfg = shipped_config()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    arena, offs, begin, mid, scores = clean_replies(29, 6000, merged)
+    if merged:
+        got, want = p.run_merged(arena, offs, begin, mid, scores, 15), o.run_merged(arena, offs, begin, mid, scores, 15, threads=8)
+    else:
+        src = np.zeros(len(scores), np.uint8)
+        got, want = p.run_scored(arena, offs, begin, scores, src), o.run_scored(arena, offs, begin, scores, src, threads=8)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "clean replies merged=%s" % merged)
+    assert p.last_timing()["general_files"] < (2000 if merged else 400)
+
+
 def test_empty_and_ragged_batches():
     cfg = shipped_config()
     p, o = pipe_for(cfg), Oracle(cfg)

@@ -72,3 +72,64 @@ def test_merged_ingest(name, cap):
     args = merged_inputs(17 + cap, 400)
     want, got = o.run_merged(*args, cap), s.run_merged(*args, cap)
     assert_same_results(got, want, s.histogram_dict(got.histogram), "%s merged cap %d" % (name, cap))
+
+
+def clean_replies(seed, n_files, merged):
+    """Replies as a tagger sends them: known tags, every tag once per reply, three-digit scores (so ties are rare but present)."""
+    rng = random.Random(seed)
+    vocab = [l.strip() for l in open(DATA + "/top_tags.txt") if l.strip()][:1500]
+    tags, begin, mid, scores = [], [0], [], []
+    for _ in range(n_files):
+        k = rng.choice([0, 1, 2, 5, 20, 40, 60, 90])
+        prim = rng.sample(vocab, k)
+        ps = sorted((round(0.4 + 0.6 * rng.random(), 3) for _ in prim), reverse=True)
+        for t, s in zip(prim, ps):
+            tags.append(t.replace("_", " ") if rng.random() < 0.2 else t); scores.append(s)
+        mid.append(len(tags))
+        if merged:
+            extra = rng.sample(vocab, rng.choice([0, 3, 10, 25]))
+            sec = [(t, s) for t, s in zip(prim, ps)] + [(t, round(0.35 + 0.05 * rng.random(), 3)) for t in extra if t not in prim]
+            sec.sort(key=lambda x: -x[1])
+            for t, s in sec:
+                tags.append(t); scores.append(s)
+        begin.append(len(tags))
+    enc = [t.encode() for t in tags]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs[1:] = np.cumsum([len(b) for b in enc])
+    arena = np.frombuffer(b"".join(enc), dtype=np.uint8).copy() if enc else np.zeros(0, np.uint8)
+    return arena, offs, np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64), np.array(scores, dtype=np.float64)
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict", "builtin"])
+def test_wave_kernel_scored_replies(name):
+    """One reply per file through the wave kernel's scored front (general pipeline for what it declines)."""
+    from test_pipeline_logic_cpu import scored_inputs
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    arena, offs, begin, _, scores = clean_replies(3, 300, False)
+    sources = np.zeros(len(scores), np.uint8)
+    want, got = o.run_scored(arena, offs, begin, scores, sources), s.run_scored_fast(arena, offs, begin, scores, sources)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name + " clean replies")
+    if name == "shipped":
+        assert got.n_general < 30, got.n_general
+    args = scored_inputs(5, 300)                                  # unknown tags, duplicates, blanks, mixed sources: mostly declined, still equal
+    want, got = o.run_scored(*args), s.run_scored_fast(args[0], args[1], args[2], args[3], args[4])
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name + " messy replies")
+
+
+@pytest.mark.parametrize("name", ["shipped", "builtin"])
+@pytest.mark.parametrize("cap", [15, 3, 0])
+def test_wave_kernel_merged_replies(name, cap):
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    arena, offs, begin, mid, scores = clean_replies(11 + cap, 300, True)
+    want = o.run_merged(arena, offs, begin, mid, scores, cap)
+    got = s.run_scored_fast(arena, offs, begin, scores, None, mid, cap)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "%s clean merged cap %d" % (name, cap))
+    if name == "shipped":
+        assert got.n_general < 100, got.n_general               # two replies of 60 or 90 tags do not fit 128 candidates
+    arena, offs, begin, mid, scores = merged_inputs(23 + cap, 300)
+    want = o.run_merged(arena, offs, begin, mid, scores, cap)
+    got = s.run_scored_fast(arena, offs, begin, scores, None, mid, cap)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "%s messy merged cap %d" % (name, cap))
