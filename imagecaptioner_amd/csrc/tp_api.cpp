@@ -168,17 +168,26 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     }
     c->last_slow += n_slow;
     if (n_slow) {
-        const uint64_t n_waves = ((uint64_t)n_slow + 63) / 64;
-        c->wave_T.need(n_waves * 4); c->wave_LB.need(n_waves * 4); c->wave_bytes.need(n_waves * 8); c->wave_off.need((n_waves + 1) * 8);
-        c->tile_sums.need(scan_tiles_needed(std::max<uint64_t>(n, n_waves)) * 8);
-        HIP_OK(launch_wave_sizes(c->dt, io.arena, io.offsets, io.tag_begin, item_list, f0, n_slow, c->wave_T.as<uint32_t>(), c->wave_LB.as<uint32_t>(),
-                                 c->wave_bytes.as<uint64_t>(), d_status, s));
-        HIP_OK(launch_scan_u64(c->wave_bytes.as<uint64_t>(), n_waves, c->wave_off.as<uint64_t>(), c->tile_sums.as<uint64_t>(), nullptr, nullptr, s));
-        uint64_t ws_bytes = 0;
+        // The general kernel runs one file per lane, and the lanes of a wavefront wait for one another at every branch where
+        // their files differ: a few thousand files go one to a wavefront (or a few), many files 64 to a wavefront.
+        uint32_t fpw = 64;
+        while (fpw > 1 && (uint64_t)n_slow / fpw < 8192) fpw >>= 1;
+        const uint64_t spread_budget = std::min<uint64_t>(c->ws_budget, (uint64_t)4 << 30);   // a workspace row is 64 lanes wide however few hold a file
+        uint64_t n_waves = 0, ws_bytes = 0;
         uint32_t status = 0;
-        HIP_OK(hipMemcpyAsync(&ws_bytes, c->wave_off.as<uint64_t>() + n_waves, 8, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
+        for (;;) {
+            n_waves = ((uint64_t)n_slow + fpw - 1) / fpw;
+            c->wave_T.need(n_waves * 4); c->wave_LB.need(n_waves * 4); c->wave_bytes.need(n_waves * 8); c->wave_off.need((n_waves + 1) * 8);
+            c->tile_sums.need(scan_tiles_needed(std::max<uint64_t>(n, n_waves)) * 8);
+            HIP_OK(launch_wave_sizes(c->dt, io.arena, io.offsets, io.tag_begin, item_list, f0, n_slow, fpw, c->wave_T.as<uint32_t>(), c->wave_LB.as<uint32_t>(),
+                                     c->wave_bytes.as<uint64_t>(), d_status, s));
+            HIP_OK(launch_scan_u64(c->wave_bytes.as<uint64_t>(), n_waves, c->wave_off.as<uint64_t>(), c->tile_sums.as<uint64_t>(), nullptr, nullptr, s));
+            HIP_OK(hipMemcpyAsync(&ws_bytes, c->wave_off.as<uint64_t>() + n_waves, 8, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            if (status || fpw == 64 || ws_bytes <= spread_budget) break;
+            fpw <<= 1;                                             // too much memory for so thin a spread
+        }
         if (status) return fail(TP_E_INVALID_ARG, "a file is longer than 2 GiB");
         if (ws_bytes > c->ws_budget && n > 64) {
             uint64_t mid = f0 + n / 2;
@@ -191,7 +200,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         PipelineArgs pa{};
         pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
         pa.secondary_begin = io.secondary_begin; pa.secondary_cap = io.secondary_cap;
-        pa.item_list = item_list; pa.file0 = f0; pa.n_items = n_slow;
+        pa.item_list = item_list; pa.file0 = f0; pa.n_items = n_slow; pa.fpw = fpw;
         pa.wave_T = c->wave_T.as<uint32_t>(); pa.wave_LB = c->wave_LB.as<uint32_t>(); pa.wave_off = c->wave_off.as<uint64_t>();
         pa.workspace = c->workspace.as<uint8_t>();
         pa.verdicts = io.verdicts; pa.n_final = n_final; pa.cap_len = cap_len; pa.slot_of = slot_of;

@@ -198,6 +198,20 @@ TP_HD uint32_t set_put(W& w, BackLds& L, uint32_t key, uint32_t order, bool& cre
     return NO_ID;
 }
 
+// The slot of a key that was put, NO_ID when it was not (no writes: call it only between syncs that separate it from puts).
+TP_HD uint32_t set_find(const BackLds& L, uint32_t key) {
+    const uint32_t hsh = key * 2654435761u;
+    uint32_t s = hsh >> 24;
+    const uint32_t step = ((hsh >> 15) & 0xFEu) | 1u;
+    for (uint32_t probe = 0; probe < FAST_SET_SLOTS; ++probe) {
+        const uint32_t k = L.set_key[s];
+        if (k == key) return s;
+        if (k == NO_ID) return NO_ID;
+        s = (s + step) & (FAST_SET_SLOTS - 1);
+    }
+    return NO_ID;
+}
+
 // First-occurrence filter over up to 128 (key, valid) pairs held two per lane (element index = blk * 64 + lane); only the
 // first nblk blocks are looked at.  On return first[blk] marks the elements that are the first with their key; returns
 // false if the set overflowed.
@@ -1231,6 +1245,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
 
     TailIn ti;
     ti.nr = nr; ti.n = n; ti.n_selected = n_selected; ti.n_dropped = n_dropped;
+    if constexpr (Front::scored) ti.n = front->n_candidates;
     ti.settled = settled; ti.rejected = rejected; ti.kid = kid;
     return fast_tail<NF>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice);
 }
@@ -1256,6 +1271,7 @@ template <class W>
 struct ScoredFront {
     static constexpr bool scored = true;
     ScoredIn in;
+    uint32_t n_candidates = 0;     // finalCandidates.Count (Program.cs:223): one reply keeps entries with one string apart, the merge of two joins them
 
     // double -> key that sorts ascending where the score sorts descending (finite scores; -0.0 counts as 0.0)
     static TP_HD uint64_t desc_key(double sc) {
@@ -1318,67 +1334,75 @@ struct ScoredFront {
             order[0] = lane < P ? w.rank(p0) : w.rank(s0);
             order[1] = lane + 64 < P ? np0 + w.rank(p1) : ns0 + w.rank(s1);
         }
-        // Two kept tags of one reply with one normalised string would merge in ParseJoyTags' consumer (Program.cs:444-458, 636-649): not followed here
-        bool alive[2] = {valid[0], valid[1]};
-        if (!in.merged) {
-            bool first[2];
-            if (!dedupe_first(w, L, id, valid, first, mblk)) return false;
-            if (w.ballot((valid[0] && !first[0]) || (valid[1] && !first[1]))) return false;
-        } else {
-            const bool isP[2] = {lane < P, lane + 64 < P};
-            const bool vp[2] = {valid[0] && isP[0], valid[1] && isP[1]}, vs[2] = {valid[0] && !isP[0], valid[1] && !isP[1]};
-            bool first[2];
-            if (!dedupe_first(w, L, id, vs, first, mblk)) return false;
-            if (w.ballot((vs[0] && !first[0]) || (vs[1] && !first[1]))) return false;
-            // the primary reply's tags into the set, each with its element index; the secondary reply's tags look themselves up
+        const bool isP[2] = {lane < P, lane + 64 < P};
+        bool accept[2] = {valid[0], valid[1]};
+        if (in.merged) {
+            // LimitSecondaryTags (Program.cs:801-815), entry by entry: what the primary reply holds passes; of the other entries
+            // the `cap` best by (score, order) pass
             set_clear(w, L);
-            bool dup = false, full = false;
-            uint32_t slot[2] = {NO_ID, NO_ID};
+            bool full = false;
             TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
-                if (vp[blk]) { bool created; slot[blk] = set_put(w, L, id[blk], (uint32_t)blk * 64 + lane, created); dup = dup || !created; full = full || slot[blk] == NO_ID; }
-            w.sync();
-            if (w.ballot(dup || full)) return false;
-            bool twin[2] = {false, false};
-            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
-                if (vs[blk]) { bool created; slot[blk] = set_put(w, L, id[blk], 0xFFFFFFFEu, created); twin[blk] = !created; full = full || slot[blk] == NO_ID; }
+                if (valid[blk] && isP[blk]) { bool created; full = full || set_put(w, L, id[blk], 0, created) == NO_ID; }
             w.sync();
             if (w.ballot(full)) return false;
-            // LimitSecondaryTags (Program.cs:801-815): tags the primary reply holds pass; of the others the `cap` best by (score, order)
-            uint64_t* twK = (uint64_t*)L.line;                     // the text is not read any more: per element of the primary reply, its twin's key ...
-            uint32_t* twO = (uint32_t*)(L.line + 1024);            // ... and order, 0xFFFFFFFF without a twin
-            uint32_t* k2q = (uint32_t*)(L.line + 1536);
-            if (lane < 64) { twO[lane] = 0xFFFFFFFFu; twO[lane + 64] = 0xFFFFFFFFu; }
-            const bool sonly[2] = {vs[0] && !twin[0], vs[1] && !twin[1]};
+            bool sonly[2] = {false, false};
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) sonly[blk] = valid[blk] && !isP[blk] && set_find(L, id[blk]) == NO_ID;
             const uint32_t n_sonly = popc64(w.ballot(sonly[0])) + (mblk > 1 ? popc64(w.ballot(sonly[1])) : 0);
-            bool accept[2] = {vs[0], vs[1]};
-            if (in.cap <= 0) { accept[0] = accept[1] = false; }   // "if (cap <= 0 ...) return []": then not even the tags of the primary reply pass
+            if (in.cap <= 0) { if (!isP[0]) accept[0] = false; if (!isP[1]) accept[1] = false; }   // "if (cap <= 0 ...) return []": nothing of the secondary reply passes
             else if (n_sonly > (uint32_t)in.cap) {
+                uint64_t* rk = (uint64_t*)L.line;                  // the text is not read any more
+                uint32_t* ro = (uint32_t*)(L.line + 1024);
                 w.sync();
-                // rank of every secondary-only tag among them, by (score descending, order): keys through LDS
-                uint64_t* rk = (uint64_t*)L.line;
-                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) { const uint32_t e = (uint32_t)blk * 64 + lane; if (e < M) { rk[e] = K[blk]; k2q[e] = sonly[blk] ? order[blk] : 0xFFFFFFFFu; } }
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) { const uint32_t e = (uint32_t)blk * 64 + lane; if (e < M) { rk[e] = K[blk]; ro[e] = sonly[blk] ? order[blk] : 0xFFFFFFFFu; } }
                 w.sync();
                 uint32_t before[2] = {0, 0};
                 for (uint32_t f = P; f < M; ++f) {
-                    const uint32_t of = k2q[f];
+                    const uint32_t of = ro[f];
                     if (of == 0xFFFFFFFFu) continue;
                     const uint64_t kf = rk[f];
                     TP_UNROLL for (int blk = 0; blk < 2; ++blk) before[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && of < order[blk]));
                 }
                 TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (sonly[blk] && before[blk] >= (uint32_t)in.cap) accept[blk] = false;
-                w.sync();
-                if (lane < 64) { twO[lane] = 0xFFFFFFFFu; twO[lane + 64] = 0xFFFFFFFFu; }
             }
             w.sync();
-            // MergeCandidateTags (Program.cs:442-461): a tag of both replies keeps the better score, the earlier order and, the
-            // scores compared as PreferSource is called there, the source of lower rank: the primary reply's
-            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
-                if (accept[blk] && twin[blk]) { const uint32_t pe = L.set_min[slot[blk]]; twK[pe] = K[blk]; twO[pe] = order[blk]; }
+        }
+        // Entries with one normalised string become one candidate with the best score and the earliest order (ParseJoyTags keeps
+        // them apart, MergeCandidateTags and SelectTags join them: Program.cs:444-458, 636-649); its source is the one of lower
+        // rank wherever PreferSource is asked with the scores it gets there, which between the two replies is the primary one.
+        bool alive[2] = {false, false};
+        {
+            uint64_t* gK = (uint64_t*)L.line;                      // per set slot: the best key of the entries with that string
+            static_assert(FAST_SET_SLOTS * 8 <= FAST_LINE_MAX && FAST_SET_SLOTS / 32 <= FAST_FRULES_MAX / 32, "per-slot columns fit the line buffer and the facet-hit words");
+            set_clear(w, L);
+            for (uint32_t k = lane; k < FAST_SET_SLOTS; k += 64) gK[k] = ~0ull;
+            if (lane < FAST_SET_SLOTS / 32) L.fhit[lane] = 0;      // bit per slot: an entry of the primary reply is among them
             w.sync();
+            uint32_t slot[2] = {NO_ID, NO_ID};
+            bool rep[2] = {false, false}, full = false;
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
+                if (accept[blk]) {
+                    slot[blk] = set_put(w, L, id[blk], order[blk], rep[blk]);
+                    if (slot[blk] == NO_ID) full = true;
+                    else {
+                        w.lds_min64(&gK[slot[blk]], K[blk]);
+                        if (in.merged && isP[blk]) w.lds_or(&L.fhit[slot[blk] >> 5], 1u << (slot[blk] & 31));
+                    }
+                }
+            w.sync();
+            if (w.ballot(full)) return false;
+            if (!in.merged && w.ballot((accept[0] && !rep[0]) || (accept[1] && !rep[1]))) {
+                // one reply with sources of its own per tag: joined entries of different sources would need PreferSource followed
+                const uint64_t m0 = w.ballot(accept[0]);
+                const uint32_t ref = m0 ? w.bcast(src[0], ctz64(m0)) : w.bcast(src[1], ctz64(w.ballot(accept[1])));
+                if (w.ballot((accept[0] && src[0] != ref) || (accept[1] && src[1] != ref))) return false;
+            }
             TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) {
-                const uint32_t e = (uint32_t)blk * 64 + lane;
-                if (vp[blk] && twO[e] != 0xFFFFFFFFu) { const uint64_t k = twK[e]; K[blk] = k < K[blk] ? k : K[blk]; order[blk] = twO[e] < order[blk] ? twO[e] : order[blk]; }
-                alive[blk] = vp[blk] || (accept[blk] && !twin[blk]);
+                alive[blk] = accept[blk] && rep[blk];
+                if (alive[blk]) {
+                    K[blk] = gK[slot[blk]];
+                    order[blk] = L.set_min[slot[blk]];
+                    if (in.merged) src[blk] = ((L.fhit[slot[blk] >> 5] >> (slot[blk] & 31)) & 1u) ? (uint32_t)TP_SRC_PRIMARY_JOY : (uint32_t)TP_SRC_SECONDARY_JOY;
+                }
             }
             w.sync();
         }
@@ -1406,6 +1430,7 @@ struct ScoredFront {
         }
         if (w.ballot(tie)) return false;                           // the insertion order of the merge decides between them: general kernel
         n = popc64(w.ballot(alive[0])) + (mblk > 1 ? popc64(w.ballot(alive[1])) : 0);
+        n_candidates = in.merged ? n : popc64(w.ballot(valid[0])) + (mblk > 1 ? popc64(w.ballot(valid[1])) : 0);
         w.sync();
         TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
             if (alive[blk]) {

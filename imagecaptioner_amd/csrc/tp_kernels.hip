@@ -79,6 +79,7 @@ struct DevWave {
     __device__ uint32_t lds_cas(uint32_t* p, uint32_t cmp, uint32_t val) const { return atomicCAS(p, cmp, val); }
     __device__ void lds_min(uint32_t* p, uint32_t v) const { atomicMin(p, v); }
     __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
+    __device__ void lds_min64(uint64_t* p, uint64_t v) const { atomicMin((unsigned long long*)p, (unsigned long long)v); }
     __device__ void copy16(uint8_t* lds_dst, const uint8_t* src) const { *(uint4*)lds_dst = *(const uint4*)src; }
     __device__ void fill16(uint32_t* lds_dst, uint32_t v) const { *(uint4*)lds_dst = make_uint4(v, v, v, v); }
 };
@@ -232,10 +233,13 @@ __device__ inline uint32_t count_commas(const uint8_t* p, uint32_t n) {
 
 __global__ __launch_bounds__(256) void k_wave_sizes(DevTables t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin,
                                                     const uint32_t* item_list, uint64_t file0, uint64_t n_items, uint32_t* wave_T, uint32_t* wave_LB,
-                                                    uint64_t* wave_bytes, uint32_t* status) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                    uint64_t* wave_bytes, uint32_t* status, uint32_t fpw) {
+    // fpw files per wavefront (lanes 0 .. fpw - 1 hold one each): few files are spread over many wavefronts, see run_range
+    const uint64_t th = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = (th >> 6) * fpw + (th & 63);
+    const bool mine = (th & 63) < fpw && i < n_items;
     uint32_t T = 1, LB = 0;
-    if (i < n_items) {
+    if (mine) {
         uint64_t f = file0 + (item_list ? (uint64_t)item_list[i] : i);
         if (tag_begin) {   // scored ingest: tag count and total text length are read off the offset arrays
             uint64_t lo = tag_begin[f], hi = tag_begin[f + 1];
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void k_wave_sizes(DevTables t, const uint8_t* 
         LB = LB > oL ? LB : oL;
     }
     if ((threadIdx.x & 63) == 0 && i < n_items) {
-        uint64_t w = i >> 6;
+        uint64_t w = th >> 6;
         WsLayout L = ws_layout(T, LB, t.final_cap, t.evidence_grow, t.lit_words);
         wave_T[w] = T;
         wave_LB[w] = LB;
@@ -328,11 +332,12 @@ uint64_t scan_tiles_needed(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE 
 // k_pipeline
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // item index
-    if (i >= a.n_items) return;
+    const uint64_t th = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // workspace slot: wavefront th >> 6, lane th & 63
+    const uint64_t i = (th >> 6) * a.fpw + (th & 63);                  // item index: a.fpw files per wavefront
+    if ((th & 63) >= a.fpw || i >= a.n_items) return;
     uint64_t f = a.file0 + (a.item_list ? (uint64_t)a.item_list[i] : i);
-    uint64_t w = i >> 6;
-    uint32_t lane = (uint32_t)(i & 63);
+    uint64_t w = th >> 6;
+    uint32_t lane = (uint32_t)(th & 63);
     WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
     FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, lane);
     FileIn in;
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
     a.verdicts[f] = out.verdict;
     a.n_final[f] = out.n_final;
     a.cap_len[f] = out.caption_len;
-    a.slot_of[f] = (uint32_t)i;
+    a.slot_of[f] = (uint32_t)th;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -600,10 +605,11 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,
-                             uint64_t file0, uint64_t n_items, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s) {
+                             uint64_t file0, uint64_t n_items, uint32_t fpw, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s) {
     if (n_items == 0) return hipSuccess;
-    unsigned blocks = (unsigned)((n_items + 255) / 256);
-    hipLaunchKernelGGL(k_wave_sizes, dim3(blocks), dim3(256), 0, s, t, arena, offsets, tag_begin, item_list, file0, n_items, wave_T, wave_LB, wave_bytes, status);
+    const uint64_t waves = (n_items + fpw - 1) / fpw;
+    unsigned blocks = (unsigned)((waves * 64 + 255) / 256);
+    hipLaunchKernelGGL(k_wave_sizes, dim3(blocks), dim3(256), 0, s, t, arena, offsets, tag_begin, item_list, file0, n_items, wave_T, wave_LB, wave_bytes, status, fpw);
     return hipGetLastError();
 }
 hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s) {
@@ -614,7 +620,8 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64
 }
 hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_t s) {
     if (a.n_items == 0) return hipSuccess;
-    unsigned blocks = (unsigned)((a.n_items + 255) / 256);
+    const uint64_t waves = (a.n_items + a.fpw - 1) / a.fpw;
+    unsigned blocks = (unsigned)((waves * 64 + 255) / 256);
     hipLaunchKernelGGL(k_pipeline, dim3(blocks), dim3(256), 0, s, t, a);
     return hipGetLastError();
 }

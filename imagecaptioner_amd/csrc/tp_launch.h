@@ -49,6 +49,7 @@ struct PipelineArgs {
     const uint32_t* item_list;    // may be null
     uint64_t file0;
     uint64_t n_items;
+    uint32_t fpw;                 // files per wavefront of the workspace layout (64, or fewer to spread few files over many wavefronts)
     const uint32_t* wave_T;       // per workspace wave: token capacity and line-length capacity
     const uint32_t* wave_LB;
     const uint64_t* wave_off;     // per workspace wave: byte offset of its workspace
@@ -82,7 +83,7 @@ struct EmitArgs {
 
 hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s);
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,
-                             uint64_t file0, uint64_t n_items, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s);
+                             uint64_t file0, uint64_t n_items, uint32_t fpw, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s);
 hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s);
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s);
 uint64_t scan_tiles_needed(uint64_t n);

@@ -104,6 +104,7 @@ struct Wave {
     uint32_t lds_cas(uint32_t* p, uint32_t cmp, uint32_t val) { uint32_t old = *p; if (old == cmp) *p = val; return old; }
     void lds_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
     void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+    void lds_min64(uint64_t* p, uint64_t v) { if (v < *p) *p = v; }
     void copy16(uint8_t* dst, const uint8_t* src) { std::memcpy(dst, src, 16); }
     void fill16(uint32_t* dst, uint32_t v) { for (int k = 0; k < 4; ++k) dst[k] = v; }
     void tick(int) {}

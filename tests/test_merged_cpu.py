@@ -133,3 +133,38 @@ def test_wave_kernel_merged_replies(name, cap):
     want = o.run_merged(arena, offs, begin, mid, scores, cap)
     got = s.run_scored_fast(arena, offs, begin, scores, None, mid, cap)
     assert_same_results(got, want, s.histogram_dict(got.histogram), "%s messy merged cap %d" % (name, cap))
+
+
+def test_wave_kernel_joins_repeated_tags():
+    """A tag twice in one reply (as written, or as two spellings of one normalised string): one candidate with the best score and
+    the earliest order, counted twice in finalCandidates; twice in the secondary reply it takes two places of the cap."""
+    from helpers import shipped_config
+    cfg = shipped_config()
+    o, s = Oracle(cfg), HostSim(cfg)
+    rng = random.Random(2)
+    vocab = [l.strip() for l in open(DATA + "/top_tags.txt") if l.strip()][:800]
+    tags, begin, mid, scores = [], [0], [], []
+    for _ in range(300):
+        prim = rng.sample(vocab, rng.choice([3, 10, 30]))
+        ps = [round(0.4 + 0.6 * rng.random(), 3) for _ in prim]
+        for t, sc in list(zip(prim, ps))[:rng.choice([1, 2, 4])]:
+            prim.append(rng.choice([t, t.replace("_", " "), t.upper()])); ps.append(round(sc + rng.choice([-0.2, -0.01, 0.0, 0.02, 0.3]), 3))
+        tags += prim; scores += ps
+        mid.append(len(tags))
+        sec = rng.sample(vocab, 12)
+        sec += [sec[0], sec[1].replace("_", " "), prim[0]]
+        tags += sec; scores += [round(0.3 + 0.2 * rng.random(), 3) for _ in sec]
+        begin.append(len(tags))
+    enc = [t.encode() for t in tags]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in enc])
+    arena = np.frombuffer(b"".join(enc), dtype=np.uint8).copy()
+    begin, mid, scores = np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64), np.array(scores, dtype=np.float64)
+    src = np.zeros(len(scores), np.uint8)
+    want, got = o.run_scored(arena, offs, begin, scores, src), s.run_scored_fast(arena, offs, begin, scores, src)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "repeated tags, one reply")
+    assert got.n_general < 60, got.n_general
+    for cap in (15, 5):
+        want, got = o.run_merged(arena, offs, begin, mid, scores, cap), s.run_scored_fast(arena, offs, begin, scores, None, mid, cap)
+        assert_same_results(got, want, s.histogram_dict(got.histogram), "repeated tags, merged cap %d" % cap)
+        assert got.n_general < 60, got.n_general
