@@ -10,7 +10,7 @@ from imagecaptioner_amd import Config, TagPipe  # noqa: E402
 from imagecaptioner_amd.corpus import make_corpus  # noqa: E402
 
 n = int(sys.argv[1])
-modes = sys.argv[2:] or ["plain", "unknown3", "blanks", "capitals", "crlf", "trailing_comma"]
+modes = sys.argv[2:] or ["plain", "unknown3", "blanks", "capitals", "crlf", "trailing_comma", "cr_inside_2pc"]
 c = make_corpus("c2", n, seed=1)
 a = bytes(c.arena)
 base = [a[int(c.offsets[i]):int(c.offsets[i + 1])].rstrip(b"\n") for i in range(n)]
@@ -27,6 +27,8 @@ for mode in modes:
         lines = [l.title() for l in base]
     elif mode == "crlf":
         lines = [l + b"\r\n" for l in base]
+    elif mode == "cr_inside_2pc":                          # every 50th file is broken over lines the Windows way: general kernel
+        lines = [l.replace(b", ", b",\r\n", 3) if i % 50 == 0 else l for i, l in enumerate(base)]
     elif mode == "trailing_comma":
         lines = [l + b"," for l in base]
     else:
