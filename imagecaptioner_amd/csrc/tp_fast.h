@@ -268,6 +268,7 @@ TP_HD uint32_t slot_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_
 //           1: interned, id in `out`
 //           2: not in any table
 //           3: the file is not for this kernel
+//           4: (only with miss_words) in no table and dropped under strict vocabulary; its normalised bytes, at most 32, in miss_words
 // On a hit `rec` receives the record of `out`.
 // `high`: the token holds bytes of characters outside ASCII.  This kernel does not decode them; it accepts the token only
 // when its bytes as they stand are a known string that the normalisation before the alias lookup leaves alone: then that
@@ -278,7 +279,7 @@ TP_HD uint32_t slot_find32(const DevTables& t, uint64_t hsh, uint32_t n, uint64_
 // stay in registers), so hashing costs one multiply per word and a probe hit is verified word by word against
 // DevTables::str_words.
 TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t j, bool special, bool high, uint32_t& out, Rec& rec, bool& valid_dyn,
-                     uint32_t& dyn_len) {
+                     uint32_t& dyn_len, uint64_t* miss_words = nullptr) {
     if (high && special) return 3;
     // Up to 32 bytes that are, or with a few byte-wise changes become, the normalised string: hashed straight from the line.
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
@@ -320,7 +321,11 @@ TP_HD int fast_token(const DevTables& t, const uint8_t* s, uint32_t i, uint32_t 
         if (id != NO_ID && (!high || (kflags & SLOT_KEY_BASIC))) { out = id; return 1; }
         // These bytes are the normalised string, and every interned string of up to 32 bytes is a key of the slots: a miss
         // means the tag is in no table.  Under strict vocabulary it is dropped whatever it looks like (Program.cs:1121-1133).
-        if (id == NO_ID && !high && t.drop_unknown) { valid_dyn = false; dyn_len = n; return 2; }
+        if (id == NO_ID && !high && t.drop_unknown) {
+            valid_dyn = false; dyn_len = n;
+            if (miss_words) { miss_words[0] = w0; miss_words[1] = w1; miss_words[2] = w2; miss_words[3] = w3; return 4; }   // ... for a caller that tells such strings apart
+            return 2;
+        }
     }
     if (high) return 3;
     while (i < j && ws32(s[i])) ++i;
@@ -1080,6 +1085,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         bad2[blk] = nonblank2[blk] && (!(r2[blk].flags & FL_VALID) || (r2[blk].flags & FL_DROP));
         ev_seed[blk] = Front::scored ? seed_in[blk] : ci[blk] < t.seed_ci_limit;   // !(score < 0.28), Program.cs:724
     }
+    if constexpr (Front::scored) style_n += front->extra_style;
     const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
     if (m_hop2) {   // a hop may have merged two candidates: keep first occurrences
         if (!dedupe_first(w, L, t2, nonblank2, first2, nblk)) return false;
@@ -1093,6 +1099,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         ev_seed[blk] = ev_seed[blk] && first2[blk];
     }
 
+    if constexpr (Front::scored) n_dropped += front->extra_dropped;
     w.tick(4);
     TP_STOP(4, t2[0] ^ t2[1] ^ r2[0].flags ^ r2[1].flags ^ r2[0].next ^ (uint32_t)uniq[0] ^ (uint32_t)uniq[1] ^ (uint32_t)ev_seed[0] ^ (uint32_t)ev_seed[1] ^ (uint32_t)style_cap ^ n_dropped)
     // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
@@ -1235,6 +1242,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
             n_evidence = w.sum(made);
             if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
         }
+        if constexpr (Front::scored) n_evidence += front->extra_evidence;
         if (!count) n_evidence = 0xFFFF;
         ev_feet = w.ballot(ev_feet) != 0;
         ev_penis = w.ballot(ev_penis) != 0;
@@ -1267,10 +1275,15 @@ struct ScoredIn {
     int cap;                       // LimitSecondaryTags' cap on tags the primary reply does not hold
 };
 
+TP_HD uint32_t classify_dyn(const DevTables& t, const uint8_t* p, uint32_t n);   // tp_pipeline.h: attributes of a string in no table
+
 template <class W>
 struct ScoredFront {
     static constexpr bool scored = true;
     ScoredIn in;
+    // Candidates in no table (strict vocabulary drops them in SelectTags, Program.cs:631-634, but they count): distinct strings
+    // among the candidates, those of them with !(score < 0.28) (evidence, Program.cs:724), those in the style bucket with score >= 0.60
+    uint32_t extra_dropped = 0, extra_evidence = 0, extra_style = 0;
     uint32_t n_candidates = 0;     // finalCandidates.Count (Program.cs:223): one reply keeps entries with one string apart, the merge of two joins them
 
     // double -> key that sorts ascending where the score sorts descending (finite scores; -0.0 counts as 0.0)
@@ -1280,6 +1293,13 @@ struct ScoredFront {
         __builtin_memcpy(&b, &sc, 8);
         const uint64_t asc = b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
         return ~asc;
+    }
+    static TP_HD double key_score(uint64_t key) {
+        const uint64_t asc = ~key;
+        const uint64_t b = asc ^ ((asc >> 63) ? 0x8000000000000000ull : ~0ull);
+        double sc;
+        __builtin_memcpy(&sc, &b, 8);
+        return sc;
     }
 
     TP_HD bool run(W& w, const DevTables& t, FastLds& L, int& nblk, uint32_t& n, bool (&act)[2], uint32_t (&h1)[2], Rec (&r1)[2], bool (&seed)[2], bool (&strong)[2]) {
@@ -1308,6 +1328,9 @@ struct ScoredFront {
         uint32_t id[2] = {NO_ID, NO_ID}, src[2] = {0, 0};
         uint64_t K[2] = {~0ull, ~0ull};
         bool valid[2] = {false, false}, decline = false;
+        bool unk[2] = {false, false}, ustyle[2] = {false, false};  // a string in no table: told apart by its bytes
+        uint64_t uw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        uint32_t un[2] = {0, 0};
         TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) {
             const uint32_t e = (uint32_t)blk * 64 + lane;
             if (e < M) {
@@ -1317,13 +1340,37 @@ struct ScoredFront {
                 uint32_t dlen = 0;
                 bool vdyn = false;
                 Rec rr;
-                const int kind = j < i ? 3 : fast_token(t, s, i, j, true, false, id[blk], rr, vdyn, dlen);
+                const int kind = j < i ? 3 : fast_token(t, s, i, j, true, false, id[blk], rr, vdyn, dlen, uw[blk]);
                 if (kind == 0) { id[blk] = t.alias1[EMPTY_ID]; rr = t.rec[id[blk]]; }      // NormalizeTag("") still goes through the alias lookup
-                if (kind >= 2) decline = true;                    // a tag in no table stays a candidate here (it counts as dropped and as evidence): general kernel
+                if (kind == 4) { unk[blk] = true; un[blk] = dlen; valid[blk] = true; }      // stays a candidate: it counts as dropped and as evidence
+                else if (kind >= 2) decline = true;               // a string in no table that may survive, or that took the byte-wise normaliser: general kernel
                 else valid[blk] = !(rr.flags & FL_BLANK);
             }
         }
         if (w.ballot(decline)) return false;
+        {
+            // strings in no table get the element index of their first occurrence as a stand-in id (above every real id)
+            const uint64_t mu[2] = {w.ballot(unk[0]), mblk > 1 ? w.ballot(unk[1]) : 0};
+            for (int b2 = 0; b2 < 2; ++b2) {
+                uint64_t m = mu[b2];
+                while (m) {
+                    const uint32_t q = ctz64(m);
+                    m &= m - 1;
+                    const uint32_t qn = w.bcast(un[b2], q);
+                    uint64_t qw[4];
+                    for (int k = 0; k < 4; ++k) qw[k] = (uint64_t)w.bcast((uint32_t)uw[b2][k], q) | ((uint64_t)w.bcast((uint32_t)(uw[b2][k] >> 32), q) << 32);
+                    TP_UNROLL for (int blk = 0; blk < 2; ++blk)
+                        if (unk[blk] && id[blk] == NO_ID && un[blk] == qn && uw[blk][0] == qw[0] && uw[blk][1] == qw[1] && uw[blk][2] == qw[2] && uw[blk][3] == qw[3])
+                            id[blk] = 0xF0000000u | ((uint32_t)b2 * 64 + q);
+                }
+            }
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk)
+                if (unk[blk]) {
+                    uint8_t bytes[32];
+                    for (int k = 0; k < 32; ++k) bytes[k] = (uint8_t)(uw[blk][k >> 3] >> (8 * (k & 7)));
+                    ustyle[blk] = fl_bucket(classify_dyn(t, bytes, un[blk])) == B_STYLE;   // DetermineStyleQualityCap classifies whatever the tagger sent (Program.cs:704-706)
+                }
+        }
         // order: the running index among the reply's kept tags (Program.cs:474, 486)
         uint32_t order[2] = {0, 0};
         {
@@ -1410,6 +1457,16 @@ struct ScoredFront {
         uint64_t* Kq = (uint64_t*)L.line;
         uint32_t* k2q = (uint32_t*)(L.line + 1024);
         uint32_t* idq = (uint32_t*)(L.line + 1536);
+        {
+            // the candidates in no table are counted here and take no lane: SelectTags drops every one of them
+            bool useed[2], ustrong[2];
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) { const double sc = key_score(K[blk]); useed[blk] = alive[blk] && unk[blk] && !(sc < 0.28); ustrong[blk] = alive[blk] && unk[blk] && ustyle[blk] && sc >= 0.60; }
+            n_candidates = popc64(w.ballot(in.merged ? alive[0] : valid[0])) + (mblk > 1 ? popc64(w.ballot(in.merged ? alive[1] : valid[1])) : 0);
+            extra_dropped = popc64(w.ballot(alive[0] && unk[0])) + (mblk > 1 ? popc64(w.ballot(alive[1] && unk[1])) : 0);
+            extra_evidence = popc64(w.ballot(useed[0])) + (mblk > 1 ? popc64(w.ballot(useed[1])) : 0);
+            extra_style = popc64(w.ballot(ustrong[0])) + (mblk > 1 ? popc64(w.ballot(ustrong[1])) : 0);
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (unk[blk]) alive[blk] = false;
+        }
         uint32_t k2[2];
         TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
             k2[blk] = alive[blk] ? ((uint32_t)source_rank(src[blk]) << 16) | order[blk] : 0xFFFFFFFFu;
@@ -1430,16 +1487,11 @@ struct ScoredFront {
         }
         if (w.ballot(tie)) return false;                           // the insertion order of the merge decides between them: general kernel
         n = popc64(w.ballot(alive[0])) + (mblk > 1 ? popc64(w.ballot(alive[1])) : 0);
-        n_candidates = in.merged ? n : popc64(w.ballot(valid[0])) + (mblk > 1 ? popc64(w.ballot(valid[1])) : 0);
         w.sync();
         TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
             if (alive[blk]) {
                 idq[before[blk]] = id[blk];
-                // !(score < 0.28) and score >= 0.60 of the merged score, read back from its key
-                const uint64_t asc = ~K[blk];
-                const uint64_t b = asc ^ ((asc >> 63) ? 0x8000000000000000ull : ~0ull);
-                double merged_score;
-                __builtin_memcpy(&merged_score, &b, 8);
+                const double merged_score = key_score(K[blk]);   // !(score < 0.28) and score >= 0.60 of the merged score
                 k2q[before[blk]] = (uint32_t)(!(merged_score < 0.28)) | ((uint32_t)(merged_score >= 0.60) << 1);
             }
         w.sync();

@@ -168,3 +168,37 @@ def test_wave_kernel_joins_repeated_tags():
         want, got = o.run_merged(arena, offs, begin, mid, scores, cap), s.run_scored_fast(arena, offs, begin, scores, None, mid, cap)
         assert_same_results(got, want, s.histogram_dict(got.histogram), "repeated tags, merged cap %d" % cap)
         assert got.n_general < 60, got.n_general
+
+
+def test_wave_kernel_counts_tags_in_no_table():
+    """Under strict vocabulary a reply's tags that are in no table are dropped by SelectTags but count as candidates, as dropped
+    tags, as evidence and (in the style bucket, score >= 0.60) towards the style cap: the scored front tells them apart by bytes."""
+    from helpers import shipped_config
+    cfg = shipped_config()
+    o, s = Oracle(cfg), HostSim(cfg)
+    rng = random.Random(6)
+    vocab = [l.strip() for l in open(DATA + "/top_tags.txt") if l.strip()][:800]
+    odd = [";)", ";d", "zz_unknown", "ZZ Unknown", "zz_unknown", "best_quality_zz", "masterpiece_zz", "highres_zz", "absurdres_zz", "some thing new", "x!y", "a"]
+    tags, begin, mid, scores = [], [0], [], []
+    for _ in range(300):
+        prim = rng.sample(vocab, rng.choice([3, 10, 30])) + rng.sample(odd, rng.choice([1, 2, 4]))
+        rng.shuffle(prim)
+        tags += prim; scores += [round(0.2 + 0.8 * rng.random(), 3) for _ in prim]
+        mid.append(len(tags))
+        sec = rng.sample(vocab, 8) + rng.sample(odd, rng.choice([0, 2, 5])) + prim[:3]
+        tags += sec; scores += [round(0.2 + 0.5 * rng.random(), 3) for _ in sec]
+        begin.append(len(tags))
+    enc = [t.encode() for t in tags]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in enc])
+    arena = np.frombuffer(b"".join(enc), dtype=np.uint8).copy()
+    begin, mid, scores = np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64), np.array(scores, dtype=np.float64)
+    src = np.zeros(len(scores), np.uint8)
+    want, got = o.run_scored(arena, offs, begin, scores, src), s.run_scored_fast(arena, offs, begin, scores, src)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "tags in no table, one reply")
+    assert got.n_general < 30, got.n_general
+    assert (want.verdicts["n_dropped"] > 0).mean() > 0.9
+    for cap in (15, 2):
+        want, got = o.run_merged(arena, offs, begin, mid, scores, cap), s.run_scored_fast(arena, offs, begin, scores, None, mid, cap)
+        assert_same_results(got, want, s.histogram_dict(got.histogram), "tags in no table, merged cap %d" % cap)
+        assert got.n_general < 30, got.n_general

@@ -2,11 +2,9 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-rm -f gpurun_out/fpw.txt
-for f in 64 16 4 1; do
-echo "fpw $f" >> gpurun_out/fpw.txt
-TAGPIPE_GENERAL_FPW=$f timeout -k 10 300 python3 tools/variant_timing.py 200000 cr_inside_2pc >> gpurun_out/fpw.txt 2>&1
-done
-echo "default" >> gpurun_out/fpw.txt
-timeout -k 10 300 python3 tools/variant_timing.py 200000 >> gpurun_out/fpw.txt 2>&1
-cat gpurun_out/fpw.txt
+timeout -k 10 900 python3 -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.txt 2>&1 || { tail -40 gpurun_out/gpu_tests.txt; exit 1; }
+tail -3 gpurun_out/gpu_tests.txt
+timeout -k 10 400 python3 tools/scored_timing.py c2 200000 > gpurun_out/scored.txt 2>&1
+cat gpurun_out/scored.txt
+timeout -k 10 300 python3 bench.py --cpu-sample 0 > gpurun_out/bench.json 2> gpurun_out/bench.err
+cut -c1-640 gpurun_out/bench.json
