@@ -991,10 +991,10 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     bool act[2] = {false, false};
     uint32_t h1[2] = {EMPTY_ID, EMPTY_ID}, ci[2] = {0, 0};
     Rec r1[2];
-    r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
     bool rejected = false;
     bool seed_in[2] = {false, false}, strong_in[2] = {false, false};   // scored candidates: !(score < 0.28), score >= 0.60
     if constexpr (Front::scored) {
+        r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
         if (!front->run(w, t, L, nblk, n, act, h1, r1, seed_in, strong_in)) return false;
     } else {
     Scan sc;
@@ -1010,6 +1010,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     // ---- S4: tokens -> interned ids; Length >= 2, !ShouldDropTag, Distinct (Program.cs:598-602) ---------------------------
     // A token's lane stays its candidate's lane: candidate index = number of kept tokens before it.
     nblk = NT == 1 ? 1 : (T > 64 ? 2 : 1);                        // tokens (and so candidates) sit two per lane only in long lines
+    r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
     {
         bool keep[2] = {false, false};
         bool dyn_survivor = false;
