@@ -33,3 +33,31 @@ def test_corpus_digests_oracle_matches_golden(name):
     assert hashlib.sha256(r.verdicts.tobytes()).hexdigest() == g["verdicts_sha256"]
     assert r.counters == g["counters"]
     assert sorted(r.histogram.items(), key=lambda kv: (-kv[1], kv[0]))[:20] == [tuple(x) for x in g["top_tags"]]
+
+
+def check_replies_golden(run_scored, run_merged, triage, name, g):
+    """Shared by the oracle test here and the GPU test: the three entry points against tests/golden/replies.json."""
+    import numpy as np
+    from golden.make_golden import pack_tags
+    files, exp = g["files"], g["expected"][name]
+    prim = [[tuple(x) for x in f["primary"]] for f in files]
+    both = [[tuple(x) for x in f["primary"] + f["secondary"]] for f in files]
+    a, offs, begin, scores = pack_tags(prim)
+    r = run_scored(a, offs, begin, scores, np.zeros(len(scores), np.uint8))
+    for i, e in enumerate(exp["scored"]):
+        assert r.caption(i).decode("utf-8") == e["caption"] and [int(x) for x in r.verdicts[i]] == e["verdict"], (name, "scored", i)
+    a, offs, begin, scores = pack_tags(both)
+    mid = begin[:-1] + np.array([len(f["primary"]) for f in files], dtype=np.uint64)
+    for cap in (15, 2):
+        r = run_merged(a, offs, begin, mid, scores, cap)
+        for i, e in enumerate(exp["merged_cap%d" % cap]):
+            assert r.caption(i).decode("utf-8") == e["caption"] and [int(x) for x in r.verdicts[i]] == e["verdict"], (name, "merged", cap, i)
+    assert [int(x) for x in triage(g["texts"])] == exp["triage"], (name, "triage")
+
+
+@pytest.mark.parametrize("name", ["shipped", "builtin"])
+def test_replies_oracle_matches_golden(name):
+    with open(os.path.join(GOLDEN, "replies.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    o = Oracle(CONFIGS[name]())
+    check_replies_golden(o.run_scored, o.run_merged, o.triage_texts, name, g)

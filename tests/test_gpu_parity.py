@@ -42,6 +42,16 @@ def test_edge_lines_match_committed_golden():
             assert [int(x) for x in got.verdicts[i]] == exp["verdict"], (name, i)
 
 
+@pytest.mark.parametrize("name", ["shipped", "builtin"])
+def test_replies_match_committed_golden(name):
+    from golden.make_golden import CONFIGS as GC
+    from test_golden import check_replies_golden
+    with open(os.path.join(GOLDEN, "replies.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    p = pipe_for(GC[name]())
+    check_replies_golden(p.run_scored, p.run_merged, p.triage_texts, name, g)
+
+
 @pytest.mark.parametrize("name,n", [("c1", 4000), ("c2", 6000), ("c3", 3000), ("c4", 3000), ("c5", 1500)])
 def test_benchmark_corpora(name, n):
     from imagecaptioner_amd.corpus import make_corpus
