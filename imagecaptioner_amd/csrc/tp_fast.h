@@ -6,8 +6,9 @@
 // It takes the COMMON shape of a file and hands anything else to the general one-thread-per-file kernel
 // (tp_pipeline.h) by returning false (whatever it wrote by then is overwritten by that kernel):
 //   * a line of at most FAST_LINE_MAX bytes (LONG_LINE_MAX in the long-file stage) without "positive:" / "negative:" and
-//     without '`' (so no POSITIVE:/NEGATIVE:/code-fence handling, Program.cs:592-595) and without a carriage return inside
-//     the trimmed text (line feeds there are the blanks they become, Program.cs:595);
+//     without '`' (so no POSITIVE:/NEGATIVE:/code-fence handling, Program.cs:592-595) and without a carriage return of its
+//     own inside the trimmed text (line feeds there are the blanks they become, Program.cs:595; "\r\n" pairs there are taken
+//     out by the stages behind the first, Program.cs:591);
 //   * at most FAST_TOK_MAX tokens, every kept token an interned string;
 //   * no two different candidates that NormalizeTag maps to one selected tag (their AddOne order would matter);
 //   * lists that fit their LDS capacities.
@@ -151,7 +152,7 @@ TP_HD uint8_t byte_class(uint32_t c) {
     if (c == '_') k |= CL_US;
     if (c >= 0x80) k |= CL_SPEC | CL_US;                                // both at once: a byte of a character outside ASCII
     if (c == ':') k |= CL_COLON;
-    if (c == '`' || c == '\r') k |= CL_BAD;                              // a code fence, a carriage return ("\r\n" shrinks to one character, Program.cs:591): not for this kernel
+    if (c == '`' || c == '\r') k |= CL_BAD;                              // a code fence; a carriage return ("\r\n" shrinks to one character, Program.cs:591): scan_line takes those out first
     if (c == 's' || c == 'S') k |= CL_S;
     if (c == 'o' || c == 'O') k |= CL_O;
     return (uint8_t)k;
@@ -455,7 +456,8 @@ struct Scan { const uint8_t* s; uint32_t a, b, ncomma; bool rejected; };
 
 // S1 + S2: the line goes to LDS, is trimmed and split at its commas (NormalizeRawTagLine, LooksBad, SplitTags:
 // Program.cs:589-596, 1141-1147, 1181-1187).  Returns false when the file needs the general kernel.
-template <class W, class LDS>
+// CRLF: take "\r\n" pairs inside the text out of the LDS copy and scan again (the first wave stage leaves such files to the second).
+template <bool CRLF, class W, class LDS>
 TP_HD __attribute__((always_inline)) bool scan_line(W& w, LDS& L, const uint8_t* cls, const uint8_t* text, uint32_t len, Scan& sc) {
     const uint32_t lane = w.lane();
     if (len > LDS::LINE_CAP) return false;
@@ -498,6 +500,8 @@ TP_HD __attribute__((always_inline)) bool scan_line(W& w, LDS& L, const uint8_t*
     uint32_t ncomma = 0;
     bool refusal = false, keyword = false;
     uint64_t any_blank = 0, any_bad = 0, any_high = 0;
+    auto scan_pass = [&]() __attribute__((always_inline)) {
+    ncomma = 0; refusal = false; keyword = false; any_blank = 0; any_bad = 0; any_high = 0;
     for (uint32_t base = a; base < b; base += 256) {
         const uint32_t p = base + 4 * lane;
         const uint32_t pp = p < b ? p : b;
@@ -548,7 +552,43 @@ TP_HD __attribute__((always_inline)) bool scan_line(W& w, LDS& L, const uint8_t*
             if (w.ballot(hit)) refusal = true;
         }
     }
+    };
+    scan_pass();
+    if constexpr (!CRLF) { if (any_bad) return false; }
+    else if (any_bad) {
+    // "\r\n" inside the text: the reference starts with raw.Replace("\r\n", "\n") (Program.cs:591).  Those carriage returns are
+    // taken out of the LDS copy in place and the scan runs once more; a carriage return of its own, or a '`', ends it here.
+    {
+        uint8_t* sw = const_cast<uint8_t*>(s);
+        uint32_t written = a;
+        bool other = false;
+        for (uint32_t base = a; base < b; base += 256) {
+            const uint32_t p = base + 4 * lane;
+            const uint32_t pp = p < b ? p : b;
+            const uint32_t x = ld32u(s + pp), nx = s[pp + 4];
+            uint32_t keep = 0, cnt = 0;
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t c = (x >> (8 * j)) & 0xFFu, c1 = j < 3 ? (x >> (8 * j + 8)) & 0xFFu : nx;
+                const bool in = p + j < b;
+                const bool gone = in && c == '\r' && c1 == '\n' && p + j + 1 < b;
+                if (in && !gone && (cls[c] & CL_BAD)) other = true;
+                if (in && !gone) { keep |= 1u << j; ++cnt; }
+            }
+            const uint32_t incl = w.scan_incl(cnt);
+            w.sync();                                              // every lane holds its bytes before any is overwritten
+            uint32_t d = written + incl - cnt;
+            for (uint32_t j = 0; j < 4; ++j) if (keep & (1u << j)) sw[d++] = (uint8_t)(x >> (8 * j));
+            written += w.bcast(incl, 63);
+            w.sync();
+        }
+        if (w.ballot(other)) return false;
+        b = written;
+        if (lane < LDS::TOK_CAP / 32) { L.tspec[lane] = 0; L.thigh[lane] = 0; }
+        w.sync();
+    }
+    scan_pass();
     if (any_bad) return false;
+    }
     if (any_high && ncomma < 2) return false;   // LooksBad measures such a line in UTF-16 units (Program.cs:1145)
     if (any_blank && !refusal) {
         // The other entries (without the two that hold ':') all have a blank that follows a letter; such a blank was seen.
@@ -998,7 +1038,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         if (!front->run(w, t, L, nblk, n, act, h1, r1, seed_in, strong_in)) return false;
     } else {
     Scan sc;
-    if (!scan_line(w, L, cls, text, len, sc)) return false;
+    if (!scan_line<NT == 2>(w, L, cls, text, len, sc)) return false;
     const uint8_t* s = sc.s;
     const uint32_t a = sc.a, b = sc.b, ncomma = sc.ncomma;
     rejected = sc.rejected;
@@ -1548,7 +1588,7 @@ TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, c
                      uint32_t* fired, uint16_t* facet_choice, bool triage = false) {
     const uint32_t lane = w.lane();
     Scan sc;
-    if (!scan_line(w, L, cls, text, len, sc)) return false;
+    if (!scan_line<true>(w, L, cls, text, len, sc)) return false;
     const uint8_t* s = sc.s;
     const uint32_t T = sc.ncomma + 1;
     if (T > LONG_TOK_MAX) return false;

@@ -204,14 +204,17 @@ def test_common_spellings():
 
 
 def test_multi_line_texts():
-    """Line feeds inside the text are the blanks they become (Program.cs:595); carriage returns inside go to the general kernel."""
+    """Line feeds inside the text are the blanks they become (Program.cs:595), "\r\n" pairs shrink to them first (Program.cs:591)."""
     from test_pipeline_logic_cpu import multi_line_texts
     lines, cfg = multi_line_texts(4000, seed=6)
     p, o = pipe_for(cfg), Oracle(cfg)
     got, want = p.run_texts(lines), o.run_texts(lines, threads=8)
     assert_same_results(got, want, p.histogram_dict(got.histogram), "multi-line")
-    assert p.last_timing()["general_files"] < 800
+    assert p.last_timing()["general_files"] == 0
     assert np.array_equal(p.triage_texts(lines), o.triage_texts(lines))
+    odd = ["a\rb, c, d, e", "1girl,\r\nsmile,\r\n\r\ndress", "1girl, sm\r\nile, dress", "i\r\ncan't do that, x, y", "1girl\r, smile, dress", "tag`x, a\r\nb, c"]
+    got, want = p.run_texts(odd), o.run_texts(odd)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "carriage returns")
 
 
 def test_known_non_ascii_tags_pass_through_the_wave_kernel():

@@ -56,4 +56,4 @@ def test_triage_multi_line_texts():
     want = o.triage_texts(lines)
     got, n_general = s.triage_texts(lines)
     assert list(got) == list(want)
-    assert n_general < 60 and 0 < want.sum() < len(lines)
+    assert n_general == 0 and 0 < want.sum() < len(lines)
