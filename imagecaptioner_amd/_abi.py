@@ -118,6 +118,10 @@ class tp_result(C.Structure):
     ]
 
 
+class tp_audit(C.Structure):
+    _fields_ = [("text", C.POINTER(C.c_uint8)), ("offsets", C.POINTER(C.c_uint64))]
+
+
 class tp_device_io(C.Structure):
     _fields_ = [
         ("arena", C.c_void_p),

@@ -62,6 +62,8 @@ struct HostResult {
     std::vector<tp_verdict> verdicts;
     std::vector<uint32_t> fired;
     std::vector<uint16_t> facet_choice;
+    std::vector<uint8_t> audit_text;        // audit mode only
+    std::vector<uint64_t> audit_offsets;
 };
 
 }  // namespace
@@ -74,6 +76,8 @@ struct tp_ctx {
     DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list1, slow_list2, scalars, workspace;
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
+    DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets;
+    bool audit = false;              // tp_set_audit: the host-pointer runs also return the audit row's tag lists
     std::vector<hipEvent_t> events;
     tp_timing timing{};
     size_t ws_budget = (size_t)64 << 30;
@@ -84,7 +88,8 @@ struct tp_ctx {
         (void)hipSetDevice(device);
         for (void* p : table_mem) (void)hipFree(p);
         for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
-                          &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets})
+                          &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
+                          &audit_cnt, &audit_len, &out_audit, &out_audit_offsets})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
@@ -103,6 +108,7 @@ struct RunIo {
     uint8_t* captions; uint64_t caption_capacity; bool grow_captions;   // grow_captions: captions live in ctx->out_captions and may be reallocated
     uint64_t* caption_offsets; tp_verdict* verdicts; uint64_t* histogram; tp_counters* counters; uint32_t* fired; uint16_t* facet_choice;
     hipStream_t stream; int mode;
+    bool audit; uint64_t* audit_offsets;    // audit: every file takes the general kernel in mode 3; the lists' text goes to ctx->out_audit
 };
 
 // One range of files [f0, f1): wave-per-file kernel, general kernel for what it declined, caption offsets, emit.
@@ -111,6 +117,8 @@ struct RunState {
     uint64_t total = 0;          // caption bytes so far (host copy of the device running total)
     int chunk = 0;               // parity of the device running-total slot
     bool over_capacity = false;
+    uint64_t audit_total = 0;    // bytes of audit text so far
+    int audit_chunk = 0;
     size_t ev = 2;               // next free event
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fast_ev, pipe_ev, emit_ev;
 };
@@ -121,8 +129,8 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     uint64_t* d_total = c->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
     uint32_t* d_status = (uint32_t*)(d_total + 2);
     uint32_t* d_slow_count = d_status + 1;
-    const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast;   // tagger replies: the wave kernel's scored front
-    const bool use_fast = use_scored || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast);
+    const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast && !io.audit;   // tagger replies: the wave kernel's scored front
+    const bool use_fast = use_scored || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast && !io.audit);
 
     c->cap_len.need(n * 4); c->n_final.need(n * 4); c->slot_of.need(n * 4);
     uint32_t* cap_len = c->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
@@ -205,7 +213,11 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         pa.wave_T = c->wave_T.as<uint32_t>(); pa.wave_LB = c->wave_LB.as<uint32_t>(); pa.wave_off = c->wave_off.as<uint64_t>();
         pa.workspace = c->workspace.as<uint8_t>();
         pa.verdicts = io.verdicts; pa.n_final = n_final; pa.cap_len = cap_len; pa.slot_of = slot_of;
-        pa.fired = io.fired; pa.facet_choice = io.facet_choice; pa.mode = io.mode;
+        pa.fired = io.fired; pa.facet_choice = io.facet_choice; pa.mode = io.audit ? 3 : io.mode;
+        if (io.audit) {
+            c->audit_cnt.need(n * AUDIT_COLS * 4); c->audit_len.need(n * AUDIT_COLS * 4);
+            pa.audit_cnt = c->audit_cnt.as<uint32_t>(); pa.audit_len = c->audit_len.as<uint32_t>();
+        }
         hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
         HIP_OK(hipEventRecord(p0, s));
         HIP_OK(launch_pipeline(c->dt, pa, s));
@@ -239,10 +251,26 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     HIP_OK(launch_emit(c->dt, ea, s));
     HIP_OK(hipEventRecord(q1, s));
     st.emit_ev.emplace_back(q0, q1);
+    if (io.audit && n_slow) {
+        // offsets of the range's audit columns, continuing the running total, then their text out of the workspaces
+        uint64_t* d_atotal = d_total + 4;
+        c->tile_sums.need(scan_tiles_needed(n * AUDIT_COLS) * 8);
+        HIP_OK(launch_scan_u32(c->audit_len.as<uint32_t>(), n * AUDIT_COLS, io.audit_offsets + f0 * AUDIT_COLS, c->tile_sums.as<uint64_t>(),
+                               d_atotal + (st.audit_chunk & 1), d_atotal + ((st.audit_chunk + 1) & 1), s));
+        HIP_OK(hipMemcpyAsync(&st.audit_total, d_atotal + ((st.audit_chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        ++st.audit_chunk;
+        c->out_audit.need(std::max<uint64_t>(st.audit_total, 16), true, s);
+        AuditArgs aa{};
+        aa.file0 = f0; aa.n_items = n_slow; aa.item_list = item_list; aa.slot_of = slot_of;
+        aa.wave_T = c->wave_T.as<uint32_t>(); aa.wave_LB = c->wave_LB.as<uint32_t>(); aa.wave_off = c->wave_off.as<uint64_t>(); aa.workspace = c->workspace.as<uint8_t>();
+        aa.audit_cnt = c->audit_cnt.as<uint32_t>(); aa.offsets = io.audit_offsets; aa.text = c->out_audit.as<uint8_t>();
+        HIP_OK(launch_audit(c->dt, aa, s));
+    }
     return TP_OK;
 }
 
-int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes) {
+int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_bytes = nullptr) {
     HIP_OK(hipSetDevice(c->device));
     hipStream_t s = io.stream;
     const uint64_t n = io.n_files;
@@ -251,6 +279,8 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes) {
     c->scalars.need(64);
     HIP_OK(hipMemsetAsync(c->scalars.p, 0, 64, s));
     if (n == 0) {
+        if (io.audit) HIP_OK(hipMemsetAsync(io.audit_offsets, 0, 8, s));
+        if (audit_bytes) *audit_bytes = 0;
         HIP_OK(hipMemsetAsync(io.caption_offsets, 0, 8, s));
         HIP_OK(hipStreamSynchronize(s));
         if (caption_bytes) *caption_bytes = 0;
@@ -278,6 +308,7 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes) {
     c->timing.other_ms = c->timing.total_ms - c->timing.select_ms - c->timing.general_ms - c->timing.emit_ms;
     c->timing.general_files = c->last_slow;
     if (caption_bytes) *caption_bytes = st.total;
+    if (audit_bytes) *audit_bytes = st.audit_total;
     if (st.over_capacity) return fail(TP_E_CAPACITY, "caption buffer too small: " + std::to_string(st.total) + " bytes needed");
     return TP_OK;
 }
@@ -343,8 +374,13 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     io.histogram = c->out_hist.as<uint64_t>(); io.counters = c->out_counters.as<tp_counters>();
     io.fired = c->out_fired.as<uint32_t>(); io.facet_choice = c->out_facets.as<uint16_t>();
     io.stream = s; io.mode = 0;
-    uint64_t cap_bytes = 0;
-    int rc = run_device(c, io, &cap_bytes);
+    io.audit = c->audit;
+    if (io.audit) {
+        c->out_audit_offsets.need((n_files * AUDIT_COLS + 1) * 8);
+        io.audit_offsets = c->out_audit_offsets.as<uint64_t>();
+    }
+    uint64_t cap_bytes = 0, audit_bytes = 0;
+    int rc = run_device(c, io, &cap_bytes, &audit_bytes);
     if (rc != TP_OK) return rc;
 
     std::unique_ptr<HostResult> r(new HostResult());
@@ -362,6 +398,12 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     HIP_OK(hipMemcpy(&ctr, c->out_counters.p, sizeof ctr, hipMemcpyDeviceToHost));
     if (n_files * t.fired_words) HIP_OK(hipMemcpy(r->fired.data(), c->out_fired.p, n_files * t.fired_words * 4, hipMemcpyDeviceToHost));
     if (n_files * t.n_facets) HIP_OK(hipMemcpy(r->facet_choice.data(), c->out_facets.p, n_files * t.n_facets * 2, hipMemcpyDeviceToHost));
+    if (io.audit) {
+        r->audit_text.resize(std::max<uint64_t>(audit_bytes, 1));
+        r->audit_offsets.resize(n_files * AUDIT_COLS + 1);
+        if (audit_bytes) HIP_OK(hipMemcpy(r->audit_text.data(), c->out_audit.p, audit_bytes, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(r->audit_offsets.data(), c->out_audit_offsets.p, (n_files * AUDIT_COLS + 1) * 8, hipMemcpyDeviceToHost));
+    }
     out->n_files = n_files;
     out->captions = r->captions.data();
     out->caption_offsets = r->caption_offsets.data();
@@ -714,6 +756,106 @@ int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t
             std::string s = "safe_mode:" + h.safe_tags[verdicts[i].safe_hit] + nl;
             std::memcpy(reject + reject_offsets[i], s.data(), s.size());
         }
+        return (int)TP_OK;
+    });
+}
+
+int tp_set_audit(tp_ctx* ctx, int on) {
+    if (!ctx) return fail(TP_E_INVALID_ARG, "null argument");
+    ctx->audit = on != 0;
+    return TP_OK;
+}
+
+int tp_get_audit(const tp_result* res, tp_audit* out) {
+    if (!res || !out) return fail(TP_E_INVALID_ARG, "null argument");
+    const HostResult* r = (const HostResult*)res->opaque;
+    if (!r || r->audit_offsets.empty()) return fail(TP_E_INVALID_ARG, "the result was not produced with tp_set_audit(ctx, 1)");
+    out->text = r->audit_text.data();
+    out->offsets = r->audit_offsets.data();
+    return TP_OK;
+}
+
+const char* tp_audit_header(void) {   // Program.cs:964
+    return "filename,final_tags,evidence_tags,fired_rules,dropped_tags_with_reason,reject_reason,used_vocab_file,used_profile,coverage_stop_reason,coverage_trace";
+}
+
+int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t* names, const uint64_t* name_offsets, const char* vocab_file,
+                         const char* used_profile, uint8_t* out, uint64_t capacity, uint64_t* out_offsets, uint64_t* needed) {
+    if (!ctx || !res || !out_offsets || !needed || !name_offsets || !used_profile) return fail(TP_E_INVALID_ARG, "null argument");
+    const HostResult* r = (const HostResult*)res->opaque;
+    if (!r || r->audit_offsets.empty()) return fail(TP_E_INVALID_ARG, "the result was not produced with tp_set_audit(ctx, 1)");
+    const uint64_t n_files = res->n_files;
+    if (n_files && name_offsets[n_files] && !names) return fail(TP_E_INVALID_ARG, "null argument");
+    const HostTables& h = ctx->ht;
+    const uint32_t n_rules = ctx->dt.n_rules, n_facets = ctx->dt.n_facets, fw = ctx->dt.fired_words;
+    const std::string nl((const char*)ctx->dt.newline, ctx->dt.newline_len);
+    return guarded([&]() {
+        std::string rows, row, field;
+        auto csv = [&](const char* p, size_t n) {                // Csv(), Program.cs:976-981: quotes doubled, always quoted
+            row.push_back('"');
+            for (size_t k = 0; k < n; ++k) { if (p[k] == '"') row.push_back('"'); row.push_back(p[k]); }
+            row.push_back('"');
+        };
+        auto csv_s = [&](const std::string& x) { csv(x.data(), x.size()); };
+        static const char* const kCats[6] = {"identity", "hair", "eyes", "outfit", "pose_action", "background_scene"};   // Program.cs:1067-1074
+        for (uint64_t i = 0; i < n_files; ++i) {
+            out_offsets[i] = rows.size();
+            const tp_verdict& v = res->verdicts[i];
+            if (v.flags & TP_F_UNSUPPORTED) continue;             // the device code did not process the file: no row
+            row.clear();
+            csv((const char*)names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i]));
+            const uint64_t* ao = r->audit_offsets.data() + i * AUDIT_COLS;
+            row.push_back(','); csv((const char*)r->audit_text.data() + ao[AUDIT_KEPT], (size_t)(ao[AUDIT_KEPT + 1] - ao[AUDIT_KEPT]));
+            row.push_back(','); csv((const char*)r->audit_text.data() + ao[AUDIT_EVIDENCE], (size_t)(ao[AUDIT_EVIDENCE + 1] - ao[AUDIT_EVIDENCE]));
+            // firedRules, Program.cs:741, 748, 764, 772
+            field.clear();
+            auto put = [&](const std::string& x) { if (!field.empty()) field.push_back(';'); field += x; };
+            const uint32_t* fb = r->fired.data() + i * fw;
+            auto bit = [&](uint32_t b) { return (fb[b >> 5] >> (b & 31)) & 1u; };
+            for (uint32_t q = 0; q < n_rules; ++q) {
+                if (!bit(q)) continue;
+                put("action:" + h.rule_names[q]);
+                for (uint32_t sb = h.rules[q].sub_off; sb < h.rules[q].sub_off + h.rules[q].sub_cnt; ++sb)
+                    if (bit(n_rules + sb)) put("subtype:" + h.sub_names[sb]);
+            }
+            for (uint32_t f = 0; f < n_facets; ++f) {
+                uint16_t c = r->facet_choice[i * n_facets + f];
+                const std::string& selected = c == 0xFFFF ? h.facet_defaults[f] : h.facet_rule_tags[f].at(c);
+                if (c != 0xFFFF) put("facet:" + h.facet_names[f] + ":" + selected);
+                if (selected == h.facet_defaults[f]) put("facet:" + h.facet_names[f] + ":" + h.facet_defaults[f] + ":default");
+            }
+            row.push_back(','); csv_s(field);
+            row.push_back(','); csv((const char*)r->audit_text.data() + ao[AUDIT_DROPPED], (size_t)(ao[AUDIT_DROPPED + 1] - ao[AUDIT_DROPPED]));
+            field.clear();                                        // rejectReason ?? "", Program.cs:329, 944
+            if (v.flags & TP_F_SAFE_REJECT) {
+                if (v.safe_hit < 0 || (size_t)v.safe_hit >= h.safe_tags.size()) return fail(TP_E_INVALID_ARG, "verdict with a safe-mode hit out of range");
+                field = "safe_mode:" + h.safe_tags[v.safe_hit];
+            }
+            row.push_back(','); csv_s(field);
+            row.push_back(','); csv_s(vocab_file ? std::string(vocab_file) : std::string());
+            row.push_back(','); csv_s(std::string(used_profile));
+            // coverageStopReason and the one coverageTrace entry of a run without the OpenAI passes (Program.cs:226-228, 246-248, 292-294)
+            std::string missing, required, details;
+            for (int k = 0; k < 6; ++k) {
+                const bool ok = (v.coverage >> k) & 1u;
+                if (!ok) {
+                    if (!missing.empty()) missing.push_back('|');
+                    missing += kCats[k];
+                    if (k < 5) { if (!required.empty()) required.push_back('|'); required += kCats[k]; }
+                }
+                if (k) details.push_back('|');
+                details += kCats[k]; details += ok ? "=ok" : "=missing";
+            }
+            row.push_back(','); csv_s(missing.empty() ? std::string("coverage_satisfied") : std::string("openai_disabled_or_missing_api_key"));
+            row.push_back(','); csv_s("pass0_joy missing=" + missing + " required_missing=" + required + " details=" + details + " tags=" + std::to_string(v.n_selected));
+            rows += row;
+            rows += nl;
+        }
+        out_offsets[n_files] = rows.size();
+        *needed = rows.size();
+        if (rows.empty()) return (int)TP_OK;
+        if (!out || capacity < rows.size()) return fail(TP_E_CAPACITY, "output buffer too small");
+        std::memcpy(out, rows.data(), rows.size());
         return (int)TP_OK;
     });
 }

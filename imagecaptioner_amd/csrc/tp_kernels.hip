@@ -358,6 +358,47 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
     a.n_final[f] = out.n_final;
     a.cap_len[f] = out.caption_len;
     a.slot_of[f] = (uint32_t)th;
+    if (a.audit_cnt) {
+        for (int c = 0; c < AUDIT_COLS; ++c) {
+            a.audit_cnt[(f - a.file0) * AUDIT_COLS + c] = out.audit_cnt[c];
+            a.audit_len[(f - a.file0) * AUDIT_COLS + c] = out.audit_len[c];
+        }
+    }
+}
+
+// The audit row's three tag lists as text: one wavefront per file, one entry per lane and step.  Entries are joined with
+// ";" (Program.cs:966); dropped tags carry their reason (Program.cs:630-631).
+__global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave_global; i < a.n_items; i += n_waves) {
+        const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
+        const uint32_t slot = a.slot_of[f];
+        const uint64_t w = slot >> 6;
+        WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
+        FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63);
+        for (int c = 0; c < AUDIT_COLS; ++c) {
+            const uint32_t cnt = a.audit_cnt[(f - a.file0) * AUDIT_COLS + c];
+            uint8_t* out = a.text + a.offsets[f * AUDIT_COLS + c];
+            uint32_t running = 0;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const bool live = k < cnt;
+                AuditElem e{nullptr, 0, nullptr};
+                if (live) e = audit_elem(t, ws, c, k);
+                const uint32_t seg = live ? e.len + (e.reason ? AUDIT_REASON_LEN : 0u) + (k ? 1u : 0u) : 0u;
+                const uint32_t incl = wave_scan_incl(seg);
+                if (live) {
+                    uint8_t* dst = out + running + (incl - seg);
+                    if (k) *dst++ = ';';
+                    for (uint32_t b = 0; b < e.len; ++b) dst[b] = e.p[b];
+                    if (e.reason) for (uint32_t b = 0; b < AUDIT_REASON_LEN; ++b) dst[e.len + b] = (uint8_t)e.reason[b];
+                }
+                running += __shfl(incl, 63);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -623,6 +664,13 @@ hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_
     const uint64_t waves = (a.n_items + a.fpw - 1) / a.fpw;
     unsigned blocks = (unsigned)((waves * 64 + 255) / 256);
     hipLaunchKernelGGL(k_pipeline, dim3(blocks), dim3(256), 0, s, t, a);
+    return hipGetLastError();
+}
+hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s) {
+    if (a.n_items == 0) return hipSuccess;
+    uint64_t want = (a.n_items + 3) / 4;                    // four wavefronts per block
+    unsigned blocks = (unsigned)(want < 256 * 8 ? want : 256 * 8);
+    hipLaunchKernelGGL(k_emit_audit, dim3(blocks), dim3(256), 0, s, t, a);
     return hipGetLastError();
 }
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {

@@ -61,6 +61,24 @@ struct PipelineArgs {
     uint32_t* fired;
     uint16_t* facet_choice;
     int mode;
+    uint32_t* audit_cnt;          // mode 3: AUDIT_COLS entries per file, indexed by file - file0: entries and bytes of the audit row's lists
+    uint32_t* audit_len;
+};
+
+// Text of the audit row's tag lists (keptTags, evidenceTags, DroppedTagsWithReason joined with ";", Program.cs:966) for the
+// files of one general-kernel launch, out of their workspaces.
+struct AuditArgs {
+    uint64_t file0;
+    uint64_t n_items;
+    const uint32_t* item_list;    // may be null
+    const uint32_t* slot_of;      // indexed by file
+    const uint32_t* wave_T;
+    const uint32_t* wave_LB;
+    const uint64_t* wave_off;
+    uint8_t* workspace;
+    const uint32_t* audit_cnt;    // indexed by (file - file0) * AUDIT_COLS + column
+    const uint64_t* offsets;      // indexed by file * AUDIT_COLS + column; the column's text is text[offsets[k] .. offsets[k + 1])
+    uint8_t* text;
 };
 
 struct EmitArgs {
@@ -88,6 +106,7 @@ hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s);
 uint64_t scan_tiles_needed(uint64_t n);
 hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_t s);
+hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s);
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s);
 uint32_t fast_fin_stride();
 

@@ -101,7 +101,16 @@ struct FileOut {
     tp_verdict verdict;
     uint32_t n_final;      // handles left in ws.fin: the caption's tags, in order
     uint32_t caption_len;  // bytes of the caption line including the newline
+    // mode 3 only: the three tag lists of the audit row (AppendAudit, Program.cs:334, 966), entries and bytes when joined with ";"
+    uint32_t audit_cnt[3];
+    uint32_t audit_len[3];
 };
+
+// The tag-list columns of the audit row (Program.cs:966): keptTags = finalTags as they stand after EnsureRequiredFacets
+// (Program.cs:307), evidenceTags after ExpandImpliedTags (Program.cs:302), finalSelection.DroppedTagsWithReason (Program.cs:682).
+// After process_file in mode 3 they sit in the file's workspace: ws.snap, ws.ev and ws.dl.
+constexpr int AUDIT_KEPT = 0, AUDIT_EVIDENCE = 1, AUDIT_DROPPED = 2, AUDIT_COLS = 3;
+constexpr uint32_t AUDIT_REASON_LEN = 12;   // ":invalid_tag" and ":policy_drop" have the same length (Program.cs:630-631)
 
 // ================================================================================================
 // string helpers
@@ -406,16 +415,29 @@ TP_HD bool has_refusal_phrase(const uint8_t* s, uint32_t a, uint32_t b) {
     return false;
 }
 
+// Entry k of an audit column: where its bytes are, and for the dropped column the reason the reference appends.
+struct AuditElem { const uint8_t* p; uint32_t len; const char* reason; };
+TP_HD AuditElem audit_elem(const DevTables& t, const FileWs& ws, int col, uint32_t k) {
+    const H h = col == AUDIT_KEPT ? ws.snap[k] : col == AUDIT_EVIDENCE ? ws.ev[k] : ws.dl[k];
+    AuditElem e;
+    if (h_is_dyn(h)) { e.p = ws.norm + h_off(h); e.len = h_len(h); }
+    else { e.p = str_ptr(t, h_id(h)); e.len = str_len(t, h_id(h)); }
+    e.reason = col != AUDIT_DROPPED ? nullptr : !(hflags(t, h) & FL_VALID) ? ":invalid_tag" : ":policy_drop";   // Program.cs:630-631
+    return e;
+}
+
 // ================================================================================================
 // The pipeline.  mode 0: whole span.  mode 2: existing-caption triage (line ingest only; stops after the candidates).
 // mode 1: stop after SelectTags and leave its result in ws.fin
 // (used once at load time to evaluate the minimal fallback line, Program.cs:298).
+// mode 3: whole span, and the lists of the audit row are kept and sized (see FileOut).
 // ================================================================================================
 TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOut& out, uint32_t* fired, uint16_t* facet_choice, int mode) {
     tp_verdict& v = out.verdict;
     v.coverage = 0; v.flags = 0; v.n_tags = 0; v.n_candidates = 0; v.n_selected = 0; v.safe_hit = -1; v.n_evidence = 0; v.n_unknown = 0; v.n_dropped = 0;
     out.n_final = 0;
     out.caption_len = 0;
+    for (int c = 0; c < AUDIT_COLS; ++c) { out.audit_cnt[c] = 0; out.audit_len[c] = 0; }
     if (fired) for (uint32_t w = 0; w < t.fired_words; ++w) fired[w] = 0;
     if (facet_choice) for (uint32_t f = 0; f < t.n_facets; ++f) facet_choice[f] = 0xFFFF;
 
@@ -651,7 +673,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         uint32_t sr = ws.src[i];
         uint32_t f2 = hflags(t, h2);
         if (f2 & FL_BLANK) continue;
-        if (!(sc < 0.28) && mode == 0) {                          // evidence keeps invalid and dropped tags too
+        if (!(sc < 0.28) && (mode == 0 || mode == 3)) {                          // evidence keeps invalid and dropped tags too
             if (!lfind(ws, ws.ev, ne, h2)) {
                 if (ne >= ws.cap_e) overflow = true; else ws.ev[ne++] = h2;
             }
@@ -855,6 +877,17 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         if (t.safe_mode && safe >= 0) { flags |= TP_F_SAFE_REJECT; v.safe_hit = (int16_t)safe; }
     }
 
+    // ---------------- the audit row's lists (Program.cs:334, 966) ----------------
+    // keptTags is the final list as it stands here, before FormatCaptionSingleLine normalises it again: a copy goes to
+    // ws.snap, which the closures no longer need (cap_snap >= cap_f >= nf).
+    uint32_t akept = 0, alen[3] = {0, 0, 0};
+    if (mode == 3) {
+        akept = nf;
+        for (uint32_t i = 0; i < nf; ++i) { H h = ws.fin[i]; ws.snap[i] = h; alen[AUDIT_KEPT] += hbytes(t, h) + (i ? 1u : 0u); }
+        for (uint32_t i = 0; i < ne; ++i) alen[AUDIT_EVIDENCE] += hbytes(t, ws.ev[i]) + (i ? 1u : 0u);
+        for (uint32_t i = 0; i < ndl; ++i) alen[AUDIT_DROPPED] += hbytes(t, ws.dl[i]) + AUDIT_REASON_LEN + (i ? 1u : 0u);
+    }
+
     // ---------------- FormatCaptionSingleLine (Program.cs:971-974) and GetUnknownTags (Program.cs:817-824) ----------------
     // Both take Select(NormalizeTag).Where(non-blank).Distinct() of the final list.
     uint32_t nc = 0, bytes = 0, unknown = 0;
@@ -875,6 +908,10 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     v.n_tags = (uint16_t)(nc > 0xFFFF ? 0xFFFF : nc);
     v.n_unknown = (uint16_t)(unknown > 0xFFFF ? 0xFFFF : unknown);
     out.n_final = nc;
+    if (mode == 3) {
+        out.audit_cnt[AUDIT_KEPT] = akept; out.audit_cnt[AUDIT_EVIDENCE] = ne; out.audit_cnt[AUDIT_DROPPED] = ndl;
+        for (int c = 0; c < AUDIT_COLS; ++c) out.audit_len[c] = alen[c];
+    }
     out.caption_len = bytes + (nc ? 2 * (nc - 1) : 0) + t.newline_len;    // string.Join(", ", …) + Environment.NewLine, Program.cs:316-317
 }
 

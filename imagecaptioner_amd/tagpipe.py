@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from ._abi import (TP_E_CAPACITY, TP_OK, VERDICT_DTYPE, Config, tp_config, tp_counters, tp_device_io, tp_result, tp_table_info,
+from ._abi import (TP_E_CAPACITY, TP_OK, VERDICT_DTYPE, Config, tp_audit, tp_config, tp_counters, tp_device_io, tp_result, tp_table_info,
                    tp_timing)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,6 +20,7 @@ EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_format_top_tags", "tp_get_last_timing",
     "tp_triage_lines", "tp_run_merged", "tp_format_fired_rules", "tp_needtag_text", "tp_format_side_files",
+    "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows",
 )
 
 
@@ -60,6 +61,11 @@ def load_library():
     L.tp_needtag_text.restype = C.c_char_p
     L.tp_format_side_files.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     L.tp_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.tp_set_audit.argtypes = [C.c_void_p, C.c_int]
+    L.tp_get_audit.argtypes = [C.POINTER(tp_result), C.POINTER(tp_audit)]
+    L.tp_audit_header.restype = C.c_char_p
+    L.tp_format_audit_rows.argtypes = [C.c_void_p, C.POINTER(tp_result), C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64,
+                                       C.c_void_p, C.POINTER(C.c_uint64)]
     _LIB = L
     return L
 
@@ -76,6 +82,8 @@ class BatchResult:
         self.histogram_other = histogram_other
         self.fired = fired                      # uint32[n, fired_words]
         self.facet_choice = facet_choice        # uint16[n, n_facets]
+        self.audit_lists = None                 # audit runs: per file (final_tags, evidence_tags, dropped_tags_with_reason) as bytes, ';'-joined
+        self.audit_rows = None                  # audit runs: per file the audit.csv line (bytes, newline included)
 
     @property
     def n_files(self):
@@ -203,7 +211,40 @@ class TagPipe:
                 "general_files": int(t.general_files)}
 
     # ---- host-buffer runs -----------------------------------------------------------------------
-    def _collect(self, res):
+    def audit_header(self):
+        return self._L.tp_audit_header()
+
+    def _collect_audit(self, res, audit):
+        """tp_get_audit + tp_format_audit_rows on a result of an audit run; audit = {"names": [...], "vocab_file": str or None, "used_profile": str}."""
+        n = int(res.n_files)
+        a = tp_audit()
+        self._check(self._L.tp_get_audit(C.byref(res), C.byref(a)))
+        offs = np.ctypeslib.as_array(a.offsets, shape=(3 * n + 1,)).copy()
+        text = C.string_at(a.text, int(offs[3 * n]))
+        lists = [tuple(text[int(offs[3 * i + c]):int(offs[3 * i + c + 1])] for c in range(3)) for i in range(n)]
+        names = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in audit["names"]]
+        assert len(names) == n
+        noffs = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            noffs[1:] = np.cumsum([len(b) for b in names], dtype=np.uint64)
+        narena = np.frombuffer(b"".join(names) + b"\0", dtype=np.uint8).copy()
+        vf = audit.get("vocab_file")
+        vf = None if vf is None else vf.encode("utf-8")
+        prof = audit["used_profile"].encode("utf-8")
+        roffs = np.zeros(n + 1, dtype=np.uint64)
+        need = C.c_uint64()
+        rc = self._L.tp_format_audit_rows(self._h, C.byref(res), narena.ctypes.data, noffs.ctypes.data, vf, prof, None, 0, roffs.ctypes.data, C.byref(need))
+        buf = np.zeros(max(need.value, 1), dtype=np.uint8)
+        if need.value:
+            assert rc == TP_E_CAPACITY, rc
+            self._check(self._L.tp_format_audit_rows(self._h, C.byref(res), narena.ctypes.data, noffs.ctypes.data, vf, prof, buf.ctypes.data, need.value,
+                                                     roffs.ctypes.data, C.byref(need)))
+        else:
+            self._check(rc)
+        raw = buf.tobytes()
+        return lists, [raw[int(roffs[i]):int(roffs[i + 1])] for i in range(n)]
+
+    def _collect(self, res, audit=None):
         n = int(res.n_files)
         total = int(res.caption_offsets[n]) if n else 0
         caps = np.ctypeslib.as_array(res.captions, shape=(max(total, 1),))[:total].copy()
@@ -214,24 +255,32 @@ class TagPipe:
         fired = np.ctypeslib.as_array(res.fired, shape=(max(n * fw, 1),))[:n * fw].copy().reshape(n, fw)
         fc = np.ctypeslib.as_array(res.facet_choice, shape=(max(n * nf, 1),))[:n * nf].copy().reshape(n, nf)
         out = BatchResult(caps, offs, ver, res.counters.as_dict(), hist, int(res.histogram_other), fired, fc)
+        if audit is not None:
+            out.audit_lists, out.audit_rows = self._collect_audit(res, audit)
         self._L.tp_release(self._h, C.byref(res))
         return out
 
-    def run_lines(self, arena, offsets):
-        """tp_run_lines: host arena + offsets in, host results out (uploads and downloads included)."""
+    def run_lines(self, arena, offsets, audit=None):
+        """tp_run_lines: host arena + offsets in, host results out (uploads and downloads included).
+        audit = {"names": [...], "vocab_file": str or None, "used_profile": str} switches the context to audit mode for the call
+        (tp_set_audit) and fills the result's audit_lists and audit_rows."""
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         res = tp_result()
-        self._check(self._L.tp_run_lines(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, len(offsets) - 1, C.byref(res)))
-        return self._collect(res)
+        self._check(self._L.tp_set_audit(self._h, int(audit is not None)))
+        try:
+            self._check(self._L.tp_run_lines(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, len(offsets) - 1, C.byref(res)))
+        finally:
+            self._L.tp_set_audit(self._h, 0)
+        return self._collect(res, audit)
 
-    def run_texts(self, texts):
+    def run_texts(self, texts, audit=None):
         bs = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
         offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
         if bs:
             offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
         arena = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
-        return self.run_lines(arena, offsets)
+        return self.run_lines(arena, offsets, audit=audit)
 
     def triage_lines(self, arena, offsets):
         """tp_triage_lines: which existing captions the reference would delete and redo (Program.cs:203-210).
@@ -251,19 +300,23 @@ class TagPipe:
         arena = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
         return self.triage_lines(arena, offsets)
 
-    def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
+    def run_scored(self, arena, tag_offsets, tag_begin, scores, sources, audit=None):
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
         tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
         scores = np.ascontiguousarray(scores, dtype=np.float64)
         sources = np.ascontiguousarray(sources, dtype=np.uint8)
         res = tp_result()
-        self._check(self._L.tp_run_scored(self._h, arena.ctypes.data if arena.size else None, tag_offsets.ctypes.data, tag_begin.ctypes.data,
-                                          scores.ctypes.data if scores.size else None, sources.ctypes.data if sources.size else None,
-                                          len(tag_begin) - 1, C.byref(res)))
-        return self._collect(res)
+        self._check(self._L.tp_set_audit(self._h, int(audit is not None)))
+        try:
+            self._check(self._L.tp_run_scored(self._h, arena.ctypes.data if arena.size else None, tag_offsets.ctypes.data, tag_begin.ctypes.data,
+                                              scores.ctypes.data if scores.size else None, sources.ctypes.data if sources.size else None,
+                                              len(tag_begin) - 1, C.byref(res)))
+        finally:
+            self._L.tp_set_audit(self._h, 0)
+        return self._collect(res, audit)
 
-    def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap=15):
+    def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap=15, audit=None):
         """tp_run_merged: primary and secondary tagger replies per file, merged as Program.cs:214-221 does."""
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
@@ -271,10 +324,14 @@ class TagPipe:
         secondary_begin = np.ascontiguousarray(secondary_begin, dtype=np.uint64)
         scores = np.ascontiguousarray(scores, dtype=np.float64)
         res = tp_result()
-        self._check(self._L.tp_run_merged(self._h, arena.ctypes.data if arena.size else None, tag_offsets.ctypes.data, tag_begin.ctypes.data,
-                                          secondary_begin.ctypes.data if secondary_begin.size else None, scores.ctypes.data if scores.size else None,
-                                          int(secondary_cap), len(tag_begin) - 1, C.byref(res)))
-        return self._collect(res)
+        self._check(self._L.tp_set_audit(self._h, int(audit is not None)))
+        try:
+            self._check(self._L.tp_run_merged(self._h, arena.ctypes.data if arena.size else None, tag_offsets.ctypes.data, tag_begin.ctypes.data,
+                                              secondary_begin.ctypes.data if secondary_begin.size else None, scores.ctypes.data if scores.size else None,
+                                              int(secondary_cap), len(tag_begin) - 1, C.byref(res)))
+        finally:
+            self._L.tp_set_audit(self._h, 0)
+        return self._collect(res, audit)
 
     # ---- device-resident run ---------------------------------------------------------------------
     def run_lines_device(self, io: tp_device_io):

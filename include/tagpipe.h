@@ -305,6 +305,44 @@ const char* tp_needtag_text(void);
 int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t n_files, int keep_needtag, uint8_t* needtag,
                          uint8_t* reject, uint64_t capacity, uint64_t* reject_offsets, uint64_t* needed);
 
+/*
+ * The audit row (AppendAudit, Program.cs:334, 958-969).  With tp_set_audit(ctx, 1) the host-pointer runs (tp_run_lines,
+ * tp_run_scored, tp_run_merged) also keep, per file, the three tag lists the row joins with ";" (Program.cs:966):
+ *   TP_AUDIT_KEPT      keptTags  = finalTags as they stand after EnsureRequiredFacets (Program.cs:307), i.e. before
+ *                                  FormatCaptionSingleLine normalises them again
+ *   TP_AUDIT_EVIDENCE  evidenceTags after ExpandImpliedTags (Program.cs:301-302), in insertion order
+ *   TP_AUDIT_DROPPED   finalSelection.DroppedTagsWithReason: "{tag}:invalid_tag" / "{tag}:policy_drop" (Program.cs:630-631, 682)
+ * Column c of file i is text[offsets[3 * i + c] .. offsets[3 * i + c + 1]); tp_get_audit's pointers live as long as the
+ * result.  In audit mode every file takes the thread-per-file kernel (the wave-per-file kernels do not keep these lists),
+ * so a run is slower than without it.  n_selected in the verdicts is exact in every mode; n_evidence is counted.
+ */
+#define TP_AUDIT_KEPT     0
+#define TP_AUDIT_EVIDENCE 1
+#define TP_AUDIT_DROPPED  2
+typedef struct tp_audit {
+    const uint8_t*  text;
+    const uint64_t* offsets;   /* 3 * n_files + 1 */
+} tp_audit;
+int tp_set_audit(tp_ctx* ctx, int on);
+int tp_get_audit(const tp_result* res, tp_audit* out);
+
+/* First line of __review/audit.csv, without a newline (Program.cs:964). */
+const char* tp_audit_header(void);
+
+/*
+ * The lines AppendAudit appends to __review/audit.csv, one per file in file order (Program.cs:966-967): every field through
+ * Csv() (Program.cs:976-981), joined with ",", followed by the configured newline.  names[name_offsets[i] ..
+ * name_offsets[i + 1]) is Path.GetFileName(imagePath) of file i (UTF-8); vocab_file is KnownTagDictionaryPath (NULL when no
+ * vocabulary file was found: the field is then the empty quoted string); used_profile is "none" under --no-profile, else the
+ * profile's name (Program.cs:334).  coverage_stop_reason and coverage_trace are those of a run without the OpenAI passes
+ * (Program.cs:226-228, 246-248, 292-294: one "pass0_joy ..." entry).  reject_reason spells the tag as SafeModeRejectTags
+ * does (see tp_format_side_files).  A file with TP_F_UNSUPPORTED gets no line.  File i's line is out[out_offsets[i] ..
+ * out_offsets[i + 1]); *needed receives the total size; TP_E_CAPACITY when capacity is smaller (nothing is written then).
+ * res must come from a run in audit mode.
+ */
+int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t* names, const uint64_t* name_offsets, const char* vocab_file,
+                         const char* used_profile, uint8_t* out, uint64_t capacity, uint64_t* out_offsets, uint64_t* needed);
+
 int tp_get_last_timing(const tp_ctx* ctx, tp_timing* out);
 
 #ifdef __cplusplus

@@ -56,6 +56,8 @@ def lib():
         L.orc_histogram_text.argtypes = [C.POINTER(orc_result), C.POINTER(C.c_uint64)]
         L.orc_detail_json.restype = C.c_char_p
         L.orc_detail_json.argtypes = [C.POINTER(orc_result), C.c_uint64]
+        L.orc_audit_row.restype = C.c_char_p
+        L.orc_audit_row.argtypes = [C.POINTER(orc_result), C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p]
         L.orc_normalize_tag.restype = C.c_char_p
         L.orc_normalize_tag.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int]
         L.orc_classify_tag.argtypes = [C.c_void_p, C.c_char_p]
@@ -181,7 +183,7 @@ class Oracle:
         return json.loads(self._L.orc_rule_names_json(self._h).decode())
 
     # ---- batch runs ---------------------------------------------------------------------------
-    def _collect(self, res, n, detail):
+    def _collect(self, res, n, detail, audit=None):
         total = int(res.caption_offsets[n]) if n else 0
         caps = np.ctypeslib.as_array(res.captions, shape=(max(total, 1),))[:total].copy()
         offs = np.ctypeslib.as_array(res.caption_offsets, shape=(n + 1,)).copy()
@@ -200,20 +202,25 @@ class Oracle:
         if detail:
             details = [json.loads(self._L.orc_detail_json(C.byref(res), i).decode("utf-8")) for i in range(n)]
         out = OracleResult(caps, offs, ver, res.counters.as_dict(), fired, fc, hist, details)
+        if audit is not None:
+            # audit = {"names": [...], "vocab_file": str or None, "used_profile": str}: the audit.csv lines (Program.cs:966), no newline
+            vf = audit.get("vocab_file")
+            out.audit_rows = [self._L.orc_audit_row(C.byref(res), i, audit["names"][i].encode("utf-8"), None if vf is None else vf.encode("utf-8"),
+                                                    audit["used_profile"].encode("utf-8")) for i in range(n)]
         self._L.orc_release(C.byref(res))
         return out
 
-    def run_lines(self, arena, offsets, threads=1, detail=False):
+    def run_lines(self, arena, offsets, threads=1, detail=False, audit=None):
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
         res = orc_result()
-        rc = self._L.orc_run_lines(self._h, arena.ctypes.data, offsets.ctypes.data, n, threads, int(detail), C.byref(res))
+        rc = self._L.orc_run_lines(self._h, arena.ctypes.data, offsets.ctypes.data, n, threads, int(detail or audit is not None), C.byref(res))
         if rc != 0:
             raise OracleError(self._L.orc_last_error().decode("utf-8", "replace"))
-        return self._collect(res, n, detail)
+        return self._collect(res, n, detail, audit)
 
-    def run_scored(self, arena, tag_offsets, tag_begin, scores, sources, threads=1, detail=False):
+    def run_scored(self, arena, tag_offsets, tag_begin, scores, sources, threads=1, detail=False, audit=None):
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
         tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
@@ -222,12 +229,12 @@ class Oracle:
         n = len(tag_begin) - 1
         res = orc_result()
         rc = self._L.orc_run_scored(self._h, arena.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data,
-                                    scores.ctypes.data, sources.ctypes.data, n, threads, int(detail), C.byref(res))
+                                    scores.ctypes.data, sources.ctypes.data, n, threads, int(detail or audit is not None), C.byref(res))
         if rc != 0:
             raise OracleError(self._L.orc_last_error().decode("utf-8", "replace"))
-        return self._collect(res, n, detail)
+        return self._collect(res, n, detail, audit)
 
-    def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap, threads=1, detail=False):
+    def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap, threads=1, detail=False, audit=None):
         """Two tagger replies per file, merged as Program.cs:214-221 does, then the pipeline."""
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
@@ -237,10 +244,10 @@ class Oracle:
         n = len(tag_begin) - 1
         res = orc_result()
         rc = self._L.orc_run_merged(self._h, arena.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data, secondary_begin.ctypes.data,
-                                    scores.ctypes.data, int(secondary_cap), n, threads, int(detail), C.byref(res))
+                                    scores.ctypes.data, int(secondary_cap), n, threads, int(detail or audit is not None), C.byref(res))
         if rc != 0:
             raise OracleError(self._L.orc_last_error().decode("utf-8", "replace"))
-        return self._collect(res, n, detail)
+        return self._collect(res, n, detail, audit)
 
     def run_texts(self, texts, **kw):
         arena, offsets = pack_lines(texts)

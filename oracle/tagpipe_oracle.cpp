@@ -216,6 +216,7 @@ static const int MaxStyleTagCap = 4;     // :401
 struct FileDetail {
     std::vector<S> fired, dropped, droppedMale, unknown, evidence, finalTags, covDetails, captionTags;
     S stopReason, rejectReason;
+    std::vector<S> coverageTrace;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -827,6 +828,11 @@ struct Engine {
             det->fired = fired; det->dropped = finalSelection.droppedReasons; det->droppedMale = finalSelection.droppedMale;
             det->unknown = unknown; det->evidence = evidence.items; det->finalTags = finalTags; det->covDetails = coverage.details;
             det->captionTags = ctags; det->stopReason = stop; det->rejectReason = rejectReason;
+            // coverageTrace's only entry when the OpenAI passes are off, Program.cs:228
+            auto bar = [](const std::vector<S>& v) { S o; for (size_t i = 0; i < v.size(); ++i) { if (i) o += u("|"); o += v[i]; } return o; };
+            const std::string cnt = std::to_string(finalSelection.tags.size());
+            det->coverageTrace = {u("pass0_joy missing=") + bar(coverage.missingForPrompt) + u(" required_missing=") + bar(coverage.missingRequired) +
+                                  u(" details=") + bar(coverage.details) + u(" tags=") + u(cnt.c_str())};
         }
     }
 
@@ -1437,6 +1443,33 @@ const char* orc_detail_json(orc_result* r, uint64_t i) {
                     ",\"unknown\":" + json_list(d.unknown) + ",\"coverage\":" + json_list(d.covDetails) + ",\"stop_reason\":\"" + json_escape(to8(d.stopReason)) +
                     "\",\"reject_reason\":\"" + json_escape(to8(d.rejectReason)) + "\"}";
     return b->detailText.c_str();
+}
+
+// The line AppendAudit appends to __review/audit.csv for file i (Program.cs:966), without the newline; needs detail != 0.
+// vocab_file null = KnownTagDictionaryPath null.
+static void csv_field(const std::string& s, std::string& out) {   // Csv(), Program.cs:976-981
+    out += '"';
+    for (char c : s) { if (c == '"') out += '"'; out += c; }
+    out += '"';
+}
+const char* orc_audit_row(orc_result* r, uint64_t i, const char* filename, const char* vocab_file, const char* used_profile) {
+    Batch* b = (Batch*)r->opaque;
+    if (i >= b->details.size()) return "";
+    const FileDetail& d = b->details[i];
+    auto semi = [](const std::vector<S>& v) { std::string o; for (size_t k = 0; k < v.size(); ++k) { if (k) o += ';'; o += to8(v[k]); } return o; };
+    std::string& o = b->detailText;
+    o.clear();
+    csv_field(filename, o); o += ',';
+    csv_field(semi(d.finalTags), o); o += ',';
+    csv_field(semi(d.evidence), o); o += ',';
+    csv_field(semi(d.fired), o); o += ',';
+    csv_field(semi(d.dropped), o); o += ',';
+    csv_field(to8(d.rejectReason), o); o += ',';          // rejectReason ?? ""
+    csv_field(vocab_file ? vocab_file : "", o); o += ','; // vocabFile ?? ""
+    csv_field(used_profile, o); o += ',';
+    csv_field(to8(d.stopReason), o); o += ',';
+    csv_field(semi(d.coverageTrace), o);
+    return o.c_str();
 }
 
 // Single-function probes used by the known-answer tests.

@@ -56,6 +56,9 @@ def sim_lib():
                                           C.POINTER(sim_result), C.POINTER(C.c_uint64)]
         L.sim_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(sim_result)]
         L.sim_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.sim_run_audit.restype = C.c_longlong
+        L.sim_run_audit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64,
+                                    C.c_void_p, C.c_void_p]
         _SIM = L
     return _SIM
 
@@ -179,6 +182,30 @@ class HostSim:
             raise RuntimeError(self._L.sim_last_error().decode())
         return bad, ng.value
 
+    def run_audit(self, arena, offsets, tag_begin=None, secondary_begin=None, scores=None, sources=None, secondary_cap=0):
+        """The audit row's tag lists from the general pipeline in audit mode: (lists, verdicts); lists[i] = (final_tags, evidence_tags,
+        dropped_tags_with_reason) as bytes, ';'-joined.  Line ingest unless tag_begin is given."""
+        arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ptr = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)
+        tb, sb, sc, sr = ptr(tag_begin, np.uint64), ptr(secondary_begin, np.uint64), ptr(scores, np.float64), ptr(sources, np.uint8)
+        n = (len(tb) if tb is not None else len(offsets)) - 1
+        offs3 = np.zeros(3 * n + 1, dtype=np.uint64)
+        ver = np.zeros(n, dtype=VERDICT_DTYPE)
+        cap = 1 << 20
+        while True:
+            text = np.zeros(cap, dtype=np.uint8)
+            d = lambda a: None if a is None else a.ctypes.data
+            rc = self._L.sim_run_audit(self._h, arena.ctypes.data, offsets.ctypes.data, d(tb), d(sb), d(sc), d(sr), int(secondary_cap), n, text.ctypes.data, cap,
+                                       offs3.ctypes.data, ver.ctypes.data)
+            if rc == -1:
+                cap *= 4
+                continue
+            assert rc >= 0, "audit list sizes reported by the pipeline differ from the emitted text"
+            break
+        raw = text.tobytes()
+        return [tuple(raw[int(offs3[3 * i + c]):int(offs3[3 * i + c + 1])] for c in range(3)) for i in range(n)], ver
+
     def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
         arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
         tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
@@ -192,6 +219,11 @@ class HostSim:
 
 
 # ---- comparison -------------------------------------------------------------------------------------
+def oracle_audit_lists(want):
+    """(final_tags, evidence_tags, dropped_tags_with_reason) per file, ';'-joined bytes, from an oracle result run with detail."""
+    return [tuple(";".join(d[k]).encode("utf-8") for k in ("final_tags", "evidence", "dropped")) for d in want.details]
+
+
 def assert_same_results(got, want, hist_of_got, what="", check_hist=True):
     """got: BatchResult/SimResult of the implementation under test; want: OracleResult.  Bit-exact on everything."""
     n = len(want.caption_offsets) - 1

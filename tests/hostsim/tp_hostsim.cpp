@@ -386,6 +386,48 @@ int sim_triage_lines(void* h, const uint8_t* arena_in, const uint64_t* offsets, 
     return g_err.empty() ? 0 : -1;
 }
 
+// The audit row's three tag lists (process_file mode 3 + audit_elem, i.e. what k_pipeline and k_emit_audit do on the GPU).
+// Line ingest when tag_begin is null, scored ingest otherwise (two replies to merge when secondary_begin is given).
+// offs3 has 3 n + 1 entries; returns the text size, or -1 when cap is too small (offs3 is filled either way).
+long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin, const double* scores,
+                        const uint8_t* sources, int secondary_cap, uint64_t n, uint8_t* text, uint64_t cap, uint64_t* offs3, tp_verdict* verdicts) {
+    const Sim& s = *(Sim*)h;
+    const DevTables& t = s.dt;
+    std::vector<uint8_t> all;
+    std::vector<uint32_t> fired(std::max<size_t>(t.fired_words, 1));
+    std::vector<uint16_t> facets(std::max<size_t>(t.n_facets, 1));
+    offs3[0] = 0;
+    for (uint64_t f = 0; f < n; ++f) {
+        uint32_t T, LB;
+        if (tag_begin) { T = (uint32_t)(tag_begin[f + 1] - tag_begin[f]); LB = (uint32_t)(offsets[tag_begin[f + 1]] - offsets[tag_begin[f]]); }
+        else { LB = (uint32_t)(offsets[f + 1] - offsets[f]); T = commas(arena + offsets[f], LB) + 1; }
+        WsLayout L = ws_layout(std::max(T, 1u), LB, t.final_cap, t.evidence_grow, t.lit_words);
+        std::vector<uint8_t> wsmem(L.total, 0xCD);
+        FileWs ws = ws_bind(wsmem.data(), L, (uint32_t)(f & 63));
+        FileIn in{};
+        if (tag_begin) { in.arena = arena; in.tag_offsets = offsets; in.tag_lo = tag_begin[f]; in.tag_hi = tag_begin[f + 1]; in.scores = scores; in.sources = sources;
+                         in.merged = secondary_begin != nullptr; in.tag_mid = secondary_begin ? secondary_begin[f] : in.tag_hi; in.secondary_cap = secondary_cap; }
+        else { in.text = arena + offsets[f]; in.len = LB; }
+        FileOut fo;
+        process_file(t, in, ws, fo, fired.data(), t.n_facets ? facets.data() : nullptr, 3);
+        if (verdicts) verdicts[f] = fo.verdict;
+        for (int c = 0; c < AUDIT_COLS; ++c) {
+            const size_t before = all.size();
+            for (uint32_t k = 0; k < fo.audit_cnt[c]; ++k) {
+                AuditElem e = audit_elem(t, ws, c, k);
+                if (k) all.push_back(';');
+                all.insert(all.end(), e.p, e.p + e.len);
+                if (e.reason) all.insert(all.end(), e.reason, e.reason + AUDIT_REASON_LEN);
+            }
+            if (all.size() - before != fo.audit_len[c]) return -2;   // the sizes process_file reports are what the emit kernel relies on
+            offs3[f * AUDIT_COLS + c + 1] = all.size();
+        }
+    }
+    if (all.size() > cap) return -1;
+    if (!all.empty()) std::memcpy(text, all.data(), all.size());
+    return (long long)all.size();
+}
+
 void sim_release(sim_result* r) { delete (SimOut*)r->opaque; r->opaque = nullptr; }
 
 }  // extern "C"

@@ -1,0 +1,121 @@
+"""The audit row (AppendAudit, Program.cs:334, 958-969): the tag lists the general pipeline keeps in audit mode, checked
+against the oracle's lists on the host build of the pipeline source, and the oracle's own row against hand-derived lines."""
+import numpy as np
+import pytest
+
+from helpers import EDGE_LINES, HostSim, Oracle, oracle_audit_lists, pack_lines, shipped_config
+from imagecaptioner_amd._abi import Config
+from imagecaptioner_amd.corpus import make_corpus
+
+
+def _check_lists(sim, orc, texts):
+    arena, offsets = pack_lines(texts)
+    want = orc.run_lines(arena, offsets, detail=True)
+    lists, ver = sim.run_audit(arena, offsets)
+    exp = oracle_audit_lists(want)
+    for i, t in enumerate(texts):
+        if ver["flags"][i] & 0x20:
+            continue                                   # outside what the device code takes: no lists
+        assert lists[i] == exp[i], (t, lists[i], exp[i])
+        assert ver[i].tobytes() == want.verdicts[i].tobytes(), t
+
+
+def test_audit_lists_edge_lines():
+    cfg = shipped_config()
+    _check_lists(HostSim(cfg), Oracle(cfg), EDGE_LINES)
+
+
+def test_audit_lists_dropped_and_invalid():
+    cfg = shipped_config(denylist=b"smile\nhat\n", allowlist=b"dress\n")
+    texts = ["1girl, smile, :bad, a!b, rating:safe, watermark, dress, hat, blue_hair, SMILE, sorry_tag",
+             "x'., y';, 1girl, (paren), -bad, smile, smile",
+             "zz_unknown_one, zz_unknown_two, 1girl, long_hair, dress, penis, feet"]
+    _check_lists(HostSim(cfg), Oracle(cfg), texts)
+    strict = shipped_config(strict_known=True, strict_known_explicit=True)
+    _check_lists(HostSim(strict), Oracle(strict), texts)
+
+
+@pytest.mark.parametrize("name", ["c1", "c3", "c5"])
+def test_audit_lists_corpus(name):
+    c = make_corpus(name, 300, seed=11)
+    cfg = Config(**c.config_kwargs)
+    arena, offsets = c.arena, c.offsets
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    want = orc.run_lines(arena, offsets, detail=True)
+    lists, ver = sim.run_audit(arena, offsets)
+    exp = oracle_audit_lists(want)
+    for i in range(len(exp)):
+        assert not (ver["flags"][i] & 0x20)
+        assert lists[i] == exp[i], i
+    # evidence and dropped counts of the verdict agree with the lists
+    for i in range(len(exp)):
+        assert ver["n_dropped"][i] == (lists[i][2].count(b";") + 1 if lists[i][2] else 0)
+        assert ver["n_evidence"][i] == (lists[i][1].count(b";") + 1 if lists[i][1] else 0)
+
+
+KNOWN_TAGS = ["1girl", "blue_hair", "blue_eyes", "dress", "standing", "classroom", ":bad", 'a"b', "watermark", "Blue Hair"]
+KNOWN_SCORES = [0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.35, 0.3, 0.29, 0.2]
+# Hand-derived from Program.cs on the shipped tables: SelectTags keeps the trigger, "1girl" and the five valid tags (tags=7);
+# ":bad" and 'a"b' fail ValidTagRegex, "watermark" is a policy drop (Program.cs:630-631); evidence holds every tag scored 0.28 or
+# more, dropped ones included (Program.cs:721-729); no facet rule matches, so each of the seven required facets adds and logs its
+# default (Program.cs:760-772); every coverage category is met (Program.cs:228, 292-294); Csv doubles the quotes (Program.cs:976-981).
+KNOWN_ROW = ('"pic ""1"".png",'
+             '"sgrui;1girl;blue_hair;blue_eyes;dress;standing;classroom;unknown_pov;unknown_gaze;unknown_underwear;unknown_fluids;unknown_ejaculation;'
+             'unknown_expression;unknown_mouth",'
+             '"1girl;blue_hair;blue_eyes;dress;standing;classroom;:bad;a""b;watermark",'
+             '"facet:viewpoint:unknown_pov:default;facet:gaze:unknown_gaze:default;facet:underwear:unknown_underwear:default;facet:fluids:unknown_fluids:default;'
+             'facet:ejaculation:unknown_ejaculation:default;facet:expression:unknown_expression:default;facet:mouth_shape:unknown_mouth:default",'
+             '":bad:invalid_tag;a""b:invalid_tag;watermark:policy_drop","","top_tags.txt","sgrui","coverage_satisfied",'
+             '"pass0_joy missing= required_missing= details=identity=ok|hair=ok|eyes=ok|outfit=ok|pose_action=ok|background_scene=ok tags=7"')
+KNOWN_AUDIT = {"names": ['pic "1".png'], "vocab_file": "top_tags.txt", "used_profile": "sgrui"}
+
+
+def known_scored_input():
+    arena, toffs = pack_lines(KNOWN_TAGS)
+    return arena, toffs, np.array([0, len(KNOWN_TAGS)], dtype=np.uint64), np.array(KNOWN_SCORES), np.zeros(len(KNOWN_TAGS), np.uint8)
+
+
+def test_oracle_audit_row_known_answer():
+    orc = Oracle(shipped_config())
+    res = orc.run_scored(*known_scored_input(), audit=KNOWN_AUDIT)
+    assert res.audit_rows[0].decode("utf-8") == KNOWN_ROW
+    # a line with nothing the categories ask for: everything but the identity is missing, the OpenAI passes are off
+    arena, offsets = pack_lines(["cat"])
+    res = orc.run_lines(arena, offsets, audit={"names": ["b.png"], "vocab_file": None, "used_profile": "none"})
+    f = res.audit_rows[0].decode("utf-8").split('","')
+    assert f[6] == "" and f[7] == "none"
+    assert f[8] == "openai_disabled_or_missing_api_key"
+    assert f[9].startswith("pass0_joy missing=hair|eyes|outfit|pose_action|background_scene required_missing=hair|eyes|outfit|pose_action details=identity=ok|hair=missing|")
+
+
+def test_audit_lists_known_scored():
+    sim = HostSim(shipped_config())
+    arena, toffs, tb, scores, src = known_scored_input()
+    lists, ver = sim.run_audit(arena, toffs, tag_begin=tb, scores=scores, sources=src)
+    f = KNOWN_ROW[1:-1].split('","')
+    assert [x.decode() for x in lists[0]] == [f[1], f[2].replace('""', '"'), f[4].replace('""', '"')]
+    assert ver["n_selected"][0] == 7
+
+
+@pytest.mark.parametrize("cap", [15, 2])
+def test_audit_lists_scored_and_merged(cap):
+    from test_merged_cpu import merged_inputs
+    for kw in (dict(), dict(strict_known=True, strict_known_explicit=True), dict(denylist=b"smile\nlong_hair\n")):
+        cfg = shipped_config(**kw)
+        sim, orc = HostSim(cfg), Oracle(cfg)
+        arena, toffs, begin, mid, scores = merged_inputs(23, 150)
+        want = orc.run_merged(arena, toffs, begin, mid, scores, cap, detail=True)
+        lists, ver = sim.run_audit(arena, toffs, tag_begin=begin, secondary_begin=mid, scores=scores, secondary_cap=cap)
+        exp = oracle_audit_lists(want)
+        n_dropped = 0
+        for i in range(len(exp)):
+            assert not (ver["flags"][i] & 0x20)
+            assert lists[i] == exp[i], (i, lists[i], exp[i])
+            assert ver[i].tobytes() == want.verdicts[i].tobytes()
+            n_dropped += len(want.details[i]["dropped"])
+        assert n_dropped > 0
+        # one reply per file, sources given
+        src = (np.arange(len(scores)) % 3).astype(np.uint8)
+        want = orc.run_scored(arena, toffs, begin, scores, src, detail=True)
+        lists, ver = sim.run_audit(arena, toffs, tag_begin=begin, scores=scores, sources=src)
+        assert lists == oracle_audit_lists(want)

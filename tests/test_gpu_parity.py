@@ -145,6 +145,90 @@ def test_audit_strings_and_side_files(name):
     assert len(act) == 0 and rej == []
 
 
+def _audit_args(n, vocab_file="top_tags.txt", used_profile="sgrui"):
+    return {"names": ['img "%d", x.png' % i for i in range(n)], "vocab_file": vocab_file, "used_profile": used_profile}
+
+
+def _check_audit(got, want, nl=b"\n"):
+    """audit.csv lines (Program.cs:966-967) and the three tag lists behind them against the oracle's."""
+    from helpers import oracle_audit_lists
+    exp_lists = oracle_audit_lists(want)
+    n = len(exp_lists)
+    assert len(got.audit_rows) == n
+    for i in range(n):
+        if got.verdicts["flags"][i] & 0x20:
+            assert got.audit_rows[i] == b"" and got.audit_lists[i] == (b"", b"", b"")
+            continue
+        assert got.audit_lists[i] == exp_lists[i], (i, got.audit_lists[i], exp_lists[i])
+        assert got.audit_rows[i] == want.audit_rows[i] + nl, (i, got.audit_rows[i], want.audit_rows[i])
+
+
+def test_audit_row_known_answer():
+    from test_audit_cpu import KNOWN_AUDIT, KNOWN_ROW, known_scored_input
+    p = pipe_for(shipped_config())
+    got = p.run_scored(*known_scored_input(), audit=KNOWN_AUDIT)
+    assert got.audit_rows[0].decode("utf-8") == KNOWN_ROW + "\n"
+    assert p.audit_header() == (b"filename,final_tags,evidence_tags,fired_rules,dropped_tags_with_reason,reject_reason,used_vocab_file,used_profile,"
+                                b"coverage_stop_reason,coverage_trace")
+
+
+@pytest.mark.parametrize("name", ["shipped", "novocab_w07_crlf", "c3", "c5"])
+def test_audit_rows_lines(name):
+    if name in ("c3", "c5"):
+        from imagecaptioner_amd.corpus import make_corpus
+        c = make_corpus(name, 2000, seed=9)
+        cfg = Config(**c.config_kwargs)
+        arena, offsets = c.arena, c.offsets
+    else:
+        cfg = CONFIGS[name]() if name != "shipped" else shipped_config(safe_mode=True)
+        lines = EDGE_LINES + fuzz_lines(91, 1500) + ["1girl, nude, smile, dress, long_hair", "1girl, smile, dress, penis, feet, barefoot, soles, toes, footjob"]
+        arena, offsets = pack_lines(lines)
+    n = len(offsets) - 1
+    audit = _audit_args(n, vocab_file=None if name != "shipped" else "top_tags.txt", used_profile="none" if name != "shipped" else "sgrui")
+    p, o = pipe_for(cfg), Oracle(cfg)
+    got, want = p.run_lines(arena, offsets, audit=audit), o.run_lines(arena, offsets, threads=8, detail=True, audit=audit)
+    nl = b"\r\n" if name == "novocab_w07_crlf" else b"\n"
+    _check_audit(got, want, nl)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name)     # audit mode changes nothing else
+    plain = p.run_lines(arena, offsets)                                      # and the context is back to the wave kernels afterwards
+    assert plain.audit_rows is None and np.array_equal(plain.captions, got.captions) and plain.verdicts.tobytes() == got.verdicts.tobytes()
+    assert p.last_timing()["general_files"] < n
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict", "builtin"])
+def test_audit_rows_tagger_replies(name):
+    from test_merged_cpu import merged_inputs
+    cfg = CONFIGS[name]()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    arena, toffs, begin, mid, scores = merged_inputs(77, 1200)
+    audit = _audit_args(len(begin) - 1)
+    got = p.run_merged(arena, toffs, begin, mid, scores, 15, audit=audit)
+    want = o.run_merged(arena, toffs, begin, mid, scores, 15, threads=8, detail=True, audit=audit)
+    _check_audit(got, want)
+    assert any(l[2] for l in got.audit_lists)                                # dropped tags with their reasons occur
+    src = (np.arange(len(scores)) % 3).astype(np.uint8)
+    got = p.run_scored(arena, toffs, begin, scores, src, audit=audit)
+    want = o.run_scored(arena, toffs, begin, scores, src, threads=8, detail=True, audit=audit)
+    _check_audit(got, want)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name)
+
+
+def test_audit_rows_chunked_and_empty(monkeypatch):
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus("c2", 3000, seed=5)
+    cfg = Config(**c.config_kwargs)
+    audit = _audit_args(3000, vocab_file=None, used_profile="none")
+    whole = pipe_for(cfg).run_lines(c.arena, c.offsets, audit=audit)
+    monkeypatch.setenv("TAGPIPE_WORKSPACE_BYTES", str(4 << 20))               # the range is halved until a piece fits: several audit passes
+    p = pipe_for(cfg)
+    chunked = p.run_lines(c.arena, c.offsets, audit=audit)
+    assert chunked.audit_rows == whole.audit_rows and chunked.audit_lists == whole.audit_lists
+    want = Oracle(cfg).run_lines(c.arena, c.offsets, threads=8, detail=True, audit=audit)
+    _check_audit(whole, want)
+    empty = p.run_lines(np.zeros(0, np.uint8), np.zeros(1, np.uint64), audit=_audit_args(0))
+    assert empty.audit_rows == [] and empty.audit_lists == []
+
+
 @pytest.mark.parametrize("merged", [False, True])
 def test_tagger_replies_take_the_wave_kernel(merged):
     """Replies as a tagger sends them (known tags, each once) stay in the wave kernel's scored front; results equal the oracle's."""
