@@ -64,6 +64,7 @@ struct HostResult {
     std::vector<uint16_t> facet_choice;
     std::vector<uint8_t> audit_text;        // audit mode only
     std::vector<uint64_t> audit_offsets;
+    std::vector<uint32_t> review_bits;
 };
 
 }  // namespace
@@ -76,7 +77,7 @@ struct tp_ctx {
     DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list1, slow_list2, scalars, workspace;
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
-    DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets;
+    DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets, out_review_bits;
     bool audit = false;              // tp_set_audit: the host-pointer runs also return the audit row's tag lists
     std::vector<hipEvent_t> events;
     tp_timing timing{};
@@ -89,7 +90,7 @@ struct tp_ctx {
         for (void* p : table_mem) (void)hipFree(p);
         for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
-                          &audit_cnt, &audit_len, &out_audit, &out_audit_offsets})
+                          &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
@@ -108,7 +109,7 @@ struct RunIo {
     uint8_t* captions; uint64_t caption_capacity; bool grow_captions;   // grow_captions: captions live in ctx->out_captions and may be reallocated
     uint64_t* caption_offsets; tp_verdict* verdicts; uint64_t* histogram; tp_counters* counters; uint32_t* fired; uint16_t* facet_choice;
     hipStream_t stream; int mode;
-    bool audit; uint64_t* audit_offsets;    // audit: every file takes the general kernel in mode 3; the lists' text goes to ctx->out_audit
+    bool audit; uint64_t* audit_offsets; uint32_t* review_bits;    // audit: every file takes the general kernel in mode 3; the lists' text goes to ctx->out_audit
 };
 
 // One range of files [f0, f1): wave-per-file kernel, general kernel for what it declined, caption offsets, emit.
@@ -216,7 +217,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         pa.fired = io.fired; pa.facet_choice = io.facet_choice; pa.mode = io.audit ? 3 : io.mode;
         if (io.audit) {
             c->audit_cnt.need(n * AUDIT_COLS * 4); c->audit_len.need(n * AUDIT_COLS * 4);
-            pa.audit_cnt = c->audit_cnt.as<uint32_t>(); pa.audit_len = c->audit_len.as<uint32_t>();
+            pa.audit_cnt = c->audit_cnt.as<uint32_t>(); pa.audit_len = c->audit_len.as<uint32_t>(); pa.review_bits = io.review_bits + f0;
         }
         hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
         HIP_OK(hipEventRecord(p0, s));
@@ -378,6 +379,8 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     if (io.audit) {
         c->out_audit_offsets.need((n_files * AUDIT_COLS + 1) * 8);
         io.audit_offsets = c->out_audit_offsets.as<uint64_t>();
+        c->out_review_bits.need(std::max<uint64_t>(n_files, 1) * 4);
+        io.review_bits = c->out_review_bits.as<uint32_t>();
     }
     uint64_t cap_bytes = 0, audit_bytes = 0;
     int rc = run_device(c, io, &cap_bytes, &audit_bytes);
@@ -403,6 +406,8 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
         r->audit_offsets.resize(n_files * AUDIT_COLS + 1);
         if (audit_bytes) HIP_OK(hipMemcpy(r->audit_text.data(), c->out_audit.p, audit_bytes, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(r->audit_offsets.data(), c->out_audit_offsets.p, (n_files * AUDIT_COLS + 1) * 8, hipMemcpyDeviceToHost));
+        r->review_bits.resize(std::max<uint64_t>(n_files, 1));
+        if (n_files) HIP_OK(hipMemcpy(r->review_bits.data(), c->out_review_bits.p, n_files * 4, hipMemcpyDeviceToHost));
     }
     out->n_files = n_files;
     out->captions = r->captions.data();
@@ -848,6 +853,152 @@ int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t*
             }
             row.push_back(','); csv_s(missing.empty() ? std::string("coverage_satisfied") : std::string("openai_disabled_or_missing_api_key"));
             row.push_back(','); csv_s("pass0_joy missing=" + missing + " required_missing=" + required + " details=" + details + " tags=" + std::to_string(v.n_selected));
+            rows += row;
+            rows += nl;
+        }
+        out_offsets[n_files] = rows.size();
+        *needed = rows.size();
+        if (rows.empty()) return (int)TP_OK;
+        if (!out || capacity < rows.size()) return fail(TP_E_CAPACITY, "output buffer too small");
+        std::memcpy(out, rows.data(), rows.size());
+        return (int)TP_OK;
+    });
+}
+
+const char* tp_review_csv_header(void) {   // Program.cs:886
+    return "image_path,caption_path,reasons,banned_tokens_detected,dropped_tags,final_tag_count,short_caption,thresholds_used,top_joy_tags,unknown_final_tags,"
+           "known_dict_found,known_dict_count,known_dict_path,coverage_stop_reason,coverage_trace";
+}
+
+namespace {
+// A string as JsonSerializer.Serialize writes it with its default encoder (Program.cs:874): of Basic Latin everything but
+// the control characters, DEL and " & ' + < > \ ` stays; backslash and the five short control escapes are written short;
+// the rest, everything beyond Basic Latin included, as \uXXXX in upper-case hex, UTF-16 code unit by code unit.
+void json_string(const std::string& s, std::string& o) {
+    static const char* const hex = "0123456789ABCDEF";
+    auto unit = [&](uint32_t u) { o += "\\u"; o += hex[(u >> 12) & 15]; o += hex[(u >> 8) & 15]; o += hex[(u >> 4) & 15]; o += hex[u & 15]; };
+    o += '"';
+    for (size_t i = 0; i < s.size();) {
+        const uint8_t c = (uint8_t)s[i];
+        if (c < 0x80) {
+            ++i;
+            switch (c) {
+                case '\\': o += "\\\\"; break;
+                case '\b': o += "\\b"; break;
+                case '\f': o += "\\f"; break;
+                case '\n': o += "\\n"; break;
+                case '\r': o += "\\r"; break;
+                case '\t': o += "\\t"; break;
+                case '"': case '&': case '\'': case '+': case '<': case '>': case '`': case 0x7F: unit(c); break;
+                default: if (c < 0x20) unit(c); else o += (char)c;
+            }
+            continue;
+        }
+        uint32_t cp = 0xFFFD;
+        size_t len = 1;
+        if ((c & 0xE0) == 0xC0 && i + 1 < s.size()) { cp = ((c & 0x1Fu) << 6) | ((uint8_t)s[i + 1] & 0x3Fu); len = 2; }
+        else if ((c & 0xF0) == 0xE0 && i + 2 < s.size()) { cp = ((c & 0x0Fu) << 12) | (((uint8_t)s[i + 1] & 0x3Fu) << 6) | ((uint8_t)s[i + 2] & 0x3Fu); len = 3; }
+        else if ((c & 0xF8) == 0xF0 && i + 3 < s.size()) {
+            cp = ((c & 0x07u) << 18) | (((uint8_t)s[i + 1] & 0x3Fu) << 12) | (((uint8_t)s[i + 2] & 0x3Fu) << 6) | ((uint8_t)s[i + 3] & 0x3Fu);
+            len = 4;
+        }
+        i += len;
+        if (cp >= 0x10000) { cp -= 0x10000; unit(0xD800 + (cp >> 10)); unit(0xDC00 + (cp & 0x3FF)); }
+        else unit(cp);
+    }
+    o += '"';
+}
+void json_list(const std::vector<std::string>& v, std::string& o) {
+    o += '[';
+    for (size_t k = 0; k < v.size(); ++k) { if (k) o += ','; json_string(v[k], o); }
+    o += ']';
+}
+std::vector<std::string> split_lines(const uint8_t* p, uint64_t n) {
+    std::vector<std::string> v;
+    if (n == 0) return v;
+    uint64_t a = 0;
+    for (uint64_t k = 0; k <= n; ++k) if (k == n || p[k] == '\n') { v.emplace_back((const char*)p + a, (size_t)(k - a)); a = k + 1; }
+    return v;
+}
+}  // namespace
+
+int tp_format_review_rows(const tp_ctx* ctx, const tp_result* res, int format, const uint8_t* image_paths, const uint64_t* image_offsets,
+                          const uint8_t* caption_paths, const uint64_t* caption_offsets, const char* thresholds_used, const char* vocab_file,
+                          uint8_t* out, uint64_t capacity, uint64_t* out_offsets, uint64_t* needed) {
+    if (!ctx || !res || !out_offsets || !needed || !image_offsets || !caption_offsets || !thresholds_used) return fail(TP_E_INVALID_ARG, "null argument");
+    if (format != TP_REVIEW_JSONL && format != TP_REVIEW_CSV) return fail(TP_E_INVALID_ARG, "unknown review format");
+    const HostResult* r = (const HostResult*)res->opaque;
+    if (!r || r->audit_offsets.empty()) return fail(TP_E_INVALID_ARG, "the result was not produced with tp_set_audit(ctx, 1)");
+    const uint64_t n_files = res->n_files;
+    if (n_files && ((image_offsets[n_files] && !image_paths) || (caption_offsets[n_files] && !caption_paths))) return fail(TP_E_INVALID_ARG, "null argument");
+    const HostTables& h = ctx->ht;
+    const std::string nl((const char*)ctx->dt.newline, ctx->dt.newline_len);
+    return guarded([&]() {
+        std::string rows, row;
+        static const char* const kCats[6] = {"identity", "hair", "eyes", "outfit", "pose_action", "background_scene"};
+        auto join = [](const std::vector<std::string>& v) { std::string o; for (size_t k = 0; k < v.size(); ++k) { if (k) o += ';'; o += v[k]; } return o; };
+        auto csv = [&](const std::string& x) { row += '"'; for (char ch : x) { if (ch == '"') row += '"'; row += ch; } row += '"'; };   // Program.cs:976-981
+        for (uint64_t i = 0; i < n_files; ++i) {
+            out_offsets[i] = rows.size();
+            const tp_verdict& v = res->verdicts[i];
+            if (v.flags & TP_F_UNSUPPORTED) continue;
+            const uint32_t rb = r->review_bits[i];
+            // BuildReviewRecord, Program.cs:826-868
+            std::vector<std::string> banned, reasons;
+            for (int k = 0; k < N_BANNED; ++k) if (rb & (1u << k)) banned.push_back(h.strings[ctx->dt.banned_ids[k]]);
+            const bool has_male = !banned.empty() || (rb & REVIEW_MALE), has_girl = (rb & REVIEW_GIRL) != 0, multi = (rb & REVIEW_MULTI) != 0;
+            const bool low = (v.flags & TP_F_LOW) != 0;
+            if (has_male) reasons.push_back("male_subject_token");
+            if (has_male && has_girl) reasons.push_back("mixed_subject_tokens");
+            if (multi) reasons.push_back("multi_person");
+            if (low) reasons.push_back("short_caption");
+            const uint64_t* ao = r->audit_offsets.data() + i * AUDIT_COLS;
+            std::vector<std::string> top = split_lines(r->audit_text.data() + ao[AUDIT_TOP], ao[AUDIT_TOP + 1] - ao[AUDIT_TOP]);
+            std::vector<std::string> unknown = split_lines(r->audit_text.data() + ao[AUDIT_UNKNOWN], ao[AUDIT_UNKNOWN + 1] - ao[AUDIT_UNKNOWN]);
+            std::stable_sort(unknown.begin(), unknown.end(), less_ordinal_ignore_case);     // OrderBy(OrdinalIgnoreCase), Program.cs:822
+            std::string missing, required, details;
+            for (int k = 0; k < 6; ++k) {
+                const bool ok = (v.coverage >> k) & 1u;
+                if (!ok) {
+                    if (!missing.empty()) missing.push_back('|');
+                    missing += kCats[k];
+                    if (k < 5) { if (!required.empty()) required.push_back('|'); required += kCats[k]; }
+                }
+                if (k) details.push_back('|');
+                details += kCats[k]; details += ok ? "=ok" : "=missing";
+            }
+            const std::string stop = missing.empty() ? "coverage_satisfied" : "openai_disabled_or_missing_api_key";
+            const bool has_coverage_log = !missing.empty();                                  // Program.cs:844 with a one-entry trace
+            if (reasons.empty() && banned.empty() && unknown.empty() && !has_coverage_log) continue;   // Program.cs:845: no record
+            const std::vector<std::string> trace = {"pass0_joy missing=" + missing + " required_missing=" + required + " details=" + details + " tags=" +
+                                                    std::to_string(v.n_selected)};
+            const std::string image((const char*)image_paths + image_offsets[i], (size_t)(image_offsets[i + 1] - image_offsets[i]));
+            const std::string caption((const char*)caption_paths + caption_offsets[i], (size_t)(caption_offsets[i + 1] - caption_offsets[i]));
+            const std::string vocab = vocab_file ? vocab_file : "";
+            row.clear();
+            if (format == TP_REVIEW_JSONL) {                                                 // JsonSerializer.Serialize(record), Program.cs:874, 415-431
+                row += "{\"ImagePath\":"; json_string(image, row);
+                row += ",\"CaptionPath\":"; json_string(caption, row);
+                row += ",\"Reasons\":"; json_list(reasons, row);
+                row += ",\"BannedTokensDetected\":"; json_list(banned, row);
+                row += ",\"DroppedTags\":"; json_list(banned, row);                       // DroppedMaleSubjectTags: the same list (Program.cs:618-623, 856)
+                row += ",\"FinalTagCount\":" + std::to_string(v.n_selected);
+                row += std::string(",\"ShortCaption\":") + (low ? "true" : "false");
+                row += ",\"ThresholdsUsed\":"; json_string(thresholds_used, row);
+                row += ",\"TopJoyTags\":"; json_list(top, row);
+                row += ",\"UnknownFinalTags\":"; json_list(unknown, row);
+                row += std::string(",\"KnownTagDictionaryFound\":") + (h.known_found ? "true" : "false");
+                row += ",\"KnownTagDictionaryCount\":" + std::to_string(h.n_known);
+                row += ",\"KnownTagDictionaryPath\":"; json_string(vocab, row);
+                row += ",\"CoverageTrace\":"; json_list(trace, row);
+                row += ",\"CoverageStopReason\":"; json_string(stop, row);
+                row += '}';
+            } else {                                                                         // Program.cs:875-881
+                csv(image); row += ','; csv(caption); row += ','; csv(join(reasons)); row += ','; csv(join(banned)); row += ','; csv(join(banned)); row += ',';
+                csv(std::to_string(v.n_selected)); row += ','; csv(low ? "true" : "false"); row += ','; csv(thresholds_used); row += ','; csv(join(top)); row += ',';
+                csv(join(unknown)); row += ','; csv(h.known_found ? "true" : "false"); row += ','; csv(std::to_string(h.n_known)); row += ','; csv(vocab); row += ',';
+                csv(stop); row += ','; csv(join(trace));
+            }
             rows += row;
             rows += nl;
         }

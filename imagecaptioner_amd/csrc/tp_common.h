@@ -56,6 +56,10 @@ enum : uint32_t {
     FL_PREFIX = 1u << 22,      // it is one of the tags SelectTags adds before the candidates (trigger, 1girl, always-add)
     FL_REACH2 = 1u << 23,      // the closure of {it} holds nothing beyond its at most two steps; Rec::s0_info / s1_info describe them
     FL_PHRASE = 1u << 25,      // holds one of the LooksBad phrases (Program.cs:56-58, 1144); only a force-allowed tag can and still be kept
+    // BuildReviewRecord's tests on a raw token that counts as a subject token (in SubjectTokens, or holding "boys" / "girls"; Program.cs:829-837):
+    FL_SUBJ_MALE = 1u << 26,   //   it is in MaleSubjectTokens (Program.cs:30-32, 835)
+    FL_SUBJ_GIRL = 1u << 27,   //   it holds "girl" (Program.cs:836)
+    FL_SUBJ_MULTI = 1u << 28,  //   it starts with "multiple_" or matches ^\d+(girl|girls|boy|boys)$ (Program.cs:837; digits: ASCII only here)
     FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone and that has no steps of
                                // its own: one ExpandImpliedTags round settles it; Rec::s0_flags .. s1_len describe the steps
 };
@@ -147,6 +151,8 @@ struct HtInfo { uint32_t val, woff, slen, pad; };   // woff: first 8-byte word o
 constexpr uint32_t NO_ID = 0xFFFFFFFFu;
 constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
 constexpr int MAX_TOTAL_TAGS = 42;        // Program.cs:38
+constexpr int N_BANNED = 9;               // BannedFinalTags, Program.cs:33-35
+constexpr int TOP_TAGS = 20;              // TopJoyTags of a review record, Program.cs:860
 constexpr int MAX_ALWAYS_ADD = 64;
 constexpr int MAX_FALLBACK = MAX_TOTAL_TAGS;
 constexpr uint32_t RC_REC_WORDS = 10;
@@ -225,6 +231,7 @@ struct DevTables {
     uint32_t rc_rule_mask, rc_frule_mask, rules_vacuous, frules_vacuous;
     uint32_t prefix_simple;      // the same for the prefix tags, and none of them has steps
     uint32_t prefix_flags[MAX_TOTAL_TAGS], prefix_len[MAX_TOTAL_TAGS];   // flags and byte length per prefix tag
+    uint32_t banned_ids[N_BANNED];   // BannedFinalTags (Program.cs:33-35) in ordinal-ignore-case order, the order BuildReviewRecord lists them in (Program.cs:828)
     uint32_t seed_ci_limit;      // candidates below this index have !(score < 0.28)  (BuildEvidenceTags, Program.cs:724)
     uint32_t style_ci_limit;     // candidates below this index have score >= 0.60     (DetermineStyleQualityCap, Program.cs:706)
 };

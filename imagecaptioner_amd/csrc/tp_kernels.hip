@@ -363,11 +363,13 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
             a.audit_cnt[(f - a.file0) * AUDIT_COLS + c] = out.audit_cnt[c];
             a.audit_len[(f - a.file0) * AUDIT_COLS + c] = out.audit_len[c];
         }
+        a.review_bits[f - a.file0] = out.review_bits;
     }
 }
 
-// The audit row's three tag lists as text: one wavefront per file, one entry per lane and step.  Entries are joined with
-// ";" (Program.cs:966); dropped tags carry their reason (Program.cs:630-631).
+// The tag lists of the audit row and the review record as text: one wavefront per file, one entry per lane and step.  The
+// audit row's entries are joined with ";" (Program.cs:966), dropped tags carry their reason (Program.cs:630-631); the review
+// record's lists are separated by "\n" (the host sorts and joins them); the unknown-tag column keeps only entries that qualify.
 __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -381,17 +383,21 @@ __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
         for (int c = 0; c < AUDIT_COLS; ++c) {
             const uint32_t cnt = a.audit_cnt[(f - a.file0) * AUDIT_COLS + c];
             uint8_t* out = a.text + a.offsets[f * AUDIT_COLS + c];
-            uint32_t running = 0;
+            const uint8_t sep = c >= AUDIT_TOP ? (uint8_t)'\n' : (uint8_t)';';
+            uint32_t running = 0, kept_before = 0;
             for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
                 const uint32_t k = k0 + lane;
-                const bool live = k < cnt;
-                AuditElem e{nullptr, 0, nullptr};
-                if (live) e = audit_elem(t, ws, c, k);
-                const uint32_t seg = live ? e.len + (e.reason ? AUDIT_REASON_LEN : 0u) + (k ? 1u : 0u) : 0u;
+                AuditElem e{nullptr, 0, nullptr, false};
+                if (k < cnt) e = audit_elem(t, ws, c, k);
+                const bool live = e.keep;
+                const uint64_t m = __ballot(live ? 1 : 0);
+                const bool first = kept_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0;
+                kept_before += (uint32_t)__popcll(m);
+                const uint32_t seg = live ? e.len + (e.reason ? AUDIT_REASON_LEN : 0u) + (first ? 0u : 1u) : 0u;
                 const uint32_t incl = wave_scan_incl(seg);
                 if (live) {
                     uint8_t* dst = out + running + (incl - seg);
-                    if (k) *dst++ = ';';
+                    if (!first) *dst++ = sep;
                     for (uint32_t b = 0; b < e.len; ++b) dst[b] = e.p[b];
                     if (e.reason) for (uint32_t b = 0; b < AUDIT_REASON_LEN; ++b) dst[e.len + b] = (uint8_t)e.reason[b];
                 }

@@ -63,6 +63,7 @@ struct PipelineArgs {
     int mode;
     uint32_t* audit_cnt;          // mode 3: AUDIT_COLS entries per file, indexed by file - file0: entries and bytes of the audit row's lists
     uint32_t* audit_len;
+    uint32_t* review_bits;        // mode 3: per file (indexed by file - file0) the REVIEW_* bits of the review record
 };
 
 // Text of the audit row's tag lists (keptTags, evidenceTags, DroppedTagsWithReason joined with ";", Program.cs:966) for the

@@ -26,7 +26,7 @@ struct LaneArr {
 // Byte layout of one wavefront's workspace (64 files).  T = the largest token
 // count among its files, LB = the largest line length.
 struct WsLayout {
-    uint64_t o_hnd, o_score, o_order, o_sorted, o_src, o_dl, o_ev, o_snap, o_fin, o_ebits, o_line, o_norm, total;
+    uint64_t o_hnd, o_score, o_order, o_sorted, o_src, o_dl, o_ev, o_snap, o_fin, o_ebits, o_line, o_norm, o_top, o_top_score, o_top_order, total;
     uint32_t cap_t, cap_e, cap_snap, cap_f, cap_norm;
 };
 TP_HD uint64_t ws_align(uint64_t x) { return (x + 255) & ~(uint64_t)255; }
@@ -51,14 +51,17 @@ TP_HD WsLayout ws_layout(uint32_t T, uint32_t LB, uint32_t final_cap, uint32_t e
     L.o_ebits = o;  o = ws_align(o + (uint64_t)(lit_words ? lit_words : 1) * 64 * 4);
     L.o_line = o;   o = ws_align(o + (uint64_t)L.cap_norm * 64);
     L.o_norm = o;   o = ws_align(o + (uint64_t)L.cap_norm * 64);
+    L.o_top = o;    o = ws_align(o + (uint64_t)TOP_TAGS * 64 * 8);
+    L.o_top_score = o; o = ws_align(o + (uint64_t)TOP_TAGS * 64 * 8);
+    L.o_top_order = o; o = ws_align(o + (uint64_t)TOP_TAGS * 64 * 4);
     L.total = o;
     return L;
 }
 
 struct FileWs {
-    LaneArr<H> hnd, dl, ev, snap, fin;
-    LaneArr<double> score;
-    LaneArr<uint32_t> order, sorted, ebits;
+    LaneArr<H> hnd, dl, ev, snap, fin, top;
+    LaneArr<double> score, top_score;
+    LaneArr<uint32_t> order, sorted, ebits, top_order;
     LaneArr<uint8_t> src;
     uint8_t* line;   // thread-contiguous, cap_norm bytes: CRLF-collapsed copy of the raw line when needed
     uint8_t* norm;   // thread-contiguous, cap_norm bytes: bytes of dynamic strings
@@ -76,6 +79,9 @@ TP_HD FileWs ws_bind(uint8_t* wave_base, const WsLayout& L, uint32_t lane) {
     w.snap.base = (H*)(wave_base + L.o_snap) + lane;
     w.fin.base = (H*)(wave_base + L.o_fin) + lane;
     w.ebits.base = (uint32_t*)(wave_base + L.o_ebits) + lane;
+    w.top.base = (H*)(wave_base + L.o_top) + lane;
+    w.top_score.base = (double*)(wave_base + L.o_top_score) + lane;
+    w.top_order.base = (uint32_t*)(wave_base + L.o_top_order) + lane;
     w.line = wave_base + L.o_line + (size_t)lane * L.cap_norm;
     w.norm = wave_base + L.o_norm + (size_t)lane * L.cap_norm;
     w.cap_t = L.cap_t; w.cap_e = L.cap_e; w.cap_snap = L.cap_snap; w.cap_f = L.cap_f; w.cap_norm = L.cap_norm;
@@ -101,15 +107,22 @@ struct FileOut {
     tp_verdict verdict;
     uint32_t n_final;      // handles left in ws.fin: the caption's tags, in order
     uint32_t caption_len;  // bytes of the caption line including the newline
-    // mode 3 only: the three tag lists of the audit row (AppendAudit, Program.cs:334, 966), entries and bytes when joined with ";"
-    uint32_t audit_cnt[3];
-    uint32_t audit_len[3];
+    // mode 3 only: the tag lists of the audit row (AppendAudit, Program.cs:334, 966) and of the review record (BuildReviewRecord,
+    // Program.cs:826-868): entries to walk and bytes of the column's text
+    uint32_t audit_cnt[5];
+    uint32_t audit_len[5];
+    uint32_t review_bits;  // REVIEW_* : which banned tags the raw candidates held, and the subject-token tests
 };
+// review_bits: bit k (k < N_BANNED) = DevTables::banned_ids[k] is among the normalised raw candidates (bannedDetected, Program.cs:828)
+constexpr uint32_t REVIEW_MALE = 1u << 16, REVIEW_GIRL = 1u << 17, REVIEW_MULTI = 1u << 18;   // Program.cs:835-837 without the banned part of hasMale
 
 // The tag-list columns of the audit row (Program.cs:966): keptTags = finalTags as they stand after EnsureRequiredFacets
 // (Program.cs:307), evidenceTags after ExpandImpliedTags (Program.cs:302), finalSelection.DroppedTagsWithReason (Program.cs:682).
 // After process_file in mode 3 they sit in the file's workspace: ws.snap, ws.ev and ws.dl.
-constexpr int AUDIT_KEPT = 0, AUDIT_EVIDENCE = 1, AUDIT_DROPPED = 2, AUDIT_COLS = 3;
+// Two more columns feed the review record (Program.cs:860-861): the TopJoyTags (the 20 best raw candidates' tags) and the
+// caption tags outside the vocabulary (GetUnknownTags before its sort, Program.cs:817-821); their entries are separated by "\n",
+// which no normalised tag holds.  The unknown column walks the caption's tags (ws.fin) and keeps those that qualify.
+constexpr int AUDIT_KEPT = 0, AUDIT_EVIDENCE = 1, AUDIT_DROPPED = 2, AUDIT_TOP = 3, AUDIT_UNKNOWN = 4, AUDIT_COLS = 5;
 constexpr uint32_t AUDIT_REASON_LEN = 12;   // ":invalid_tag" and ":policy_drop" have the same length (Program.cs:630-631)
 
 // ================================================================================================
@@ -177,6 +190,33 @@ TP_HD uint32_t classify_dyn(const DevTables& t, const uint8_t* p, uint32_t n) {
     bool drop = !valid || (mask & CM_SORRY) || (t.allow_nonempty && (rating || (mask & CM_WATERMARK))) || t.drop_unknown;    // ShouldDropTag, Program.cs:1121-1133
     return (valid ? (uint32_t)FL_VALID : 0u) | (drop ? (uint32_t)FL_DROP : 0u) | (n >= 2 ? (uint32_t)FL_LEN2 : 0u) | (bucket << FL_BUCKET_SHIFT) |
            ((mask & CM_HAIR) ? (uint32_t)FL_HAIR : 0u) | ((mask & CM_EYES) ? (uint32_t)FL_EYES : 0u);
+}
+
+// BuildReviewRecord's subject-token tests (Program.cs:829-837) on a string that is in no table (ASCII, normalised, so lower
+// case): such a string is in none of the reference's fixed sets, so it is a subject token only by holding "boys" or "girls".
+TP_HD bool has_word(const uint8_t* p, uint32_t n, const char* w, uint32_t wl) {
+    for (uint32_t i = 0; i + wl <= n; ++i) {
+        uint32_t k = 0;
+        while (k < wl && p[i + k] == (uint8_t)w[k]) ++k;
+        if (k == wl) return true;
+    }
+    return false;
+}
+TP_HD uint32_t subject_bits_dyn(const uint8_t* p, uint32_t n) {
+    const bool girls = has_word(p, n, "girls", 5);
+    if (!girls && !has_word(p, n, "boys", 4)) return 0;
+    uint32_t bits = 0;
+    if (girls || has_word(p, n, "girl", 4)) bits |= FL_SUBJ_GIRL;
+    bool multi = n >= 9 && has_word(p, 9, "multiple_", 9);
+    uint32_t d = 0;
+    while (d < n && p[d] >= '0' && p[d] <= '9') ++d;
+    if (d > 0) {
+        const uint32_t r = n - d;
+        const uint8_t* q = p + d;
+        multi |= (r == 4 && has_word(q, 4, "girl", 4)) || (r == 5 && has_word(q, 5, "girls", 5)) || (r == 3 && has_word(q, 3, "boy", 3)) || (r == 4 && has_word(q, 4, "boys", 4));
+    }
+    if (multi) bits |= FL_SUBJ_MULTI;
+    return bits;
 }
 
 // Hash-table probe with the candidate bytes given as plain memory.
@@ -416,10 +456,12 @@ TP_HD bool has_refusal_phrase(const uint8_t* s, uint32_t a, uint32_t b) {
 }
 
 // Entry k of an audit column: where its bytes are, and for the dropped column the reason the reference appends.
-struct AuditElem { const uint8_t* p; uint32_t len; const char* reason; };
+struct AuditElem { const uint8_t* p; uint32_t len; const char* reason; bool keep; };
+TP_HD bool tag_unknown(const DevTables& t, H h) { return t.known_active && (h_is_dyn(h) || !(t.flags[h_id(h)] & FL_KNOWN)); }   // Program.cs:818-820
 TP_HD AuditElem audit_elem(const DevTables& t, const FileWs& ws, int col, uint32_t k) {
-    const H h = col == AUDIT_KEPT ? ws.snap[k] : col == AUDIT_EVIDENCE ? ws.ev[k] : ws.dl[k];
+    const H h = col == AUDIT_KEPT ? ws.snap[k] : col == AUDIT_EVIDENCE ? ws.ev[k] : col == AUDIT_DROPPED ? ws.dl[k] : col == AUDIT_TOP ? ws.top[k] : ws.fin[k];
     AuditElem e;
+    e.keep = col != AUDIT_UNKNOWN || tag_unknown(t, h);
     if (h_is_dyn(h)) { e.p = ws.norm + h_off(h); e.len = h_len(h); }
     else { e.p = str_ptr(t, h_id(h)); e.len = str_len(t, h_id(h)); }
     e.reason = col != AUDIT_DROPPED ? nullptr : !(hflags(t, h) & FL_VALID) ? ":invalid_tag" : ":policy_drop";   // Program.cs:630-631
@@ -438,6 +480,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     out.n_final = 0;
     out.caption_len = 0;
     for (int c = 0; c < AUDIT_COLS; ++c) { out.audit_cnt[c] = 0; out.audit_len[c] = 0; }
+    out.review_bits = 0;
     if (fired) for (uint32_t w = 0; w < t.fired_words; ++w) fired[w] = 0;
     if (facet_choice) for (uint32_t f = 0; f < t.n_facets; ++f) facet_choice[f] = 0xFFFF;
 
@@ -665,14 +708,34 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     // ---------------- SelectTags, first half (Program.cs:625-655) + BuildEvidenceTags (Program.cs:721-729) ----------------
     // Both walk the candidates in order applying NormalizeTag once, so they share the walk.  The unique list is compacted
     // in place: entry nu is written only after candidate i >= nu has been read.
-    uint32_t nu = 0, ndl = 0, ne = 0;
+    uint32_t nu = 0, ndl = 0, ne = 0, ntop = 0, rbits = 0;
     for (uint32_t i = 0; i < n; ++i) {
         H h2 = norm_hop(t, ws, ws.hnd[i]);
         double sc = ws.score[i];
         uint32_t od = ws.order[i];
         uint32_t sr = ws.src[i];
         uint32_t f2 = hflags(t, h2);
+        if (mode == 3) {
+            // TopJoyTags: rawCandidates.OrderByDescending(Score).ThenBy(Order).Take(20).Select(c => c.Tag), a stable sort (Program.cs:860)
+            uint32_t pos = ntop;
+            while (pos > 0 && (ws.top_score[pos - 1] < sc || (ws.top_score[pos - 1] == sc && ws.top_order[pos - 1] > od))) --pos;
+            if (pos < (uint32_t)TOP_TAGS) {
+                for (uint32_t q = ntop < (uint32_t)TOP_TAGS ? ntop : (uint32_t)TOP_TAGS - 1; q > pos; --q) {
+                    ws.top[q] = ws.top[q - 1]; ws.top_score[q] = ws.top_score[q - 1]; ws.top_order[q] = ws.top_order[q - 1];
+                }
+                ws.top[pos] = ws.hnd[i]; ws.top_score[pos] = sc; ws.top_order[pos] = od;
+                if (ntop < (uint32_t)TOP_TAGS) ++ntop;
+            }
+        }
         if (f2 & FL_BLANK) continue;
+        if (mode == 3) {                                          // rawTokens of BuildReviewRecord (Program.cs:827-837)
+            if (h_is_dyn(h2)) rbits |= subject_bits_dyn(ws.norm + h_off(h2), h_len(h2)) >> 10;
+            else {
+                const uint32_t fs = t.flags[h_id(h2)];
+                if (fs & FL_BANNED) for (int k = 0; k < N_BANNED; ++k) if (t.banned_ids[k] == h_id(h2)) rbits |= 1u << k;
+                rbits |= (fs & (FL_SUBJ_MALE | FL_SUBJ_GIRL | FL_SUBJ_MULTI)) >> 10;
+            }
+        }
         if (!(sc < 0.28) && (mode == 0 || mode == 3)) {                          // evidence keeps invalid and dropped tags too
             if (!lfind(ws, ws.ev, ne, h2)) {
                 if (ne >= ws.cap_e) overflow = true; else ws.ev[ne++] = h2;
@@ -880,12 +943,13 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     // ---------------- the audit row's lists (Program.cs:334, 966) ----------------
     // keptTags is the final list as it stands here, before FormatCaptionSingleLine normalises it again: a copy goes to
     // ws.snap, which the closures no longer need (cap_snap >= cap_f >= nf).
-    uint32_t akept = 0, alen[3] = {0, 0, 0};
+    uint32_t akept = 0, alen[AUDIT_COLS] = {0, 0, 0, 0, 0};
     if (mode == 3) {
         akept = nf;
         for (uint32_t i = 0; i < nf; ++i) { H h = ws.fin[i]; ws.snap[i] = h; alen[AUDIT_KEPT] += hbytes(t, h) + (i ? 1u : 0u); }
         for (uint32_t i = 0; i < ne; ++i) alen[AUDIT_EVIDENCE] += hbytes(t, ws.ev[i]) + (i ? 1u : 0u);
         for (uint32_t i = 0; i < ndl; ++i) alen[AUDIT_DROPPED] += hbytes(t, ws.dl[i]) + AUDIT_REASON_LEN + (i ? 1u : 0u);
+        for (uint32_t i = 0; i < ntop; ++i) alen[AUDIT_TOP] += hbytes(t, ws.top[i]) + (i ? 1u : 0u);
     }
 
     // ---------------- FormatCaptionSingleLine (Program.cs:971-974) and GetUnknownTags (Program.cs:817-824) ----------------
@@ -899,7 +963,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         if (lfind(ws, ws.fin, nc, h6)) continue;
         ws.fin[nc++] = h6;
         bytes += hbytes(t, h6);
-        if (t.known_active && (h_is_dyn(h6) || !(f & FL_KNOWN))) ++unknown;
+        if (t.known_active && (h_is_dyn(h6) || !(f & FL_KNOWN))) { alen[AUDIT_UNKNOWN] += hbytes(t, h6) + (unknown ? 1u : 0u); ++unknown; }
         if (h6 == (H)t.footjob_n) footjob = true;                 // HasTag(finalTags, "footjob"), Program.cs:311
     }
     if (overflow) { v.flags = TP_F_UNSUPPORTED; out.n_final = 0; out.caption_len = 0; return; }
@@ -910,6 +974,8 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     out.n_final = nc;
     if (mode == 3) {
         out.audit_cnt[AUDIT_KEPT] = akept; out.audit_cnt[AUDIT_EVIDENCE] = ne; out.audit_cnt[AUDIT_DROPPED] = ndl;
+        out.audit_cnt[AUDIT_TOP] = ntop; out.audit_cnt[AUDIT_UNKNOWN] = nc;
+        out.review_bits = rbits;
         for (int c = 0; c < AUDIT_COLS; ++c) out.audit_len[c] = alen[c];
     }
     out.caption_len = bytes + (nc ? 2 * (nc - 1) : 0) + t.newline_len;    // string.Join(", ", …) + Environment.NewLine, Program.cs:316-317

@@ -683,6 +683,10 @@ struct Interner {
 
 }  // namespace
 
+bool less_ordinal_ignore_case(const std::string& a, const std::string& b) {
+    return folded(from_utf8((const uint8_t*)a.data(), a.size())) < folded(from_utf8((const uint8_t*)b.data(), b.size()));
+}
+
 void compile_tables(const tp_config& cfg, HostTables& out) {
     Loader ld;
     try {
@@ -805,6 +809,20 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             for (uint32_t k = 0; k < 20; ++k) if (folded(widen(kSafeList[k])) == fs) f |= k << FL_SAFE_IDX_SHIFT;
         }
         if (ld.known.contains(s)) f |= FL_KNOWN;
+        {   // BuildReviewRecord's subject-token tests, Program.cs:829-837 (ordinal-ignore-case: on the folded string)
+            const W fs = folded(s);
+            auto holds = [&](const char* w) { return fs.find(widen(w)) != W::npos; };
+            if (ld.subject.contains(s) || holds("BOYS") || holds("GIRLS")) {
+                static const char* const kMale[8] = {"boy", "1boy", "2boys", "3boys", "4boys", "multiple_boys", "male_focus", "yaoi"};   // :30-32
+                for (const char* m : kMale) if (fs == folded(widen(m))) f |= FL_SUBJ_MALE;
+                if (holds("GIRL")) f |= FL_SUBJ_GIRL;
+                bool multi = fs.size() >= 9 && fs.substr(0, 9) == widen("MULTIPLE_");
+                size_t d = 0;
+                while (d < fs.size() && fs[d] >= '0' && fs[d] <= '9') ++d;
+                if (d > 0) { const W r = fs.substr(d); multi |= r == widen("GIRL") || r == widen("GIRLS") || r == widen("BOY") || r == widen("BOYS"); }
+                if (multi) f |= FL_SUBJ_MULTI;
+            }
+        }
         out.flags[i] = f;
     }
     out.str_off[N] = (uint32_t)out.str_bytes.size();
@@ -930,6 +948,10 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     for (uint32_t k = 0; k < sc.n_always; ++k) sc.always_ids[k] = id_of(always_final[k]);
     sc.n_fallback = 0;
     sc.feet_n = feet_id; sc.penis_n = penis_id; sc.footjob_n = footjob_id;
+    {   // BannedFinalTags in the order OrderBy(OrdinalIgnoreCase) lists them (Program.cs:828): compared upper-cased
+        static const char* const kBannedSorted[N_BANNED] = {"1boy", "2boys", "3boys", "4boys", "boy", "male", "male_focus", "multiple_boys", "yaoi"};
+        for (int k = 0; k < N_BANNED; ++k) sc.banned_ids[k] = id_of(widen(kBannedSorted[k]));
+    }
     sc.drop_unknown = (ld.known_found && ld.strict) ? 1 : 0;
     sc.allow_nonempty = ld.allow.size() > 0 ? 1 : 0;
     sc.known_active = (ld.known_found && ld.known.size() > 0) ? 1 : 0;

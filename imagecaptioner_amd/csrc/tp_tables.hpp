@@ -54,6 +54,9 @@ void compile_tables(const tp_config& cfg, HostTables& out);
 // derives the final-set form the wave-per-file kernel starts from.
 void set_fallback(const HostTables& ht, DevTables& dt, const uint32_t* ids, uint32_t n);
 
+// a < b under StringComparer.OrdinalIgnoreCase (UTF-16 code units, upper-cased the invariant way), both UTF-8.
+bool less_ordinal_ignore_case(const std::string& a, const std::string& b);
+
 // A DevTables whose pointers address the HostTables vectors themselves (host-side logic checks).
 DevTables bind_host_pointers(const HostTables& ht);
 

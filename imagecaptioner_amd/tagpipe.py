@@ -20,7 +20,7 @@ EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_format_top_tags", "tp_get_last_timing",
     "tp_triage_lines", "tp_run_merged", "tp_format_fired_rules", "tp_needtag_text", "tp_format_side_files",
-    "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows",
+    "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows", "tp_review_csv_header", "tp_format_review_rows",
 )
 
 
@@ -66,6 +66,9 @@ def load_library():
     L.tp_audit_header.restype = C.c_char_p
     L.tp_format_audit_rows.argtypes = [C.c_void_p, C.POINTER(tp_result), C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64,
                                        C.c_void_p, C.POINTER(C.c_uint64)]
+    L.tp_review_csv_header.restype = C.c_char_p
+    L.tp_format_review_rows.argtypes = [C.c_void_p, C.POINTER(tp_result), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p,
+                                        C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     _LIB = L
     return L
 
@@ -82,7 +85,10 @@ class BatchResult:
         self.histogram_other = histogram_other
         self.fired = fired                      # uint32[n, fired_words]
         self.facet_choice = facet_choice        # uint16[n, n_facets]
-        self.audit_lists = None                 # audit runs: per file (final_tags, evidence_tags, dropped_tags_with_reason) as bytes, ';'-joined
+        self.audit_lists = None                 # audit runs: per file (final_tags, evidence_tags, dropped_tags_with_reason) as bytes, ';'-joined,
+                                                #             then (top tagger tags, unknown caption tags), "\n"-separated
+        self.review_jsonl = None                # audit runs given image and caption paths: per file the review_candidates.jsonl / .csv line
+        self.review_csv = None                  #             (bytes, newline included; b"" where the reference writes no record)
         self.audit_rows = None                  # audit runs: per file the audit.csv line (bytes, newline included)
 
     @property
@@ -219,9 +225,9 @@ class TagPipe:
         n = int(res.n_files)
         a = tp_audit()
         self._check(self._L.tp_get_audit(C.byref(res), C.byref(a)))
-        offs = np.ctypeslib.as_array(a.offsets, shape=(3 * n + 1,)).copy()
-        text = C.string_at(a.text, int(offs[3 * n]))
-        lists = [tuple(text[int(offs[3 * i + c]):int(offs[3 * i + c + 1])] for c in range(3)) for i in range(n)]
+        offs = np.ctypeslib.as_array(a.offsets, shape=(5 * n + 1,)).copy()
+        text = C.string_at(a.text, int(offs[5 * n]))
+        lists = [tuple(text[int(offs[5 * i + c]):int(offs[5 * i + c + 1])] for c in range(5)) for i in range(n)]
         names = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in audit["names"]]
         assert len(names) == n
         noffs = np.zeros(n + 1, dtype=np.uint64)
@@ -244,6 +250,38 @@ class TagPipe:
         raw = buf.tobytes()
         return lists, [raw[int(roffs[i]):int(roffs[i + 1])] for i in range(n)]
 
+    def review_csv_header(self):
+        return self._L.tp_review_csv_header()
+
+    def _collect_review(self, res, audit, fmt):
+        """tp_format_review_rows; audit also holds "image_paths", "caption_paths" and "thresholds"."""
+        n = int(res.n_files)
+
+        def pack(strs):
+            bs = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in strs]
+            o = np.zeros(n + 1, dtype=np.uint64)
+            if n:
+                o[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+            return np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy(), o
+        ia, io_ = pack(audit["image_paths"])
+        ca, co = pack(audit["caption_paths"])
+        vf = audit.get("vocab_file")
+        vf = None if vf is None else vf.encode("utf-8")
+        th = audit["thresholds"].encode("utf-8")
+        roffs = np.zeros(n + 1, dtype=np.uint64)
+        need = C.c_uint64()
+        rc = self._L.tp_format_review_rows(self._h, C.byref(res), fmt, ia.ctypes.data, io_.ctypes.data, ca.ctypes.data, co.ctypes.data, th, vf, None, 0,
+                                           roffs.ctypes.data, C.byref(need))
+        buf = np.zeros(max(need.value, 1), dtype=np.uint8)
+        if need.value:
+            assert rc == TP_E_CAPACITY, rc
+            self._check(self._L.tp_format_review_rows(self._h, C.byref(res), fmt, ia.ctypes.data, io_.ctypes.data, ca.ctypes.data, co.ctypes.data, th, vf,
+                                                      buf.ctypes.data, need.value, roffs.ctypes.data, C.byref(need)))
+        else:
+            self._check(rc)
+        raw = buf.tobytes()
+        return [raw[int(roffs[i]):int(roffs[i + 1])] for i in range(n)]
+
     def _collect(self, res, audit=None):
         n = int(res.n_files)
         total = int(res.caption_offsets[n]) if n else 0
@@ -257,6 +295,8 @@ class TagPipe:
         out = BatchResult(caps, offs, ver, res.counters.as_dict(), hist, int(res.histogram_other), fired, fc)
         if audit is not None:
             out.audit_lists, out.audit_rows = self._collect_audit(res, audit)
+            if "image_paths" in audit:
+                out.review_jsonl, out.review_csv = self._collect_review(res, audit, 0), self._collect_review(res, audit, 1)
         self._L.tp_release(self._h, C.byref(res))
         return out
 

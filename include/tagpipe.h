@@ -312,16 +312,22 @@ int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t
  *                                  FormatCaptionSingleLine normalises them again
  *   TP_AUDIT_EVIDENCE  evidenceTags after ExpandImpliedTags (Program.cs:301-302), in insertion order
  *   TP_AUDIT_DROPPED   finalSelection.DroppedTagsWithReason: "{tag}:invalid_tag" / "{tag}:policy_drop" (Program.cs:630-631, 682)
- * Column c of file i is text[offsets[3 * i + c] .. offsets[3 * i + c + 1]); tp_get_audit's pointers live as long as the
- * result.  In audit mode every file takes the thread-per-file kernel (the wave-per-file kernels do not keep these lists),
+ * and two lists of the review record (BuildReviewRecord, Program.cs:826-868), entries separated by "\n":
+ *   TP_AUDIT_TOP       TopJoyTags: the tags of the 20 best raw candidates by score, then order (Program.cs:860)
+ *   TP_AUDIT_UNKNOWN   the caption's tags outside the vocabulary, in caption order (GetUnknownTags before its sort, Program.cs:817-821)
+ * Column c of file i is text[offsets[TP_AUDIT_COLS * i + c] .. offsets[TP_AUDIT_COLS * i + c + 1]); tp_get_audit's pointers live
+ * as long as the result.  In audit mode every file takes the thread-per-file kernel (the wave-per-file kernels do not keep these lists),
  * so a run is slower than without it.  n_selected in the verdicts is exact in every mode; n_evidence is counted.
  */
 #define TP_AUDIT_KEPT     0
 #define TP_AUDIT_EVIDENCE 1
 #define TP_AUDIT_DROPPED  2
+#define TP_AUDIT_TOP      3
+#define TP_AUDIT_UNKNOWN  4
+#define TP_AUDIT_COLS     5
 typedef struct tp_audit {
     const uint8_t*  text;
-    const uint64_t* offsets;   /* 3 * n_files + 1 */
+    const uint64_t* offsets;   /* TP_AUDIT_COLS * n_files + 1 */
 } tp_audit;
 int tp_set_audit(tp_ctx* ctx, int on);
 int tp_get_audit(const tp_result* res, tp_audit* out);
@@ -342,6 +348,25 @@ const char* tp_audit_header(void);
  */
 int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t* names, const uint64_t* name_offsets, const char* vocab_file,
                          const char* used_profile, uint8_t* out, uint64_t capacity, uint64_t* out_offsets, uint64_t* needed);
+
+/*
+ * The review log (BuildReviewRecord, AppendReviewLog, Program.cs:826-890): per file the line appended to
+ * review_candidates.jsonl (format TP_REVIEW_JSONL: JsonSerializer.Serialize of the record, Program.cs:874, properties in the
+ * order of Program.cs:415-431) or to review_candidates.csv (TP_REVIEW_CSV, Program.cs:875-881; tp_review_csv_header() is its
+ * first line, Program.cs:886), each followed by the configured newline, and empty for files BuildReviewRecord returns null
+ * for (Program.cs:845) and for files with TP_F_UNSUPPORTED.  image_paths / caption_paths are imagePath and txtPath of every
+ * file (UTF-8, with their own offsets arrays); thresholds_used is the record's ThresholdsUsed text (Program.cs:847-849);
+ * vocab_file is KnownTagDictionaryPath or NULL.  Which banned and subject tokens the raw candidates held comes from the
+ * device (per-string facts compiled at load; "\d" of Program.cs:837 is taken as the ASCII digits).  rawCandidates are the
+ * candidates the run was given (the reference passes joyCandidates, which are the final candidates when the OpenAI passes
+ * are off).  res must come from a run in audit mode.  Output conventions as tp_format_audit_rows.
+ */
+#define TP_REVIEW_JSONL 0
+#define TP_REVIEW_CSV   1
+const char* tp_review_csv_header(void);
+int tp_format_review_rows(const tp_ctx* ctx, const tp_result* res, int format, const uint8_t* image_paths, const uint64_t* image_offsets,
+                          const uint8_t* caption_paths, const uint64_t* caption_offsets, const char* thresholds_used, const char* vocab_file,
+                          uint8_t* out, uint64_t capacity, uint64_t* out_offsets, uint64_t* needed);
 
 int tp_get_last_timing(const tp_ctx* ctx, tp_timing* out);
 

@@ -58,6 +58,8 @@ def lib():
         L.orc_detail_json.argtypes = [C.POINTER(orc_result), C.c_uint64]
         L.orc_audit_row.restype = C.c_char_p
         L.orc_audit_row.argtypes = [C.POINTER(orc_result), C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.orc_review_row.restype = C.c_char_p
+        L.orc_review_row.argtypes = [C.c_void_p, C.POINTER(orc_result), C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
         L.orc_normalize_tag.restype = C.c_char_p
         L.orc_normalize_tag.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int]
         L.orc_classify_tag.argtypes = [C.c_void_p, C.c_char_p]
@@ -207,6 +209,13 @@ class Oracle:
             vf = audit.get("vocab_file")
             out.audit_rows = [self._L.orc_audit_row(C.byref(res), i, audit["names"][i].encode("utf-8"), None if vf is None else vf.encode("utf-8"),
                                                     audit["used_profile"].encode("utf-8")) for i in range(n)]
+            if "image_paths" in audit:
+                # review_candidates.jsonl / .csv lines (Program.cs:871-890), no newline; b"" where BuildReviewRecord returns null
+                vfb = None if vf is None else vf.encode("utf-8")
+                th = audit["thresholds"].encode("utf-8")
+                out.review_jsonl, out.review_csv = [
+                    [self._L.orc_review_row(self._h, C.byref(res), i, fmt, audit["image_paths"][i].encode("utf-8"), audit["caption_paths"][i].encode("utf-8"), th, vfb)
+                     for i in range(n)] for fmt in (0, 1)]
         self._L.orc_release(C.byref(res))
         return out
 

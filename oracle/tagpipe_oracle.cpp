@@ -217,6 +217,8 @@ struct FileDetail {
     std::vector<S> fired, dropped, droppedMale, unknown, evidence, finalTags, covDetails, captionTags;
     S stopReason, rejectReason;
     std::vector<S> coverageTrace;
+    // BuildReviewRecord's result (Program.cs:826-868); present == false: it returned null
+    struct Review { bool present = false; std::vector<S> reasons, banned, dropped, top, unknown; int finalTagCount = 0; bool shortCaption = false; } review;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -763,6 +765,54 @@ struct Engine {
         return distinct_oic(v);
     }
 
+    // ---- Program.cs:826-868 (the fields that do not depend on paths and options) --------------
+    // Regex ^\d+(girl|girls|boy|boys)$ with IgnoreCase (:837): \d is taken as the ASCII digits here (.NET's also matches the
+    // other Unicode decimal digits: no test of the reference pins either reading).
+    static bool MultiPersonCount(const S& t) {
+        size_t d = 0;
+        while (d < t.size() && t[d] >= '0' && t[d] <= '9') ++d;
+        if (d == 0) return false;
+        S r = fold(t.substr(d));
+        return r == fold(u("girl")) || r == fold(u("girls")) || r == fold(u("boy")) || r == fold(u("boys"));
+    }
+    FileDetail::Review BuildReviewRecord(const std::vector<Candidate>& rawCandidates, const Selection& selection, const std::vector<S>& unknownFinalTags,
+                                         bool shortCaption, size_t traceCount, const S& coverageStopReason) const {
+        std::vector<S> rawTokens;
+        for (auto& c : rawCandidates) { S t = NormalizeTag(c.tag); if (!is_blank(t)) rawTokens.push_back(t); }
+        std::vector<S> bannedDetected;
+        for (auto& t : rawTokens) if (BannedFinalTags.has(t)) bannedDetected.push_back(t);
+        bannedDetected = distinct_oic(bannedDetected);
+        sort_oic(bannedDetected);
+        std::vector<S> subjectTokens;
+        for (auto& t : rawTokens) if (SubjectTokens.has(t) || contains(fold(t), fold(u("boys"))) || contains(fold(t), fold(u("girls")))) subjectTokens.push_back(t);
+        subjectTokens = distinct_oic(subjectTokens);
+        bool hasMale = !bannedDetected.empty(), hasGirl = false, hasMultiPerson = false;
+        for (auto& t : subjectTokens) {
+            if (MaleSubjectTokens.has(t)) hasMale = true;
+            if (contains(fold(t), fold(u("girl")))) hasGirl = true;
+            if (starts_with_oic(t, u("multiple_")) || MultiPersonCount(t)) hasMultiPerson = true;
+        }
+        FileDetail::Review r;
+        if (hasMale) r.reasons.push_back(u("male_subject_token"));
+        if (hasMale && hasGirl) r.reasons.push_back(u("mixed_subject_tokens"));
+        if (hasMultiPerson) r.reasons.push_back(u("multi_person"));
+        if (shortCaption) r.reasons.push_back(u("short_caption"));
+        bool hasCoverageLog = traceCount > 1 || fold(coverageStopReason) != fold(u("coverage_satisfied"));
+        if (r.reasons.empty() && bannedDetected.empty() && unknownFinalTags.empty() && !hasCoverageLog) return r;   // null
+        r.present = true;
+        r.reasons = distinct_oic(r.reasons);
+        r.banned = bannedDetected;
+        r.dropped = selection.droppedMale;
+        r.finalTagCount = (int)selection.tags.size();
+        r.shortCaption = shortCaption;
+        std::vector<const Candidate*> byScore;
+        for (auto& c : rawCandidates) byScore.push_back(&c);
+        std::stable_sort(byScore.begin(), byScore.end(), [](const Candidate* a, const Candidate* b) { return a->score != b->score ? a->score > b->score : a->order < b->order; });
+        for (size_t k = 0; k < byScore.size() && k < 20; ++k) r.top.push_back(byScore[k]->tag);
+        r.unknown = unknownFinalTags;
+        return r;
+    }
+
     // ---- the pure span, Program.cs:223-229, 246-248, 292-329 (OpenAI branch off) ------------
     void run_candidates(const std::vector<Candidate>& finalCandidates, bool lineRejected, std::string& caption, tp_verdict& v,
                         FileDetail* det, uint32_t* firedBits, size_t firedWords, uint16_t* facetChoice, std::vector<S>* captionTagsOut) const {
@@ -831,6 +881,7 @@ struct Engine {
             // coverageTrace's only entry when the OpenAI passes are off, Program.cs:228
             auto bar = [](const std::vector<S>& v) { S o; for (size_t i = 0; i < v.size(); ++i) { if (i) o += u("|"); o += v[i]; } return o; };
             const std::string cnt = std::to_string(finalSelection.tags.size());
+            det->review = BuildReviewRecord(finalCandidates, finalSelection, unknown, isLow, /*traceCount=*/1, stop);   // :328
             det->coverageTrace = {u("pass0_joy missing=") + bar(coverage.missingForPrompt) + u(" required_missing=") + bar(coverage.missingRequired) +
                                   u(" details=") + bar(coverage.details) + u(" tags=") + u(cnt.c_str())};
         }
@@ -1469,6 +1520,72 @@ const char* orc_audit_row(orc_result* r, uint64_t i, const char* filename, const
     csv_field(used_profile, o); o += ',';
     csv_field(to8(d.stopReason), o); o += ',';
     csv_field(semi(d.coverageTrace), o);
+    return o.c_str();
+}
+
+// System.Text.Json's default encoder on a string (JsonSerializer.Serialize, Program.cs:874): Basic Latin stays except the
+// control characters, DEL and " & ' + < > \ `; backslash and \b \f \n \r \t have short escapes; all else is \uXXXX (upper-case hex).
+static void stj_string(const S& s, std::string& o) {
+    static const char* const hex = "0123456789ABCDEF";
+    o += '"';
+    for (C c : s) {
+        unsigned v = (unsigned)c;
+        auto unit = [&]() { o += "\\u"; o += hex[(v >> 12) & 15]; o += hex[(v >> 8) & 15]; o += hex[(v >> 4) & 15]; o += hex[v & 15]; };
+        if (v == '\\') o += "\\\\";
+        else if (v == '\b') o += "\\b";
+        else if (v == '\f') o += "\\f";
+        else if (v == '\n') o += "\\n";
+        else if (v == '\r') o += "\\r";
+        else if (v == '\t') o += "\\t";
+        else if (v < 0x20 || v >= 0x7F || v == '"' || v == '&' || v == '\'' || v == '+' || v == '<' || v == '>' || v == '`') unit();
+        else o += (char)v;
+    }
+    o += '"';
+}
+static void stj_list(const std::vector<S>& v, std::string& o) {
+    o += '[';
+    for (size_t k = 0; k < v.size(); ++k) { if (k) o += ','; stj_string(v[k], o); }
+    o += ']';
+}
+// The line AppendReviewLog appends for file i (Program.cs:871-890), without the newline: format 0 = review_candidates.jsonl,
+// 1 = review_candidates.csv; "" when BuildReviewRecord returned null (Program.cs:336).  Needs detail != 0.
+const char* orc_review_row(void* ctx, orc_result* r, uint64_t i, int format, const char* image_path, const char* caption_path, const char* thresholds_used,
+                           const char* vocab_file) {
+    Ctx* cx = (Ctx*)ctx;
+    Batch* b = (Batch*)r->opaque;
+    std::string& o = b->detailText;
+    o.clear();
+    if (i >= b->details.size() || !b->details[i].review.present) return o.c_str();
+    const FileDetail& d = b->details[i];
+    auto w = [](const char* p) { return utf8_to_16((const uint8_t*)p, std::strlen(p)); };
+    auto semi = [](const std::vector<S>& v) { std::string x; for (size_t k = 0; k < v.size(); ++k) { if (k) x += ';'; x += to8(v[k]); } return x; };
+    const bool found = cx->eng.KnownTagDictionaryFound;
+    const std::string count = std::to_string(cx->eng.KnownTags.size());
+    const std::string vocab = vocab_file ? vocab_file : "";                                  // KnownTagDictionaryPath ?? ""
+    if (format == 0) {
+        o += "{\"ImagePath\":"; stj_string(w(image_path), o);
+        o += ",\"CaptionPath\":"; stj_string(w(caption_path), o);
+        o += ",\"Reasons\":"; stj_list(d.review.reasons, o);
+        o += ",\"BannedTokensDetected\":"; stj_list(d.review.banned, o);
+        o += ",\"DroppedTags\":"; stj_list(d.review.dropped, o);
+        o += ",\"FinalTagCount\":" + std::to_string(d.review.finalTagCount);
+        o += std::string(",\"ShortCaption\":") + (d.review.shortCaption ? "true" : "false");
+        o += ",\"ThresholdsUsed\":"; stj_string(w(thresholds_used), o);
+        o += ",\"TopJoyTags\":"; stj_list(d.review.top, o);
+        o += ",\"UnknownFinalTags\":"; stj_list(d.review.unknown, o);
+        o += std::string(",\"KnownTagDictionaryFound\":") + (found ? "true" : "false");
+        o += ",\"KnownTagDictionaryCount\":" + count;
+        o += ",\"KnownTagDictionaryPath\":"; stj_string(w(vocab.c_str()), o);
+        o += ",\"CoverageTrace\":"; stj_list(d.coverageTrace, o);
+        o += ",\"CoverageStopReason\":"; stj_string(d.stopReason, o);
+        o += '}';
+    } else {
+        csv_field(image_path, o); o += ','; csv_field(caption_path, o); o += ','; csv_field(semi(d.review.reasons), o); o += ',';
+        csv_field(semi(d.review.banned), o); o += ','; csv_field(semi(d.review.dropped), o); o += ','; csv_field(std::to_string(d.review.finalTagCount), o); o += ',';
+        csv_field(d.review.shortCaption ? "true" : "false", o); o += ','; csv_field(thresholds_used, o); o += ','; csv_field(semi(d.review.top), o); o += ',';
+        csv_field(semi(d.review.unknown), o); o += ','; csv_field(found ? "true" : "false", o); o += ','; csv_field(count, o); o += ',';
+        csv_field(vocab, o); o += ','; csv_field(to8(d.stopReason), o); o += ','; csv_field(semi(d.coverageTrace), o);
+    }
     return o.c_str();
 }
 

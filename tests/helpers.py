@@ -58,7 +58,7 @@ def sim_lib():
         L.sim_triage_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         L.sim_run_audit.restype = C.c_longlong
         L.sim_run_audit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64,
-                                    C.c_void_p, C.c_void_p]
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
         _SIM = L
     return _SIM
 
@@ -190,21 +190,22 @@ class HostSim:
         ptr = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)
         tb, sb, sc, sr = ptr(tag_begin, np.uint64), ptr(secondary_begin, np.uint64), ptr(scores, np.float64), ptr(sources, np.uint8)
         n = (len(tb) if tb is not None else len(offsets)) - 1
-        offs3 = np.zeros(3 * n + 1, dtype=np.uint64)
+        offs3 = np.zeros(5 * n + 1, dtype=np.uint64)
         ver = np.zeros(n, dtype=VERDICT_DTYPE)
+        self.review_bits = np.zeros(n, dtype=np.uint32)
         cap = 1 << 20
         while True:
             text = np.zeros(cap, dtype=np.uint8)
             d = lambda a: None if a is None else a.ctypes.data
             rc = self._L.sim_run_audit(self._h, arena.ctypes.data, offsets.ctypes.data, d(tb), d(sb), d(sc), d(sr), int(secondary_cap), n, text.ctypes.data, cap,
-                                       offs3.ctypes.data, ver.ctypes.data)
+                                       offs3.ctypes.data, ver.ctypes.data, self.review_bits.ctypes.data)
             if rc == -1:
                 cap *= 4
                 continue
             assert rc >= 0, "audit list sizes reported by the pipeline differ from the emitted text"
             break
         raw = text.tobytes()
-        return [tuple(raw[int(offs3[3 * i + c]):int(offs3[3 * i + c + 1])] for c in range(3)) for i in range(n)], ver
+        return [tuple(raw[int(offs3[5 * i + c]):int(offs3[5 * i + c + 1])] for c in range(5)) for i in range(n)], ver
 
     def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
         arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
@@ -222,6 +223,32 @@ class HostSim:
 def oracle_audit_lists(want):
     """(final_tags, evidence_tags, dropped_tags_with_reason) per file, ';'-joined bytes, from an oracle result run with detail."""
     return [tuple(";".join(d[k]).encode("utf-8") for k in ("final_tags", "evidence", "dropped")) for d in want.details]
+
+
+BANNED_SORTED = ["1boy", "2boys", "3boys", "4boys", "boy", "male", "male_focus", "multiple_boys", "yaoi"]   # Program.cs:33-35 under OrderBy(OrdinalIgnoreCase)
+
+
+def check_review_facts(lists, review_bits, verdicts, want):
+    """The device-side facts behind a review record (banned-token bits, subject-token bits -> reasons; top tagger tags; unknown caption
+    tags) against the oracle's record, taken from its JSON line (want.review_jsonl, b"" where the reference writes none)."""
+    import json
+    for i, line in enumerate(want.review_jsonl):
+        rb = int(review_bits[i])
+        banned = [BANNED_SORTED[k] for k in range(9) if rb >> k & 1]
+        male, girl, multi, low = bool(banned) or bool(rb >> 16 & 1), bool(rb >> 17 & 1), bool(rb >> 18 & 1), bool(int(verdicts["flags"][i]) & 1)
+        reasons = (["male_subject_token"] if male else []) + (["mixed_subject_tokens"] if male and girl else []) + (["multi_person"] if multi else []) + \
+                  (["short_caption"] if low else [])
+        top = lists[i][3].decode("utf-8").split("\n") if lists[i][3] else []
+        unknown = lists[i][4].decode("utf-8").split("\n") if lists[i][4] else []
+        if not line:
+            assert not reasons and not banned and not unknown and int(verdicts["coverage"][i]) == 0x3F, i
+            continue
+        rec = json.loads(line.decode("utf-8"))
+        assert rec["Reasons"] == reasons, (i, rec["Reasons"], reasons)
+        assert rec["BannedTokensDetected"] == banned and rec["DroppedTags"] == banned, (i, rec, banned)
+        assert rec["TopJoyTags"] == top, (i, rec["TopJoyTags"], top)
+        assert sorted(rec["UnknownFinalTags"]) == sorted(unknown), (i, rec["UnknownFinalTags"], unknown)
+        assert rec["FinalTagCount"] == int(verdicts["n_selected"][i])
 
 
 def assert_same_results(got, want, hist_of_got, what="", check_hist=True):

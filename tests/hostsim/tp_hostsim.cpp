@@ -388,9 +388,9 @@ int sim_triage_lines(void* h, const uint8_t* arena_in, const uint64_t* offsets, 
 
 // The audit row's three tag lists (process_file mode 3 + audit_elem, i.e. what k_pipeline and k_emit_audit do on the GPU).
 // Line ingest when tag_begin is null, scored ingest otherwise (two replies to merge when secondary_begin is given).
-// offs3 has 3 n + 1 entries; returns the text size, or -1 when cap is too small (offs3 is filled either way).
+// offs3 has AUDIT_COLS (5) n + 1 entries; returns the text size, or -1 when cap is too small (offs3 is filled either way).
 long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin, const double* scores,
-                        const uint8_t* sources, int secondary_cap, uint64_t n, uint8_t* text, uint64_t cap, uint64_t* offs3, tp_verdict* verdicts) {
+                        const uint8_t* sources, int secondary_cap, uint64_t n, uint8_t* text, uint64_t cap, uint64_t* offs3, tp_verdict* verdicts, uint32_t* review_bits) {
     const Sim& s = *(Sim*)h;
     const DevTables& t = s.dt;
     std::vector<uint8_t> all;
@@ -411,11 +411,15 @@ long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, 
         FileOut fo;
         process_file(t, in, ws, fo, fired.data(), t.n_facets ? facets.data() : nullptr, 3);
         if (verdicts) verdicts[f] = fo.verdict;
+        if (review_bits) review_bits[f] = fo.review_bits;
         for (int c = 0; c < AUDIT_COLS; ++c) {
             const size_t before = all.size();
+            bool first = true;
             for (uint32_t k = 0; k < fo.audit_cnt[c]; ++k) {
                 AuditElem e = audit_elem(t, ws, c, k);
-                if (k) all.push_back(';');
+                if (!e.keep) continue;
+                if (!first) all.push_back(c >= AUDIT_TOP ? '\n' : ';');
+                first = false;
                 all.insert(all.end(), e.p, e.p + e.len);
                 if (e.reason) all.insert(all.end(), e.reason, e.reason + AUDIT_REASON_LEN);
             }

@@ -16,7 +16,7 @@ def _check_lists(sim, orc, texts):
     for i, t in enumerate(texts):
         if ver["flags"][i] & 0x20:
             continue                                   # outside what the device code takes: no lists
-        assert lists[i] == exp[i], (t, lists[i], exp[i])
+        assert lists[i][:3] == exp[i], (t, lists[i], exp[i])
         assert ver[i].tobytes() == want.verdicts[i].tobytes(), t
 
 
@@ -46,7 +46,7 @@ def test_audit_lists_corpus(name):
     exp = oracle_audit_lists(want)
     for i in range(len(exp)):
         assert not (ver["flags"][i] & 0x20)
-        assert lists[i] == exp[i], i
+        assert lists[i][:3] == exp[i], i
     # evidence and dropped counts of the verdict agree with the lists
     for i in range(len(exp)):
         assert ver["n_dropped"][i] == (lists[i][2].count(b";") + 1 if lists[i][2] else 0)
@@ -93,7 +93,7 @@ def test_audit_lists_known_scored():
     arena, toffs, tb, scores, src = known_scored_input()
     lists, ver = sim.run_audit(arena, toffs, tag_begin=tb, scores=scores, sources=src)
     f = KNOWN_ROW[1:-1].split('","')
-    assert [x.decode() for x in lists[0]] == [f[1], f[2].replace('""', '"'), f[4].replace('""', '"')]
+    assert [x.decode() for x in lists[0][:3]] == [f[1], f[2].replace('""', '"'), f[4].replace('""', '"')]
     assert ver["n_selected"][0] == 7
 
 
@@ -110,7 +110,7 @@ def test_audit_lists_scored_and_merged(cap):
         n_dropped = 0
         for i in range(len(exp)):
             assert not (ver["flags"][i] & 0x20)
-            assert lists[i] == exp[i], (i, lists[i], exp[i])
+            assert lists[i][:3] == exp[i], (i, lists[i], exp[i])
             assert ver[i].tobytes() == want.verdicts[i].tobytes()
             n_dropped += len(want.details[i]["dropped"])
         assert n_dropped > 0
@@ -118,4 +118,100 @@ def test_audit_lists_scored_and_merged(cap):
         src = (np.arange(len(scores)) % 3).astype(np.uint8)
         want = orc.run_scored(arena, toffs, begin, scores, src, detail=True)
         lists, ver = sim.run_audit(arena, toffs, tag_begin=begin, scores=scores, sources=src)
-        assert lists == oracle_audit_lists(want)
+        assert [l[:3] for l in lists] == oracle_audit_lists(want)
+
+
+# ---- review records (BuildReviewRecord / AppendReviewLog, Program.cs:826-890) -----------------------------------------------
+def review_args(n, vocab_file="top_tags.txt"):
+    return {"names": ["%d.png" % i for i in range(n)], "vocab_file": vocab_file, "used_profile": "sgrui",
+            "image_paths": ['C:\\data\\set "a"\\%d+x.png' % i for i in range(n)], "caption_paths": ["C:\\data\\set\\%d.txt" % i for i in range(n)],
+            "thresholds": "primary=0.35;secondary=0.25"}
+
+
+SUBJECT_LINES = [
+    "1girl, smile, dress, long_hair",
+    "1boy, 1girl, smile, dress",
+    "2girls, smile, dress, long_hair, blue_eyes, standing, classroom",
+    "multiple_girls, multiple_boys, smile",
+    "3girls, 4boys, yaoi, male_focus, male, BOY, smile, dress",
+    "zz_girls_club, smile, dress, long_hair",
+    "zz_boys_team, dress, long_hair",
+    "12girls, 7boy, 3girl, x2girls, 2girlsx",
+    "multiple_zz, multiple_girls_x",
+    "girl, solo, dress, blue_hair",
+    "1girl, blue_hair, blue_eyes, dress, standing, classroom",
+    "1girl, blue_hair, blue_eyes, dress, standing, classroom, zz_unknown_b, Zz_unknown_A, _zz, zz-y",
+    "cat",
+]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(strict_known=False, strict_known_explicit=True), dict(vocabulary=None, profile=None)])
+def test_review_facts_lines(kw):
+    cfg = shipped_config(**kw)
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    texts = SUBJECT_LINES + EDGE_LINES
+    arena, offsets = pack_lines(texts)
+    want = orc.run_lines(arena, offsets, detail=True, audit=review_args(len(texts)))
+    lists, ver = sim.run_audit(arena, offsets)
+    from helpers import check_review_facts
+    keep = [i for i in range(len(texts)) if not (ver["flags"][i] & 0x20)]
+    assert len(keep) == len(texts)
+    check_review_facts(lists, sim.review_bits, ver, want)
+    assert any(want.review_jsonl)
+
+
+def test_review_facts_tagger_replies():
+    from helpers import check_review_facts
+    from test_merged_cpu import merged_inputs
+    for kw in (dict(), dict(strict_known=False, strict_known_explicit=True)):
+        cfg = shipped_config(**kw)
+        sim, orc = HostSim(cfg), Oracle(cfg)
+        arena, toffs, begin, mid, scores = merged_inputs(31, 200)
+        n = len(begin) - 1
+        want = orc.run_merged(arena, toffs, begin, mid, scores, 15, detail=True, audit=review_args(n))
+        lists, ver = sim.run_audit(arena, toffs, tag_begin=begin, secondary_begin=mid, scores=scores, secondary_cap=15)
+        check_review_facts(lists, sim.review_bits, ver, want)
+        src = (np.arange(len(scores)) % 3).astype(np.uint8)
+        want = orc.run_scored(arena, toffs, begin, scores, src, detail=True, audit=review_args(n))
+        lists, ver = sim.run_audit(arena, toffs, tag_begin=begin, scores=scores, sources=src)
+        check_review_facts(lists, sim.review_bits, ver, want)
+
+
+# Hand-derived from Program.cs:826-890 on the shipped tables for the tagger reply below: "1boy" is banned (male_subject_token; with
+# "2girls" also mixed_subject_tokens and multi_person); no outfit tag, so the caption is short and outfit is missing; "zz_b" and "Zz_A"
+# normalise to "zz_b" / "zz_a", are valid and not in the vocabulary -- under the shipped (strict) vocabulary they are dropped; the
+# unknown final tags are the trigger and the seven facet defaults, none of which top_tags.txt holds, in ordinal-ignore-case order
+# (Program.cs:817-823); the top tags are the candidates by score, then order; System.Text.Json writes " as \u0022, + as \u002B
+# and \ as \; Csv doubles the quotes.
+REVIEW_TAGS = ["2girls", "1boy", "blue_hair", "blue_eyes", "standing", "classroom", "zz_b", "Zz_A"]
+REVIEW_SCORES = [0.9, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.95]
+REVIEW_JSON = ('{"ImagePath":"C:\\\\data\\\\set \\u0022a\\u0022\\\\0\\u002Bx.png","CaptionPath":"C:\\\\data\\\\set\\\\0.txt",'
+               '"Reasons":["male_subject_token","mixed_subject_tokens","multi_person","short_caption"],"BannedTokensDetected":["1boy"],"DroppedTags":["1boy"],'
+               '"FinalTagCount":7,"ShortCaption":true,"ThresholdsUsed":"primary=0.35;secondary=0.25",'
+               '"TopJoyTags":["zz_a","2girls","1boy","blue_hair","blue_eyes","standing","classroom","zz_b"],'
+               '"UnknownFinalTags":["sgrui","unknown_ejaculation","unknown_expression","unknown_fluids","unknown_gaze","unknown_mouth","unknown_pov","unknown_underwear"],'
+               '"KnownTagDictionaryFound":true,"KnownTagDictionaryCount":5811,"KnownTagDictionaryPath":"top_tags.txt",'
+               '"CoverageTrace":["pass0_joy missing=outfit required_missing=outfit details=identity=ok|hair=ok|eyes=ok|outfit=missing|pose_action=ok|background_scene=ok tags=7"],'
+               '"CoverageStopReason":"openai_disabled_or_missing_api_key"}')
+REVIEW_CSV = ('"C:\\data\\set ""a""\\0+x.png","C:\\data\\set\\0.txt","male_subject_token;mixed_subject_tokens;multi_person;short_caption","1boy","1boy","7","true",'
+              '"primary=0.35;secondary=0.25","zz_a;2girls;1boy;blue_hair;blue_eyes;standing;classroom;zz_b",'
+              '"sgrui;unknown_ejaculation;unknown_expression;unknown_fluids;unknown_gaze;unknown_mouth;unknown_pov;unknown_underwear","true","5811","top_tags.txt",'
+              '"openai_disabled_or_missing_api_key",'
+              '"pass0_joy missing=outfit required_missing=outfit details=identity=ok|hair=ok|eyes=ok|outfit=missing|pose_action=ok|background_scene=ok tags=7"')
+
+
+def review_scored_input():
+    arena, toffs = pack_lines(REVIEW_TAGS)
+    return arena, toffs, np.array([0, len(REVIEW_TAGS)], dtype=np.uint64), np.array(REVIEW_SCORES), np.zeros(len(REVIEW_TAGS), np.uint8)
+
+
+def test_oracle_review_row_known_answer():
+    orc = Oracle(shipped_config())
+    res = orc.run_scored(*review_scored_input(), audit=review_args(1))
+    assert res.review_jsonl[0].decode("utf-8") == REVIEW_JSON
+    assert res.review_csv[0].decode("utf-8") == REVIEW_CSV
+    # nothing to report (no vocabulary file, so no unknown tags either): no record (Program.cs:845).  "1girl" in the reply would
+    # count as multi_person: it matches ^\\d+(girl|girls|boy|boys)$ (Program.cs:837)
+    arena, offsets = pack_lines(["girl, blue_hair, blue_eyes, dress, standing, classroom"])
+    res = Oracle(shipped_config(vocabulary=None)).run_lines(arena, offsets, audit=review_args(1, vocab_file=None))
+    assert res.review_jsonl == [b""] and res.review_csv == [b""]

@@ -157,10 +157,71 @@ def _check_audit(got, want, nl=b"\n"):
     assert len(got.audit_rows) == n
     for i in range(n):
         if got.verdicts["flags"][i] & 0x20:
-            assert got.audit_rows[i] == b"" and got.audit_lists[i] == (b"", b"", b"")
+            assert got.audit_rows[i] == b"" and got.audit_lists[i] == (b"",) * 5
             continue
-        assert got.audit_lists[i] == exp_lists[i], (i, got.audit_lists[i], exp_lists[i])
+        assert got.audit_lists[i][:3] == exp_lists[i], (i, got.audit_lists[i], exp_lists[i])
         assert got.audit_rows[i] == want.audit_rows[i] + nl, (i, got.audit_rows[i], want.audit_rows[i])
+
+
+def _review_args(n, vocab_file="top_tags.txt", used_profile="sgrui"):
+    from test_audit_cpu import review_args
+    a = review_args(n, vocab_file)
+    a["used_profile"] = used_profile
+    return a
+
+
+def _check_review(got, want, nl=b"\n"):
+    """review_candidates.jsonl / .csv lines (Program.cs:871-890) against the oracle's, file by file; b"" where no record is written."""
+    n = len(want.review_jsonl)
+    assert len(got.review_jsonl) == n and len(got.review_csv) == n
+    for i in range(n):
+        if got.verdicts["flags"][i] & 0x20:
+            assert got.review_jsonl[i] == b"" and got.review_csv[i] == b""
+            continue
+        assert got.review_jsonl[i] == (want.review_jsonl[i] + nl if want.review_jsonl[i] else b""), (i, got.review_jsonl[i], want.review_jsonl[i])
+        assert got.review_csv[i] == (want.review_csv[i] + nl if want.review_csv[i] else b""), (i, got.review_csv[i], want.review_csv[i])
+
+
+def test_review_rows_known_answer():
+    from test_audit_cpu import REVIEW_CSV, REVIEW_JSON, review_args, review_scored_input
+    p = pipe_for(shipped_config())
+    got = p.run_scored(*review_scored_input(), audit=review_args(1))
+    assert got.review_jsonl[0].decode("utf-8") == REVIEW_JSON + "\n"
+    assert got.review_csv[0].decode("utf-8") == REVIEW_CSV + "\n"
+    assert p.review_csv_header() == (b"image_path,caption_path,reasons,banned_tokens_detected,dropped_tags,final_tag_count,short_caption,thresholds_used,"
+                                     b"top_joy_tags,unknown_final_tags,known_dict_found,known_dict_count,known_dict_path,coverage_stop_reason,coverage_trace")
+    p = pipe_for(shipped_config(vocabulary=None))
+    got = p.run_texts(["girl, blue_hair, blue_eyes, dress, standing, classroom"], audit=review_args(1, vocab_file=None))
+    assert got.review_jsonl == [b""] and got.review_csv == [b""]
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict", "novocab_w07_crlf", "c5"])
+def test_review_rows(name):
+    from test_audit_cpu import SUBJECT_LINES
+    from test_merged_cpu import merged_inputs
+    nl = b"\r\n" if name == "novocab_w07_crlf" else b"\n"
+    vf = None if name == "novocab_w07_crlf" else "top_tags.txt"
+    if name == "c5":
+        from imagecaptioner_amd.corpus import make_corpus
+        c = make_corpus("c5", 1500, seed=13)
+        cfg = Config(**c.config_kwargs)
+        arena, offsets = c.arena, c.offsets
+    else:
+        cfg = CONFIGS[name]()
+        arena, offsets = pack_lines(SUBJECT_LINES + EDGE_LINES + fuzz_lines(5, 1000))
+    p, o = pipe_for(cfg), Oracle(cfg)
+    audit = _review_args(len(offsets) - 1, vocab_file=vf)
+    got, want = p.run_lines(arena, offsets, audit=audit), o.run_lines(arena, offsets, threads=8, detail=True, audit=audit)
+    _check_review(got, want, nl)
+    _check_audit(got, want, nl)
+    assert any(got.review_jsonl)
+    if name != "c5":
+        arena, toffs, begin, mid, scores = merged_inputs(41, 800)
+        audit = _review_args(len(begin) - 1, vocab_file=vf)
+        got = p.run_merged(arena, toffs, begin, mid, scores, 15, audit=audit)
+        want = o.run_merged(arena, toffs, begin, mid, scores, 15, threads=8, detail=True, audit=audit)
+        _check_review(got, want, nl)
+        assert any(b"male_subject_token" in x for x in got.review_jsonl)
 
 
 def test_audit_row_known_answer():
