@@ -46,6 +46,36 @@ def main():
         json.dump(digests, f, indent=1)
     with open(os.path.join(HERE, "replies.json"), "w", encoding="utf-8") as f:
         json.dump(replies_golden(), f, ensure_ascii=False, indent=0)
+    write_audit_golden()
+
+
+def audit_args(n):
+    """File names, paths and option texts the audit and review lines are made with."""
+    return {"names": ["img_%03d.png" % i for i in range(n)], "vocab_file": "top_tags.txt", "used_profile": "sgrui",
+            "image_paths": ["D:\\set \"x\"\\img_%03d.png" % i for i in range(n)], "caption_paths": ["D:\\set \"x\"\\img_%03d.txt" % i for i in range(n)],
+            "thresholds": "primary=0.40;secondary=0.30"}
+
+
+def audit_inputs():
+    """The first 40 files of replies.json, both replies."""
+    import numpy as np
+    with open(os.path.join(HERE, "replies.json"), encoding="utf-8") as f:
+        files = json.load(f)["files"][:40]
+    a, offs, begin, scores = pack_tags([[tuple(x) for x in f["primary"] + f["secondary"]] for f in files])
+    mid = begin[:-1] + np.array([len(f["primary"]) for f in files], dtype=np.uint64)
+    return a, offs, begin, mid, scores
+
+
+def write_audit_golden():
+    """audit.csv and review_candidates.jsonl/.csv lines (Program.cs:871-890, 958-969) of the merged replies (cap 15), without newlines."""
+    a, offs, begin, mid, scores = audit_inputs()
+    out = {}
+    for name in ("shipped", "shipped_nonstrict"):
+        r = Oracle(CONFIGS[name]()).run_merged(a, offs, begin, mid, scores, 15, audit=audit_args(len(begin) - 1))
+        out[name] = {"audit": [x.decode("utf-8") for x in r.audit_rows], "review_jsonl": [x.decode("utf-8") for x in r.review_jsonl],
+                     "review_csv": [x.decode("utf-8") for x in r.review_csv]}
+    with open(os.path.join(HERE, "audit_rows.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=0)
 
 
 def pack_tags(files):
@@ -102,4 +132,7 @@ def replies_golden():
 
 
 if __name__ == "__main__":
-    main()
+    if "--audit-only" in sys.argv:
+        write_audit_golden()
+    else:
+        main()

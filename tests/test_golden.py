@@ -61,3 +61,19 @@ def test_replies_oracle_matches_golden(name):
         g = json.load(f)
     o = Oracle(CONFIGS[name]())
     check_replies_golden(o.run_scored, o.run_merged, o.triage_texts, name, g)
+
+
+def check_audit_golden(run_merged, name, nl=""):
+    """Shared by the oracle test here and the GPU test: audit and review lines against tests/golden/audit_rows.json."""
+    from golden.make_golden import audit_args, audit_inputs
+    with open(os.path.join(GOLDEN, "audit_rows.json"), encoding="utf-8") as f:
+        g = json.load(f)[name]
+    a, offs, begin, mid, scores = audit_inputs()
+    r = run_merged(a, offs, begin, mid, scores, 15, audit=audit_args(len(begin) - 1))
+    for key, got in (("audit", r.audit_rows), ("review_jsonl", r.review_jsonl), ("review_csv", r.review_csv)):
+        assert [x.decode("utf-8") for x in got] == [e + nl if e else e for e in g[key]], (name, key)
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict"])
+def test_audit_rows_oracle_matches_golden(name):
+    check_audit_golden(Oracle(CONFIGS[name]()).run_merged, name)

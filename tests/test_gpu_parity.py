@@ -163,6 +163,13 @@ def _check_audit(got, want, nl=b"\n"):
         assert got.audit_rows[i] == want.audit_rows[i] + nl, (i, got.audit_rows[i], want.audit_rows[i])
 
 
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict"])
+def test_audit_and_review_rows_match_committed_golden(name):
+    from golden.make_golden import CONFIGS as GC
+    from test_golden import check_audit_golden
+    check_audit_golden(pipe_for(GC[name]()).run_merged, name, nl="\n")
+
+
 def _review_args(n, vocab_file="top_tags.txt", used_profile="sgrui"):
     from test_audit_cpu import review_args
     a = review_args(n, vocab_file)
