@@ -791,6 +791,7 @@ int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t*
     if (!r || r->audit_offsets.empty()) return fail(TP_E_INVALID_ARG, "the result was not produced with tp_set_audit(ctx, 1)");
     const uint64_t n_files = res->n_files;
     if (n_files && name_offsets[n_files] && !names) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_files; ++i) if (name_offsets[i + 1] < name_offsets[i]) return fail(TP_E_INVALID_ARG, "name_offsets must be non-decreasing");
     const HostTables& h = ctx->ht;
     const uint32_t n_rules = ctx->dt.n_rules, n_facets = ctx->dt.n_facets, fw = ctx->dt.fired_words;
     const std::string nl((const char*)ctx->dt.newline, ctx->dt.newline_len);
@@ -931,6 +932,8 @@ int tp_format_review_rows(const tp_ctx* ctx, const tp_result* res, int format, c
     if (!r || r->audit_offsets.empty()) return fail(TP_E_INVALID_ARG, "the result was not produced with tp_set_audit(ctx, 1)");
     const uint64_t n_files = res->n_files;
     if (n_files && ((image_offsets[n_files] && !image_paths) || (caption_offsets[n_files] && !caption_paths))) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_files; ++i)
+        if (image_offsets[i + 1] < image_offsets[i] || caption_offsets[i + 1] < caption_offsets[i]) return fail(TP_E_INVALID_ARG, "path offsets must be non-decreasing");
     const HostTables& h = ctx->ht;
     const std::string nl((const char*)ctx->dt.newline, ctx->dt.newline_len);
     return guarded([&]() {
