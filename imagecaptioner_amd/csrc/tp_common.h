@@ -59,7 +59,7 @@ enum : uint32_t {
     // BuildReviewRecord's tests on a raw token that counts as a subject token (in SubjectTokens, or holding "boys" / "girls"; Program.cs:829-837):
     FL_SUBJ_MALE = 1u << 26,   //   it is in MaleSubjectTokens (Program.cs:30-32, 835)
     FL_SUBJ_GIRL = 1u << 27,   //   it holds "girl" (Program.cs:836)
-    FL_SUBJ_MULTI = 1u << 28,  //   it starts with "multiple_" or matches ^\d+(girl|girls|boy|boys)$ (Program.cs:837; digits: ASCII only here)
+    FL_SUBJ_MULTI = 1u << 28,  //   it starts with "multiple_" or matches ^\d+(girl|girls|boy|boys)$ (Program.cs:837; \d is the Unicode category Nd)
     FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone and that has no steps of
                                // its own: one ExpandImpliedTags round settles it; Rec::s0_flags .. s1_len describe the steps
 };

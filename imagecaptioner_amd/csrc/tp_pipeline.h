@@ -268,6 +268,39 @@ TP_HD bool make_token(const DevTables& t, FileWs& ws, uint32_t& norm_used, const
     while (i < j && is_ws8(s[i])) ++i;                 // TrimEntries / Trim()
     while (j > i && is_ws8(s[j - 1])) --j;
     if (i == j) return false;
+    {
+        // Characters outside ASCII need Unicode white-space, case and punctuation rules, which this code does not carry.  One case
+        // needs none of them: the bytes are, as they stand, an interned string that the steps before the alias lookup leave alone
+        // (such a string holds no white space, capital, or quote or punctuation at its ends): then they are the normalised string.
+        bool high = false;
+        for (uint32_t p = i; p < j; ++p) high |= s[p] >= 0x80;
+        if (high) {
+            Hasher hs;
+            for (uint32_t p = i; p < j; ++p) hs.add(s[p]);
+            const uint32_t n = j - i;
+            const uint64_t hsh = hs.done();
+            uint32_t slot = (uint32_t)hsh & t.ht_mask;
+            for (;;) {
+                const uint64_t hh = t.ht_hash[slot];
+                if (hh == 0) break;
+                if (hh == hsh) {
+                    const uint32_t id = t.ht_id[slot];
+                    if (str_len(t, id) == n) {
+                        const uint8_t* q = str_ptr(t, id);
+                        uint32_t k = 0;
+                        while (k < n && q[k] == s[i + k]) ++k;
+                        if (k == n) {
+                            if (t.slots[slot].kflags & SLOT_KEY_BASIC) { out = t.alias1[id]; return true; }
+                            break;
+                        }
+                    }
+                }
+                slot = (slot + 1) & t.ht_mask;
+            }
+            unsupported = true;
+            return false;
+        }
+    }
     while (i < j && is_quote8(s[i])) ++i;              // Trim('"', '\'', '`')
     while (j > i && is_quote8(s[j - 1])) --j;
     uint32_t tail = j;                                 // [;。、\.]+$
@@ -492,15 +525,14 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         // ---------------- NormalizeRawTagLine (Program.cs:589-605) ----------------
         const uint8_t* s = in.text;
         uint32_t a = 0, b = in.len;
-        bool has_colon = false, has_tick = false, has_crlf = false;
+        bool has_colon = false, has_tick = false, has_crlf = false, has_high = false;
         for (uint32_t p = 0; p < b; ++p) {
             uint8_t c = s[p];
-            if (c >= 0x80) unsupported = true;
+            has_high |= c >= 0x80;                              // such tokens are taken only as known strings, see make_token
             has_colon |= (c == ':');
             has_tick |= (c == '`');
             if (c == '\r' && p + 1 < b && s[p + 1] == '\n') has_crlf = true;
         }
-        if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
         if (has_crlf) {                                         // raw.Replace("\r\n", "\n")
             uint32_t k = 0;
             for (uint32_t p = 0; p < b; ++p) {
@@ -554,7 +586,11 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         else {
             uint32_t commas = 0;
             for (uint32_t p = a; p < b; ++p) commas += (s[p] == ',');
-            if (has_refusal_phrase(s, a, b) || (commas < 2 && (b - a) > 40)) rejected = true;
+            if (has_refusal_phrase(s, a, b)) rejected = true;
+            else if (commas < 2 && (b - a) > 40) {
+                if (has_high) unsupported = true;               // LooksBad counts UTF-16 units (Program.cs:1145), which are fewer than these bytes
+                else rejected = true;
+            }
         }
         if (!rejected) {
             // SplitTags -> NormalizeTag -> Length >= 2 -> !ShouldDropTag -> Distinct (Program.cs:598-602); the join and the second
@@ -606,8 +642,6 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             for (uint64_t k = lo; k < hi; ++k) {
                 const uint8_t* s = in.arena + in.tag_offsets[k];
                 uint32_t len = (uint32_t)(in.tag_offsets[k + 1] - in.tag_offsets[k]);
-                for (uint32_t p = 0; p < len; ++p) if (s[p] >= 0x80) unsupported = true;
-                if (unsupported) break;
                 H h;
                 bool nonempty = make_token(t, ws, norm_used, s, 0, len, true, h, unsupported);
                 if (unsupported) break;

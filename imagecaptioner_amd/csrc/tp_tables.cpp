@@ -818,7 +818,12 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
                 if (holds("GIRL")) f |= FL_SUBJ_GIRL;
                 bool multi = fs.size() >= 9 && fs.substr(0, 9) == widen("MULTIPLE_");
                 size_t d = 0;
-                while (d < fs.size() && fs[d] >= '0' && fs[d] <= '9') ++d;
+                auto nd = [](wc ch) {                               // \d: Unicode category Nd
+                    if (ch >= '0' && ch <= '9') return true;
+                    for (uint16_t z : kDigitZero) if (ch >= z && ch < z + 10) return true;
+                    return false;
+                };
+                while (d < fs.size() && nd(fs[d])) ++d;
                 if (d > 0) { const W r = fs.substr(d); multi |= r == widen("GIRL") || r == widen("GIRLS") || r == widen("BOY") || r == widen("BOYS"); }
                 if (multi) f |= FL_SUBJ_MULTI;
             }

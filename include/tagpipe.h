@@ -357,7 +357,7 @@ int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t*
  * for (Program.cs:845) and for files with TP_F_UNSUPPORTED.  image_paths / caption_paths are imagePath and txtPath of every
  * file (UTF-8, with their own offsets arrays); thresholds_used is the record's ThresholdsUsed text (Program.cs:847-849);
  * vocab_file is KnownTagDictionaryPath or NULL.  Which banned and subject tokens the raw candidates held comes from the
- * device (per-string facts compiled at load; "\d" of Program.cs:837 is taken as the ASCII digits).  rawCandidates are the
+ * device (per-string facts compiled at load).  rawCandidates are the
  * candidates the run was given (the reference passes joyCandidates, which are the final candidates when the OpenAI passes
  * are off).  res must come from a run in audit mode.  Output conventions as tp_format_audit_rows.
  */

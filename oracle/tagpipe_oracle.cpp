@@ -766,11 +766,15 @@ struct Engine {
     }
 
     // ---- Program.cs:826-868 (the fields that do not depend on paths and options) --------------
-    // Regex ^\d+(girl|girls|boy|boys)$ with IgnoreCase (:837): \d is taken as the ASCII digits here (.NET's also matches the
-    // other Unicode decimal digits: no test of the reference pins either reading).
+    // Regex ^\d+(girl|girls|boy|boys)$ with IgnoreCase (:837): \d is the Unicode category Nd (BMP runs from the generated table).
+    static bool IsDecimalDigit(C c) {
+        if (c >= '0' && c <= '9') return true;
+        for (int k = 0; k < kDigitZeroCount; ++k) if (c >= kDigitZero[k] && c < kDigitZero[k] + 10) return true;
+        return false;
+    }
     static bool MultiPersonCount(const S& t) {
         size_t d = 0;
-        while (d < t.size() && t[d] >= '0' && t[d] <= '9') ++d;
+        while (d < t.size() && IsDecimalDigit(t[d])) ++d;
         if (d == 0) return false;
         S r = fold(t.substr(d));
         return r == fold(u("girl")) || r == fold(u("girls")) || r == fold(u("boy")) || r == fold(u("boys"));

@@ -215,3 +215,44 @@ def test_oracle_review_row_known_answer():
     arena, offsets = pack_lines(["girl, blue_hair, blue_eyes, dress, standing, classroom"])
     res = Oracle(shipped_config(vocabulary=None)).run_lines(arena, offsets, audit=review_args(1, vocab_file=None))
     assert res.review_jsonl == [b""] and res.review_csv == [b""]
+
+
+def test_general_kernel_takes_known_non_ascii_tags():
+    """Audit mode runs every file through the thread-per-file code: it takes a tag with characters outside ASCII under the same
+    condition as the wave kernels (a known string, as written, that normalisation leaves alone) and reports the rest as unsupported."""
+    from helpers import NON_ASCII_LINES, check_non_ascii, check_review_facts, non_ascii_config
+    cfg = non_ascii_config()
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    check_non_ascii(sim.run_texts, orc)
+    texts = [t for t, taken in NON_ASCII_LINES if taken]
+    arena, offsets = pack_lines(texts)
+    want = orc.run_lines(arena, offsets, detail=True, audit=review_args(len(texts)))
+    lists, ver = sim.run_audit(arena, offsets)
+    assert [l[:3] for l in lists] == oracle_audit_lists(want)
+    check_review_facts(lists, sim.review_bits, ver, want)
+    # a line of one long tag: LooksBad counts UTF-16 units, fewer than the bytes (Program.cs:1145): left alone
+    long_one = "青" * 20
+    got = HostSim(shipped_config(vocabulary=(long_one + "\n").encode("utf-8"), vocabulary_is_json=0)).run_texts([long_one, "1girl, smile, dress"])
+    assert got.verdicts["flags"][0] & 0x20 and not got.verdicts["flags"][1] & 0x20
+
+
+def test_multi_person_digits_are_unicode_digits():
+    """^\\d+(girl|girls|boy|boys)$ (Program.cs:837): \\d matches every Unicode decimal digit.  Such a tag fails ValidTagRegex, so only a
+    tagger reply can bring it among the raw candidates (line ingest drops it before, Program.cs:600)."""
+    from helpers import check_review_facts
+    import json
+    tag = "\u0662girls"                                       # ARABIC-INDIC DIGIT TWO
+    cfg = shipped_config(vocabulary=("1girl\nsmile\ndress\nlong_hair\n%s\nx%s\n" % (tag, tag)).encode("utf-8"), vocabulary_is_json=0)
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    tags = [tag, "smile", "dress", "long_hair", "x" + tag, "smile", "dress", "long_hair"]
+    arena, toffs = pack_lines(tags)
+    begin = np.array([0, 4, 8], dtype=np.uint64)
+    scores = np.array([0.9, 0.8, 0.7, 0.6] * 2)
+    src = np.zeros(8, np.uint8)
+    want = orc.run_scored(arena, toffs, begin, scores, src, detail=True, audit=review_args(2))
+    lists, ver = sim.run_audit(arena, toffs, tag_begin=begin, scores=scores, sources=src)
+    assert not (ver["flags"] & 0x20).any()
+    assert [l[:3] for l in lists] == oracle_audit_lists(want)
+    check_review_facts(lists, sim.review_bits, ver, want)
+    assert "multi_person" in json.loads(want.review_jsonl[0])["Reasons"] and "multi_person" not in json.loads(want.review_jsonl[1])["Reasons"]
+    assert lists[0][2] == (tag + ":invalid_tag").encode("utf-8")

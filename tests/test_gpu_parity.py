@@ -231,6 +231,25 @@ def test_review_rows(name):
         assert any(b"male_subject_token" in x for x in got.review_jsonl)
 
 
+def test_audit_mode_takes_known_non_ascii_tags():
+    """Audit mode (thread-per-file kernel) takes what the wave kernels take of tags with characters outside ASCII, and the JSON line
+    escapes them the way System.Text.Json does."""
+    from helpers import NON_ASCII_LINES
+    cfg = non_ascii_config()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    texts = [t for t, _ in NON_ASCII_LINES]
+    audit = _review_args(len(texts))
+    audit["image_paths"] = ["/data/\u9752 %d.png" % i for i in range(len(texts))]
+    got, want = p.run_texts(texts, audit=audit), o.run_texts(texts, detail=True, audit=audit)
+    for i, (text, taken) in enumerate(NON_ASCII_LINES):
+        assert bool(got.verdicts["flags"][i] & 0x20) == (not taken), text
+    _check_audit(got, want)
+    _check_review(got, want)
+    assert any(b"\\u9752" in x for x in got.review_jsonl)
+    plain = p.run_texts(texts)
+    assert plain.verdicts.tobytes() == got.verdicts.tobytes() and np.array_equal(plain.captions, got.captions)
+
+
 def test_audit_row_known_answer():
     from test_audit_cpu import KNOWN_AUDIT, KNOWN_ROW, known_scored_input
     p = pipe_for(shipped_config())
