@@ -166,6 +166,17 @@ TP_HD bool lfind(const FileWs& ws, const LaneArr<H>& arr, uint32_t n, H h) {
     return false;
 }
 
+// Index of h in arr[0 .. n), or n: the same walk, eight elements at a time.
+TP_HD uint32_t lfind_idx(const FileWs& ws, const LaneArr<H>& arr, uint32_t n, H h) {
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const H v[8] = {arr[i], arr[i + 1], arr[i + 2], arr[i + 3], arr[i + 4], arr[i + 5], arr[i + 6], arr[i + 7]};
+        for (int k = 0; k < 8; ++k) if (heq(ws, v[k], h)) return i + (uint32_t)k;
+    }
+    for (; i < n; ++i) if (heq(ws, arr[i], h)) return i;
+    return n;
+}
+
 // Attributes of a string that is in no table (ASCII, already normalised).
 TP_HD uint32_t classify_dyn(const DevTables& t, const uint8_t* p, uint32_t n) {
     bool valid = n > 0 && is_tag_first8(p[0]);
@@ -400,40 +411,38 @@ TP_HD H norm_hop(const DevTables& t, const FileWs& ws, H h) {
 }
 
 // ExpandImpliedTags (Program.cs:1160-1179) on an insertion-ordered set.
+// The reference repeats whole rounds (normalise every tag, add each form that is missing, then its implied tags) until nothing
+// changes.  A tag that was there when an earlier round began has had its form and that form's implied tags added by that round,
+// and the set only grows, so visiting it again adds nothing: each round needs to visit only the tags the round before appended,
+// in their order, which appends the same tags in the same order.
 TP_HD void expand_implied(const DevTables& t, FileWs& ws, const LaneArr<H>& L, uint32_t& n, uint32_t cap, bool& overflow) {
     bool any = false;
     for (uint32_t i = 0; i < n; ++i) if (hflags(t, L[i]) & FL_EDGE) { any = true; break; }
     if (!any) return;   // every NormalizeTag is the identity and nothing has implied tags: the loop body cannot change the set
-    bool changed;
-    do {
-        changed = false;
-        uint32_t ns = 0;
-        for (uint32_t i = 0; i < n; ++i) {             // snapshot = tags.Select(NormalizeTag).Where(non-blank).Distinct().ToList()
-            H s = norm_hop(t, ws, L[i]);
-            if (hflags(t, s) & FL_BLANK) continue;
-            if (lfind(ws, ws.snap, ns, s)) continue;
-            if (ns >= ws.cap_snap) { overflow = true; return; }
-            ws.snap[ns++] = s;
-        }
-        for (uint32_t k = 0; k < ns; ++k) {
-            H tag = ws.snap[k];
-            if (!lfind(ws, L, n, tag)) {
+    uint32_t done = 0;
+    while (done < n) {
+        const uint32_t round_end = n;                  // tags appended from here on belong to the next round's snapshot
+        for (uint32_t i = done; i < round_end; ++i) {
+            const H cur = L[i];
+            if (!(hflags(t, cur) & FL_EDGE)) continue;  // its form is itself and has no implied tags
+            const H tag = norm_hop(t, ws, cur);
+            if (hflags(t, tag) & FL_BLANK) continue;
+            if (tag != cur && !lfind(ws, L, n, tag)) {
                 if (n >= cap) { overflow = true; return; }
                 L[n++] = tag;
-                changed = true;
             }
             if (!h_is_dyn(tag)) {
-                uint32_t a = t.imp_off[h_id(tag)], b = t.imp_off[h_id(tag) + 1];
+                const uint32_t a = t.imp_off[h_id(tag)], b = t.imp_off[h_id(tag) + 1];
                 for (uint32_t m = a; m < b; ++m) {
-                    H imp = t.imp_ids[m];
+                    const H imp = t.imp_ids[m];
                     if (lfind(ws, L, n, imp)) continue;
                     if (n >= cap) { overflow = true; return; }
                     L[n++] = imp;
-                    changed = true;
                 }
             }
         }
-    } while (changed);
+        done = round_end;
+    }
 }
 
 TP_HD bool ebit(const FileWs& ws, uint32_t idx) { return (ws.ebits[idx >> 5] >> (idx & 31)) & 1u; }
@@ -671,8 +680,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
                 uint32_t nm = 0, nm_primary = 0;
                 auto feed = [&](uint32_t i, uint32_t limit_to) -> bool {          // limit_to: entries searched for the tag
                     H h = ws.hnd[i]; double sc = ws.score[i]; uint32_t od = ws.order[i]; uint32_t sr = ws.src[i];
-                    uint32_t j = 0;
-                    for (; j < limit_to; ++j) if (heq(ws, ws.hnd[j], h)) break;
+                    const uint32_t j = lfind_idx(ws, ws.hnd, limit_to, h);
                     if (j == limit_to) return false;
                     double osc = ws.score[j];
                     uint32_t osr = ws.src[j];
@@ -696,8 +704,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
                 int cap = in.secondary_cap;
                 if (cap > 0) {
                     for (uint32_t i = np; i < np + ns; ++i) {
-                        bool in_primary = false;
-                        for (uint32_t j = 0; j < nm_primary && !in_primary; ++j) in_primary = heq(ws, ws.hnd[j], ws.hnd[i]);
+                        const bool in_primary = lfind_idx(ws, ws.hnd, nm_primary, ws.hnd[i]) < nm_primary;
                         if (!in_primary) { if (cap == 0) continue; --cap; }
                         if (!feed(i, nm)) append(i);
                     }
@@ -779,8 +786,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             if (!lfind(ws, ws.dl, ndl, h2)) ws.dl[ndl++] = h2;
             continue;
         }
-        uint32_t j = 0;
-        for (; j < nu; ++j) if (heq(ws, ws.hnd[j], h2)) break;
+        const uint32_t j = lfind_idx(ws, ws.hnd, nu, h2);
         if (j == nu) {
             ws.hnd[nu] = h2; ws.score[nu] = sc; ws.order[nu] = od; ws.src[nu] = (uint8_t)(sr | (fl_bucket(f2) << 4));
             ++nu;
