@@ -510,6 +510,40 @@ TP_HD AuditElem audit_elem(const DevTables& t, const FileWs& ws, int col, uint32
     return e;
 }
 
+// ---- eight bytes of a text at a time (texts have eight readable bytes behind their end) -----------------------------------
+constexpr uint64_t PL_01 = 0x0101010101010101ull, PL_7F = 0x7F7F7F7F7F7F7F7Full, PL_80 = 0x8080808080808080ull;
+TP_HD uint64_t pl_ld8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+TP_HD uint64_t pl_eq8(uint64_t x, uint8_t c) { const uint64_t y = x ^ (PL_01 * c); return ~(((y & PL_7F) + PL_7F) | y | PL_7F); }   // 0x80 in every byte equal to c
+TP_HD uint64_t pl_first(uint32_t n) { return n >= 8 ? PL_80 : (PL_80 & ((1ull << (8 * n)) - 1)); }                                // 0x80 in each of the first n bytes
+TP_HD uint32_t pl_low(uint64_t m) { return (uint32_t)__builtin_ctzll(m) >> 3; }                                                   // byte index of the lowest flag, m != 0
+TP_HD bool is_letter8(uint8_t c) { c |= 0x20; return c >= 'a' && c <= 'z'; }
+
+// has_refusal_phrase for a text without ':' (so without the two entries that hold one).  Every other entry but "sorry" has a
+// blank that follows a letter: the text is searched for such blanks (a line feed counts as the blank it becomes) and for
+// 's', and the entries are tried only there.
+TP_HD bool has_refusal_phrase_nocolon(const uint8_t* s, uint32_t a, uint32_t b) {
+    for (uint32_t p = a; p < b; p += 8) {
+        const uint64_t x = pl_ld8(s + p), in = pl_first(b - p);
+        uint64_t ss = pl_eq8(x | (PL_01 * 0x20), 's') & in;
+        uint64_t sp = (pl_eq8(x, ' ') | pl_eq8(x, '\n')) & in & ~(pl_eq8(x, ',') << 8);   // a blank right after a comma starts no entry
+        while (ss) {
+            const uint32_t q = p + pl_low(ss);
+            ss &= ss - 1;
+            if (match_ci(s, q, b, "sorry", 5, true)) return true;
+        }
+        while (sp) {
+            const uint32_t q = p + pl_low(sp);
+            sp &= sp - 1;
+            if (q <= a || !is_letter8(s[q - 1])) continue;
+            if (match_ci(s, q - 1, b, "i can't", 7, true) || match_ci(s, q - 1, b, "i cannot", 8, true) || match_ci(s, q - 1, b, "i won't", 7, true)) return true;
+            if (q >= a + 2 && match_ci(s, q - 2, b, "as an ai", 8, true)) return true;
+            if (q >= a + 3 && match_ci(s, q - 3, b, "i'm not able", 12, true)) return true;
+            if (q >= a + 6 && (match_ci(s, q - 6, b, "cannot provide", 14, true) || match_ci(s, q - 6, b, "unable to", 9, true))) return true;
+        }
+    }
+    return false;
+}
+
 // ================================================================================================
 // The pipeline.  mode 0: whole span.  mode 2: existing-caption triage (line ingest only; stops after the candidates).
 // mode 1: stop after SelectTags and leave its result in ws.fin
@@ -535,12 +569,17 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         const uint8_t* s = in.text;
         uint32_t a = 0, b = in.len;
         bool has_colon = false, has_tick = false, has_crlf = false, has_high = false;
-        for (uint32_t p = 0; p < b; ++p) {
-            uint8_t c = s[p];
-            has_high |= c >= 0x80;                              // such tokens are taken only as known strings, see make_token
-            has_colon |= (c == ':');
-            has_tick |= (c == '`');
-            if (c == '\r' && p + 1 < b && s[p + 1] == '\n') has_crlf = true;
+        {
+            bool prev_cr = false;                               // the word before ended in a carriage return
+            for (uint32_t p = 0; p < b; p += 8) {
+                const uint64_t x = pl_ld8(s + p), in = pl_first(b - p);
+                has_high |= (x & in) != 0;                      // such tokens are taken only as known strings, see make_token
+                has_colon |= (pl_eq8(x, ':') & in) != 0;
+                has_tick |= (pl_eq8(x, '`') & in) != 0;
+                const uint64_t cr = pl_eq8(x, '\r') & in, lf = pl_eq8(x, '\n') & in;
+                if ((cr & (lf >> 8)) || (prev_cr && (lf & 0x80))) has_crlf = true;
+                prev_cr = (cr >> 63) != 0;
+            }
         }
         if (has_crlf) {                                         // raw.Replace("\r\n", "\n")
             uint32_t k = 0;
@@ -594,8 +633,8 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         if (a >= b) rejected = true;
         else {
             uint32_t commas = 0;
-            for (uint32_t p = a; p < b; ++p) commas += (s[p] == ',');
-            if (has_refusal_phrase(s, a, b)) rejected = true;
+            for (uint32_t p = a; p < b; p += 8) commas += (uint32_t)__builtin_popcountll(pl_eq8(pl_ld8(s + p), ',') & pl_first(b - p));
+            if (has_colon ? has_refusal_phrase(s, a, b) : has_refusal_phrase_nocolon(s, a, b)) rejected = true;
             else if (commas < 2 && (b - a) > 40) {
                 if (has_high) unsupported = true;               // LooksBad counts UTF-16 units (Program.cs:1145), which are fewer than these bytes
                 else rejected = true;
@@ -607,7 +646,12 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             uint32_t i = a;
             for (;;) {
                 uint32_t j = i;
-                while (j < b && s[j] != ',') ++j;
+                while (j < b) {                                  // the next comma
+                    const uint64_t m = pl_eq8(pl_ld8(s + j), ',') & pl_first(b - j);
+                    if (m) { j += pl_low(m); break; }
+                    j += 8;
+                }
+                if (j > b) j = b;
                 H h;
                 if (make_token(t, ws, norm_used, s, i, j, false, h, unsupported)) {
                     uint32_t f = hflags(t, h);

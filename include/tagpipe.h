@@ -231,7 +231,7 @@ void tp_release(tp_ctx* ctx, tp_result* res);
  * returns TP_E_CAPACITY and *caption_bytes holds the required size.
  */
 typedef struct tp_device_io {
-    const uint8_t*  arena;            /* in  */
+    const uint8_t*  arena;            /* in; 16 bytes past offsets[n_files] must be readable (the kernels fetch texts in aligned pieces) */
     const uint64_t* offsets;          /* in, n_files + 1 */
     uint64_t        n_files;
     uint8_t*        captions;         /* out */
