@@ -175,6 +175,8 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         HIP_OK(hipStreamSynchronize(s));
         item_list = c->slow_list.as<uint32_t>();
     }
+    const bool want_ids = use_fast || (io.histogram != nullptr && io.mode == 0);   // rows of tag ids: the wave kernels' output, and what the histogram kernel counts
+    if (want_ids && !use_fast) c->fin32.need(n * fast_fin_stride() * 4);
     c->last_slow += n_slow;
     if (n_slow) {
         // The general kernel runs one file per lane, and the lanes of a wavefront wait for one another at every branch where
@@ -244,7 +246,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     EmitArgs ea{};
     ea.file0 = f0; ea.file_end = f1;
     ea.wave_T = c->wave_T.as<uint32_t>(); ea.wave_LB = c->wave_LB.as<uint32_t>(); ea.wave_off = c->wave_off.as<uint64_t>(); ea.workspace = c->workspace.as<uint8_t>();
-    ea.fin32 = use_fast ? c->fin32.as<uint32_t>() : nullptr; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
+    ea.fin32 = want_ids ? c->fin32.as<uint32_t>() : nullptr; ea.fast_ran = use_fast ? 1 : 0; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
     ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
     ea.histogram = io.histogram; ea.counters = io.counters;
     hipEvent_t q0 = c->event(st.ev++), q1 = c->event(st.ev++);

@@ -542,7 +542,8 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
 // Tag histogram of the wave-kernel files: ids id0 .. id0 + HIST_IDS are counted in LDS (a tag occurs at most once per file,
 // so a block's 16-bit counters cannot overflow before HIST_FILES_PER_FLUSH files), then added to the global histogram.
 // Wider id ranges take further launches.  One wavefront per file, two files per step so that their loads overlap.
-__global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t id0) {
+// general != 0: the files of the general kernel whose ids its emit kernel left in the same rows are counted too.
+__global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t id0, int general) {
     __shared__ uint32_t bins[HIST_IDS / 2];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const uint32_t span = t.n_strings - id0 < HIST_IDS ? t.n_strings - id0 : HIST_IDS;
@@ -557,7 +558,8 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
             const uint64_t g = f + waves;
             const bool two = g < c1;
             const uint32_t nf0 = a.n_final[f], nf1 = two ? a.n_final[g] : 0;
-            const bool fast0 = a.slot_of[f] == SLOT_FAST, fast1 = two && a.slot_of[g] == SLOT_FAST;
+            const bool fast0 = a.slot_of[f] == SLOT_FAST || (general && nf0 <= FAST_FIN_MAX);
+            const bool fast1 = two && (a.slot_of[g] == SLOT_FAST || (general && nf1 <= FAST_FIN_MAX));
             const uint32_t* i0 = a.fin32 + (f - a.file0) * FAST_FIN_MAX;
             const uint32_t* i1 = a.fin32 + ((two ? g : f) - a.file0) * FAST_FIN_MAX;
             const uint32_t x0 = i0[lane], x1 = i0[lane + 64], y0 = i1[lane], y1 = i1[lane + 64];
@@ -579,8 +581,24 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
 }
 
 // Files of the general kernel (a.item_list, or every file of the range when it is null): tags may be strings outside the
-// tables, kept in the file's workspace.  One wavefront per file, bytes stored one by one.
+// tables, kept in the file's workspace.  One wavefront per file, 64 tags at a time: every lane puts its tag (and separator)
+// into an LDS staging area, eight bytes per load, then the wavefront stores the area with consecutive lanes on consecutive
+// bytes.  A group of tags too long for the area is stored lane by lane.
+constexpr uint32_t GEN_STAGE = 4096;
+__device__ inline void put_bytes(uint8_t* dst, const uint8_t* src, uint32_t len) {   // src is readable eight bytes past its end
+    uint32_t b = 0;
+    for (; b + 8 <= len; b += 8) { const uint64_t v = ld64u(src + b); __builtin_memcpy(dst + b, &v, 8); }
+    if (b < len) {
+        uint64_t v = ld64u(src + b);
+        const uint32_t r = len - b;
+        if (r & 4) { const uint32_t y = (uint32_t)v; __builtin_memcpy(dst + b, &y, 4); v >>= 32; b += 4; }
+        if (r & 2) { const uint16_t y = (uint16_t)v; __builtin_memcpy(dst + b, &y, 2); v >>= 16; b += 2; }
+        if (r & 1) dst[b] = (uint8_t)v;
+    }
+}
 __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][GEN_STAGE];
+    uint8_t* stage = stage_all[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -598,6 +616,7 @@ __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
         WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
         FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63);
         uint32_t running = 0;
+        const bool ids_out = a.fin32 != nullptr && nfin <= FAST_FIN_MAX;
         for (uint32_t k0 = 0; k0 < nfin; k0 += 64) {
             uint32_t k = k0 + lane;
             bool live = k < nfin;
@@ -612,13 +631,29 @@ __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
             bool sep = live && (k + 1 < nfin);
             uint32_t seg = len + (sep ? 2u : 0u);
             uint32_t incl = wave_scan_incl(seg);
-            uint8_t* dst = a.captions + out0 + running + (incl - seg);
-            for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
-            if (sep) { dst[len] = ','; dst[len + 1] = ' '; }
-            running += __shfl(incl, 63);
+            const uint32_t group = __shfl(incl, 63);
+            uint8_t* gdst = a.captions + out0 + running;
+            if (group <= GEN_STAGE) {
+                if (live) {
+                    uint8_t* dst = stage + (incl - seg);
+                    put_bytes(dst, src, len);
+                    if (sep) { dst[len] = ','; dst[len + 1] = ' '; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t o = lane; o < group; o += 64) gdst[o] = stage[o];
+                __builtin_amdgcn_wave_barrier();                    // the area is read before the next group's bytes are written
+            } else if (live) {
+                uint8_t* dst = gdst + (incl - seg);
+                for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+                if (sep) { dst[len] = ','; dst[len + 1] = ' '; }
+            }
+            running += group;
             if (live && a.histogram) {
                 if (h_is_dyn(h)) ++c_other;
-                else atomicAdd((unsigned long long*)&a.histogram[h_id(h)], 1ull);
+                if (ids_out) a.fin32[(f - a.file0) * FAST_FIN_MAX + k] = h_is_dyn(h) ? NO_ID : h_id(h);   // counted by the histogram kernel
+                else if (!h_is_dyn(h)) atomicAdd((unsigned long long*)&a.histogram[h_id(h)], 1ull);
             }
         }
         if (lane < t.newline_len) a.captions[out0 + running + lane] = t.newline[lane];
@@ -682,12 +717,7 @@ hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s) {
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
-    if (a.fin32) {                                          // the wave-per-file kernel ran: its files first
-        if (a.histogram) {
-            uint64_t hb = (n + 1023) / 1024;                      // a block is worth launching for a thousand files
-            unsigned hblocks = (unsigned)(hb < 256 ? hb : 256);   // one per CU: the counters take most of its LDS
-            for (uint32_t id0 = 0; id0 < t.n_strings; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0);
-        }
+    if (a.fin32 && a.fast_ran) {                            // the wave-per-file kernel ran: its files first
         uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
         unsigned blocks = (unsigned)(want < 256 * 5 ? want : 256 * 5);   // five blocks (twenty wavefronts) per CU
         hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
@@ -698,6 +728,12 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
         uint64_t want = (a.n_items + 3) / 4;                // four wavefronts per block
         unsigned blocks = (unsigned)(want < 1024 ? want : 1024);
         hipLaunchKernelGGL(k_emit_general, dim3(blocks), dim3(256), 0, s, t, a);
+    }
+    if (a.fin32 && a.histogram) {                           // after both emit kernels: the general one leaves its files' tag ids in the same rows
+        uint64_t hb = (n + 1023) / 1024;                      // a block is worth launching for a thousand files
+        unsigned hblocks = (unsigned)(hb < 256 ? hb : 256);   // one per CU: the counters take most of its LDS
+        const int general = a.n_items ? 1 : 0;
+        for (uint32_t id0 = 0; id0 < t.n_strings; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0, general);
     }
     return hipGetLastError();
 }

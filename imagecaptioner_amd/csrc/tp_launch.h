@@ -88,7 +88,9 @@ struct EmitArgs {
     const uint32_t* wave_LB;
     const uint64_t* wave_off;
     uint8_t* workspace;
-    const uint32_t* fin32;        // indexed by file - file0; null when the wave-per-file kernel did not run
+    uint32_t* fin32;              // FAST_FIN_MAX tag ids per file, indexed by file - file0: written by the wave-per-file kernels for their files and by
+                                  // the general emit kernel for the others (what the histogram kernel counts); null when neither is wanted
+    int fast_ran;                 // the wave-per-file kernels ran over the range
     const uint32_t* item_list;    // the files of the general kernel, relative to file0 (null: all files of the range)
     uint64_t n_items;             // how many of them
     const uint32_t* slot_of;
