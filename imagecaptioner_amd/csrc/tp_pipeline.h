@@ -230,6 +230,33 @@ TP_HD uint32_t subject_bits_dyn(const uint8_t* p, uint32_t n) {
     return bits;
 }
 
+// ---- eight bytes of a text at a time (texts have eight readable bytes behind their end) -----------------------------------
+constexpr uint64_t PL_01 = 0x0101010101010101ull, PL_7F = 0x7F7F7F7F7F7F7F7Full, PL_80 = 0x8080808080808080ull;
+TP_HD uint64_t pl_ld8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+TP_HD uint64_t pl_eq8(uint64_t x, uint8_t c) { const uint64_t y = x ^ (PL_01 * c); return ~(((y & PL_7F) + PL_7F) | y | PL_7F); }   // 0x80 in every byte equal to c
+TP_HD uint64_t pl_first(uint32_t n) { return n >= 8 ? PL_80 : (PL_80 & ((1ull << (8 * n)) - 1)); }                                // 0x80 in each of the first n bytes
+TP_HD uint32_t pl_low(uint64_t m) { return (uint32_t)__builtin_ctzll(m) >> 3; }                                                   // byte index of the lowest flag, m != 0
+TP_HD bool is_letter8(uint8_t c) { c |= 0x20; return c >= 'a' && c <= 'z'; }
+
+// The slot of a normalised token of at most 32 bytes, given as four zero-padded words: the id NormalizeTag gives it, or NO_ID
+// when it is in no table (every interned string of up to 32 bytes is a key of the slots).
+TP_HD uint32_t slot_lookup(const DevTables& t, uint32_t n, const uint64_t w[4]) {
+    const uint64_t hsh = hash_finish(hash_word(hash_word(hash_word(hash_word(HASH_SEED, w[0], 0), w[1], 1), w[2], 2), w[3], 3), n);
+    uint32_t slot = (uint32_t)hsh & t.ht_mask;
+    const uint32_t h32 = (uint32_t)(hsh >> 32);
+    for (;;) {
+        const Slot* sl = t.slots + slot;
+        const uint32_t slen = sl->slen;
+        if (slen == SLOT_EMPTY) return NO_ID;
+        if (sl->hash == h32 && slen == n) {
+            uint64_t k[4];
+            __builtin_memcpy(k, sl->key, 32);
+            if (((k[0] ^ w[0]) | (k[1] ^ w[1]) | (k[2] ^ w[2]) | (k[3] ^ w[3])) == 0) return sl->val;
+        }
+        slot = (slot + 1) & t.ht_mask;
+    }
+}
+
 // Hash-table probe with the candidate bytes given as plain memory.
 TP_HD uint32_t probe_bytes(const DevTables& t, const uint8_t* p, uint32_t n, uint64_t hash) {
     uint32_t slot = (uint32_t)hash & t.ht_mask;
@@ -355,6 +382,26 @@ TP_HD bool make_token(const DevTables& t, FileWs& ws, uint32_t& norm_used, const
     }
     while (tail > i && is_punct8(s[tail - 1])) --tail;
     j = tail;
+    // The usual token holds nothing the steps above and below change (no capital, white space, doubled underscore, and by now
+    // no quote or punctuation at its ends): its bytes are the normalised string, looked up as four words in one probe.
+    if (j - i <= 32 && !is_quote8(s[i])) {
+        const uint32_t n = j - i;
+        uint64_t w[4], changed = 0, prev_us = 0;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t r = n > 8 * k ? n - 8 * k : 0;
+            const uint64_t x = r == 0 ? 0 : pl_ld8(s + i + 8 * k) & (r >= 8 ? ~0ull : ((1ull << (8 * r)) - 1));
+            w[k] = x;
+            const uint64_t up = (x + PL_01 * 0x3F) & ~(x + PL_01 * 0x25) & PL_80;                         // 'A' .. 'Z' (bytes below 0x80)
+            const uint64_t wsm = pl_eq8(x, ' ') | ((x + PL_01 * (0x80 - 9)) & ~(x + PL_01 * (0x80 - 14)) & PL_80);   // white space
+            const uint64_t us = pl_eq8(x, '_');
+            changed |= up | wsm | (us & ((us << 8) | (prev_us >> 56)));
+            prev_us = us;
+        }
+        if (!changed) {
+            const uint32_t id = slot_lookup(t, n, w);
+            if (id != NO_ID) { out = id; return true; }
+        }
+    }
     // pass 1: hash and length of the normalised form
     Hasher hs;
     {
@@ -509,14 +556,6 @@ TP_HD AuditElem audit_elem(const DevTables& t, const FileWs& ws, int col, uint32
     e.reason = col != AUDIT_DROPPED ? nullptr : !(hflags(t, h) & FL_VALID) ? ":invalid_tag" : ":policy_drop";   // Program.cs:630-631
     return e;
 }
-
-// ---- eight bytes of a text at a time (texts have eight readable bytes behind their end) -----------------------------------
-constexpr uint64_t PL_01 = 0x0101010101010101ull, PL_7F = 0x7F7F7F7F7F7F7F7Full, PL_80 = 0x8080808080808080ull;
-TP_HD uint64_t pl_ld8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-TP_HD uint64_t pl_eq8(uint64_t x, uint8_t c) { const uint64_t y = x ^ (PL_01 * c); return ~(((y & PL_7F) + PL_7F) | y | PL_7F); }   // 0x80 in every byte equal to c
-TP_HD uint64_t pl_first(uint32_t n) { return n >= 8 ? PL_80 : (PL_80 & ((1ull << (8 * n)) - 1)); }                                // 0x80 in each of the first n bytes
-TP_HD uint32_t pl_low(uint64_t m) { return (uint32_t)__builtin_ctzll(m) >> 3; }                                                   // byte index of the lowest flag, m != 0
-TP_HD bool is_letter8(uint8_t c) { c |= 0x20; return c >= 'a' && c <= 'z'; }
 
 // has_refusal_phrase for a text without ':' (so without the two entries that hold one).  Every other entry but "sorry" has a
 // blank that follows a letter: the text is searched for such blanks (a line feed counts as the blank it becomes) and for
