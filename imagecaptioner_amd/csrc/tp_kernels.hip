@@ -367,10 +367,24 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
     }
 }
 
+constexpr uint32_t GEN_STAGE = 4096, AUDIT_STAGE = 4096;   // bytes of LDS staging per wavefront in the general emit kernels
+__device__ inline void put_bytes(uint8_t* dst, const uint8_t* src, uint32_t len) {   // src is readable eight bytes past its end
+    uint32_t b = 0;
+    for (; b + 8 <= len; b += 8) { const uint64_t v = ld64u(src + b); __builtin_memcpy(dst + b, &v, 8); }
+    if (b < len) {
+        uint64_t v = ld64u(src + b);
+        const uint32_t r = len - b;
+        if (r & 4) { const uint32_t y = (uint32_t)v; __builtin_memcpy(dst + b, &y, 4); v >>= 32; b += 4; }
+        if (r & 2) { const uint16_t y = (uint16_t)v; __builtin_memcpy(dst + b, &y, 2); v >>= 16; b += 2; }
+        if (r & 1) dst[b] = (uint8_t)v;
+    }
+}
 // The tag lists of the audit row and the review record as text: one wavefront per file, one entry per lane and step.  The
 // audit row's entries are joined with ";" (Program.cs:966), dropped tags carry their reason (Program.cs:630-631); the review
 // record's lists are separated by "\n" (the host sorts and joins them); the unknown-tag column keeps only entries that qualify.
 __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][AUDIT_STAGE];
+    uint8_t* stage = stage_all[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -395,13 +409,25 @@ __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
                 kept_before += (uint32_t)__popcll(m);
                 const uint32_t seg = live ? e.len + (e.reason ? AUDIT_REASON_LEN : 0u) + (first ? 0u : 1u) : 0u;
                 const uint32_t incl = wave_scan_incl(seg);
+                const uint32_t group = __shfl(incl, 63);
+                // the group's text goes through the staging area (eight bytes per load, consecutive lanes store consecutive bytes);
+                // a group too long for it is stored lane by lane
+                const bool staged = group <= AUDIT_STAGE;
                 if (live) {
-                    uint8_t* dst = out + running + (incl - seg);
+                    uint8_t* dst = (staged ? stage : out + running) + (incl - seg);
                     if (!first) *dst++ = sep;
-                    for (uint32_t b = 0; b < e.len; ++b) dst[b] = e.p[b];
+                    if (staged) put_bytes(dst, e.p, e.len);
+                    else for (uint32_t b = 0; b < e.len; ++b) dst[b] = e.p[b];
                     if (e.reason) for (uint32_t b = 0; b < AUDIT_REASON_LEN; ++b) dst[e.len + b] = (uint8_t)e.reason[b];
                 }
-                running += __shfl(incl, 63);
+                if (staged) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (uint32_t o = lane; o < group; o += 64) out[running + o] = stage[o];
+                    __builtin_amdgcn_wave_barrier();                // the area is read before the next group's bytes are written
+                }
+                running += group;
             }
         }
     }
@@ -584,18 +610,6 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
 // tables, kept in the file's workspace.  One wavefront per file, 64 tags at a time: every lane puts its tag (and separator)
 // into an LDS staging area, eight bytes per load, then the wavefront stores the area with consecutive lanes on consecutive
 // bytes.  A group of tags too long for the area is stored lane by lane.
-constexpr uint32_t GEN_STAGE = 4096;
-__device__ inline void put_bytes(uint8_t* dst, const uint8_t* src, uint32_t len) {   // src is readable eight bytes past its end
-    uint32_t b = 0;
-    for (; b + 8 <= len; b += 8) { const uint64_t v = ld64u(src + b); __builtin_memcpy(dst + b, &v, 8); }
-    if (b < len) {
-        uint64_t v = ld64u(src + b);
-        const uint32_t r = len - b;
-        if (r & 4) { const uint32_t y = (uint32_t)v; __builtin_memcpy(dst + b, &y, 4); v >>= 32; b += 4; }
-        if (r & 2) { const uint16_t y = (uint16_t)v; __builtin_memcpy(dst + b, &y, 2); v >>= 16; b += 2; }
-        if (r & 1) dst[b] = (uint8_t)v;
-    }
-}
 __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][GEN_STAGE];
     uint8_t* stage = stage_all[threadIdx.x >> 6];
