@@ -838,6 +838,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         double sc = ws.score[i];
         uint32_t od = ws.order[i];
         uint32_t sr = ws.src[i];
+        if (sr > 3) sr = 3;                                       // every other source ranks alike (Program.cs:712-717); the byte's upper bits are used below
         uint32_t f2 = hflags(t, h2);
         if (mode == 3) {
             // TopJoyTags: rawCandidates.OrderByDescending(Score).ThenBy(Order).Take(20).Select(c => c.Tag), a stable sort (Program.cs:860)
@@ -932,14 +933,17 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             int used = 0;
             for (uint32_t k = 0; k < nu; ++k) {
                 uint32_t q = ws.sorted[k];
-                if ((uint32_t)(ws.src[q] >> 4) != bkt) continue;
+                const uint8_t sb = ws.src[q];
+                if ((uint32_t)((sb >> 4) & 7) != bkt) continue;
                 if (nr >= (uint32_t)MAX_TOTAL_TAGS || used >= caps[bkt]) break;
-                if (add_one(ws.hnd[q])) ++used;
+                if (add_one(ws.hnd[q])) { ++used; ws.src[q] = (uint8_t)(sb | 0x80); }   // bit 7: its tag is in the result
             }
         }
         for (uint32_t k = 0; k < nu; ++k) {                       // final sweep, Program.cs:677-680
             if (nr >= (uint32_t)MAX_TOTAL_TAGS) break;
-            add_one(ws.hnd[ws.sorted[k]]);
+            const uint32_t q = ws.sorted[k];
+            if (ws.src[q] & 0x80) continue;                       // AddOne would find its tag selected already
+            add_one(ws.hnd[q]);
         }
     }
     v.n_selected = (uint16_t)nr;
