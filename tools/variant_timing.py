@@ -29,6 +29,8 @@ for mode in modes:
         lines = [l + b"\r\n" for l in base]
     elif mode == "cr_inside_2pc":                          # every 50th file is broken over lines the Windows way: general kernel
         lines = [l.replace(b", ", b",\r\n", 3) if i % 50 == 0 else l for i, l in enumerate(base)]
+    elif mode == "lone_cr_2pc":                            # every 50th file holds a carriage return of its own: the general kernel takes it
+        lines = [l.replace(b", ", b",\r ", 1) if i % 50 == 0 else l for i, l in enumerate(base)]
     elif mode == "trailing_comma":
         lines = [l + b"," for l in base]
     else:
