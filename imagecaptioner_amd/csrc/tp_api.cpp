@@ -74,7 +74,7 @@ struct tp_ctx {
     HostTables ht;
     DevTables dt;
     std::vector<void*> table_mem;
-    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list1, slow_list2, scalars, workspace;
+    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, scalars, workspace;
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
     DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets, out_review_bits;
@@ -83,12 +83,13 @@ struct tp_ctx {
     tp_timing timing{};
     size_t ws_budget = (size_t)64 << 30;
     bool no_fast = false;            // TAGPIPE_NO_FAST=1: every file takes the general kernel (testing aid)
+    bool use_lean = false;           // the lean stage runs ahead of the wave stages (TAGPIPE_NO_LEAN=1 turns it off: testing aid)
     uint64_t last_slow = 0;
 
     ~tp_ctx() {
         (void)hipSetDevice(device);
         for (void* p : table_mem) (void)hipFree(p);
-        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
+        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
                           &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits})
             b->release();
@@ -160,7 +161,17 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         } else {
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
         // through the long-file stage, and what is left to the general kernel.  Later stages learn their item counts on the device.
-        fa.stage = 1; fa.slow_list = c->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1; fa.item_list = nullptr; fa.item_count = nullptr;
+        fa.item_list = nullptr; fa.item_count = nullptr;
+        if (c->use_lean && io.mode == 0) {
+            // stage 0: the lean stage takes the common shape of a file; the stages below see what it declines
+            c->slow_list0.need(n * 4);
+            uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
+            HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
+            fa.stage = 0; fa.slow_list = c->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0;
+            HIP_OK(launch_fast(c->dt, fa, s));
+            fa.item_list = c->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+        }
+        fa.stage = 1; fa.slow_list = c->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
         HIP_OK(launch_fast(c->dt, fa, s));
         fa.stage = 2; fa.item_list = c->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
         fa.slow_list = c->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
@@ -529,6 +540,8 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.reach_off = upload(c->table_mem, h.reach_off);
         d.reach_ent = upload(c->table_mem, h.reach_ent);
         compute_fallback(c.get());
+        c->use_lean = lean_ok(c->dt);
+        if (const char* b = std::getenv("TAGPIPE_NO_LEAN")) if (b[0] == '1') c->use_lean = false;
         return TP_OK;
     });
     if (rc != TP_OK) return nullptr;

@@ -60,8 +60,10 @@ enum : uint32_t {
     FL_SUBJ_MALE = 1u << 26,   //   it is in MaleSubjectTokens (Program.cs:30-32, 835)
     FL_SUBJ_GIRL = 1u << 27,   //   it holds "girl" (Program.cs:836)
     FL_SUBJ_MULTI = 1u << 28,  //   it starts with "multiple_" or matches ^\d+(girl|girls|boy|boys)$ (Program.cs:837; \d is the Unicode category Nd)
-    FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone and that has no steps of
-                               // its own: one ExpandImpliedTags round settles it; Rec::s0_flags .. s1_len describe the steps
+    FL_FENCE = 1u << 29,       // holds '`': StripCodeFences may act on a line with it (Program.cs:595, 1189-1210)
+    FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone (whatever a step's own
+                               // visit appends is among these steps): one ExpandImpliedTags round settles it; Rec::s0_flags .. s1_len
+                               // describe the steps
 };
 enum Bucket : uint32_t { B_IDENTITY = 0, B_FACE = 1, B_OUTFIT = 2, B_POSE = 3, B_BACKGROUND = 4, B_STYLE = 5, B_OTHER = 6 };
 TP_HD uint32_t fl_bucket(uint32_t f) { return (f & FL_BUCKET_MASK) >> FL_BUCKET_SHIFT; }

@@ -707,7 +707,7 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
     if (settled) {
         // One round settles it: the implied tags of the selected tags (read from the per-position columns written in S6) are
         // offered to the set under the key (position, first or second); winners are appended in key order with their flags
-        // and lengths; nothing appended has steps of its own.
+        // and lengths; whatever an appended tag's own visit would append is already among the tags offered here.
         set_clear(w, L);
         if (lane < nf) { bool created; set_put(w, L, own0, 0, created); }
         w.sync();

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "tp_fast.h"
+#include "tp_lean.h"
 #include "tp_launch.h"
 #include "tp_pipeline.h"
 
@@ -44,14 +45,14 @@ __device__ inline uint32_t wave_scan_incl(uint32_t v) {
 
 struct DevWave {
 #ifdef TP_PROF
-    uint64_t last = 0, acc[16] = {0};
+    uint64_t last = 0, acc[32] = {0};
     __device__ __forceinline__ void tick(int k) {
         uint64_t now = __builtin_readcyclecounter();
-        if (k > 0) acc[k] += now - last;      // section 0 starts the file's clock
+        if (k > 0) acc[k] += now - last;      // section 0 starts the file's clock (the lean stage uses 16 .. 24; 16 is the time between its files)
         last = now;
     }
     __device__ void flush() {
-        if (lane() == 0) for (int k = 0; k < 16; ++k) if (acc[k]) atomicAdd(&g_prof[k], (unsigned long long)acc[k]);
+        if (lane() == 0) for (int k = 0; k < 32; ++k) if (acc[k]) atomicAdd(&g_prof[k], (unsigned long long)acc[k]);
     }
 #else
     __device__ void tick(int) const {}
@@ -81,10 +82,35 @@ struct DevWave {
     __device__ void lds_or(uint32_t* p, uint32_t v) const { atomicOr(p, v); }
     __device__ void lds_min64(uint64_t* p, uint64_t v) const { atomicMin((unsigned long long*)p, (unsigned long long)v); }
     __device__ void copy16(uint8_t* lds_dst, const uint8_t* src) const { *(uint4*)lds_dst = *(const uint4*)src; }
+    __device__ void load16(const uint8_t* src, uint32_t (&x)[4]) const { const uint4 v = *(const uint4*)src; x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+    __device__ void store16(uint8_t* lds_dst, const uint32_t (&x)[4]) const { *(uint4*)lds_dst = make_uint4(x[0], x[1], x[2], x[3]); }
     __device__ void fill16(uint32_t* lds_dst, uint32_t v) const { *(uint4*)lds_dst = make_uint4(v, v, v, v); }
 };
 
 constexpr int FAST_WAVES_PER_BLOCK = 4;
+
+// The files a wavefront declines, handed on in batches: one atomic on the list's counter per DECLINE_BATCH files instead
+// of one per file (a single counter takes about 90 atomics per microsecond, which a stage that declines a quarter of a
+// million files would spend milliseconds on).
+constexpr uint32_t DECLINE_BATCH = 32;
+struct DeclineBuf { uint32_t item[DECLINE_BATCH]; };
+__device__ inline void decline_flush(DeclineBuf& b, uint32_t& n, uint32_t* list, uint32_t* count) {   // wave-uniform n
+    if (n == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, n);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (lane < n) list[base + lane] = b.item[lane];
+    n = 0;
+}
+__device__ inline void decline_push(DeclineBuf& b, uint32_t& n, uint32_t item, uint32_t* list, uint32_t* count) {
+    if ((threadIdx.x & 63u) == 0) b.item[n] = item;
+    ++n;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (n == DECLINE_BATCH) decline_flush(b, n, list, count);
+}
 
 // The first stage serves files of at most 64 tokens (and 128 final tags) over the whole range [file0, file_end); the second
 // serves the files the first declined (a.item_list, a.item_count entries on the device) with 128 tokens.  Files both decline
@@ -95,9 +121,12 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
     __shared__ uint8_t cls[256];                                // byte classes of the line scan
     extern __shared__ uint32_t rc_lds[];                        // the rule cache, t.rc_words words (dynamic LDS)
+    if (a.item_list && (uint64_t)blockIdx.x * FAST_WAVES_PER_BLOCK >= (uint64_t)*a.item_count) return;   // a later stage with nothing left for this block
     for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
     __syncthreads();
+    __shared__ DeclineBuf dbuf[FAST_WAVES_PER_BLOCK];
+    uint32_t n_declined = 0;
     FastLds& L = lds[threadIdx.x >> 6];
     DevWave w;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -113,19 +142,19 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
             done = fast_file<NT, 2>(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
                                  a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR);
         }
-        if (w.lane() == 0) {
-            if (done) {
+        if (done) {
+            if (w.lane() == 0) {
                 a.verdicts[f] = out.verdict;
                 a.n_final[f] = out.n_final;
                 a.cap_len[f] = out.caption_len;
                 a.slot_of[f] = SLOT_FAST;
-            } else {
-                uint32_t k = atomicAdd(a.slow_count, 1u);
-                a.slow_list[k] = (uint32_t)(f - a.file0);
             }
+        } else {
+            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)(f - a.file0), a.slow_list, a.slow_count);
         }
         w.sync();
     }
+    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
 #ifdef TP_PROF
     w.flush();
 #endif
@@ -140,6 +169,53 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast_triage(DevTables t, FastArgs a) { fast_body<1, true>(t, a); }
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2_triage(DevTables t, FastArgs a) { fast_body<2, true>(t, a); }
 
+// The lean stage (tp_lean.h) over the whole range; the files it declines go to a.slow_list for the stages above.
+constexpr int LEAN_WAVES_PER_BLOCK = 4;
+#ifndef TP_LEAN_WAVES_PER_SIMD
+#define TP_LEAN_WAVES_PER_SIMD 6
+#endif
+__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_WAVES_PER_SIMD))) void k_lean(DevTables t, FastArgs a) {
+    __shared__ LeanLds lds[LEAN_WAVES_PER_BLOCK];
+    __shared__ LeanShared shared;
+    extern __shared__ uint32_t rc_lds[];                        // the rule cache, t.rc_words words (dynamic LDS)
+    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
+    lean_shared_init(t, shared, threadIdx.x, blockDim.x);
+    __syncthreads();
+    __shared__ DeclineBuf dbuf[LEAN_WAVES_PER_BLOCK];
+    uint32_t n_declined = 0;
+    LeanLds& L = lds[threadIdx.x >> 6];
+    DevWave w;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_items = a.file_end - a.file0;
+    for (uint64_t i = wave_global; i < n_items; i += n_waves) {
+        const uint64_t f = a.file0 + i;
+        const uint64_t o = a.offsets[f];
+        const uint64_t len64 = a.offsets[f + 1] - o;
+        bool done = false;
+        FastOut out;
+        if (len64 <= LEAN_LINE_MAX) {
+            done = lean_file(w, t, L, shared, rc_lds, a.arena + o, (uint32_t)len64, out, a.fin32 + i * FAST_FIN_MAX, a.fired ? a.fired + f * t.fired_words : nullptr,
+                             a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+        }
+        if (done) {
+            if (w.lane() == 0) {
+                a.verdicts[f] = out.verdict;
+                a.n_final[f] = out.n_final;
+                a.cap_len[f] = out.caption_len;
+                a.slot_of[f] = SLOT_FAST;
+            }
+        } else {
+            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
+        }
+        w.sync();
+    }
+    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
+#ifdef TP_PROF
+    w.flush();
+#endif
+}
+
 // Scored candidates (tagger replies as text and score per tag) through the wave kernel's scored front, two candidates per lane.
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables t, FastArgs a) {
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
@@ -148,6 +224,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
     for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
     __syncthreads();
+    __shared__ DeclineBuf dbuf[FAST_WAVES_PER_BLOCK];
+    uint32_t n_declined = 0;
     FastLds& L = lds[threadIdx.x >> 6];
     DevWave w;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -162,19 +240,19 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
         const bool done = fast_file<2, 2, DevWave, ScoredFront<DevWave>>(w, t, L, rc_lds, cls, nullptr, 0, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
                                                                          a.fired ? a.fired + f * t.fired_words : nullptr,
                                                                          a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, false, &front);
-        if (w.lane() == 0) {
-            if (done) {
+        if (done) {
+            if (w.lane() == 0) {
                 a.verdicts[f] = out.verdict;
                 a.n_final[f] = out.n_final;
                 a.cap_len[f] = out.caption_len;
                 a.slot_of[f] = SLOT_FAST;
-            } else {
-                uint32_t k = atomicAdd(a.slow_count, 1u);
-                a.slow_list[k] = (uint32_t)(f - a.file0);
             }
+        } else {
+            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)(f - a.file0), a.slow_list, a.slow_count);
         }
         w.sync();
     }
+    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
 }
 
 // Third stage: the files the second declined, up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes; one wavefront per block.
@@ -683,6 +761,7 @@ __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
 // launchers
 // ------------------------------------------------------------------------------------------------
 uint32_t fast_fin_stride() { return FAST_FIN_MAX; }
+bool lean_ok(const DevTables& t) { return lean_tables_ok(t); }
 
 hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
@@ -694,7 +773,11 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     const unsigned cap = a.stage == 1 ? max_blocks : 256u * 8u;
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     const bool tr = a.triage != 0;
-    if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    if (a.stage == 0) {
+        static const unsigned lean_blocks = [] { const char* e = getenv("TAGPIPE_LEAN_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
+        want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK;
+        hipLaunchKernelGGL(k_lean, dim3((unsigned)(want < lean_blocks ? want : lean_blocks)), dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);

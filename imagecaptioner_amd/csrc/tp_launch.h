@@ -31,7 +31,7 @@ struct FastArgs {
     const uint64_t* secondary_begin;   // two replies per file to merge: first tag of the secondary reply (else null)
     int secondary_cap;
     int triage;                   // 1: existing-caption triage: stop after the candidates, verdict flags carry TP_F_TRIAGE_BAD
-    int stage;                    // 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)
+    int stage;                    // 0: the lean stage (tp_lean.h); 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)
     uint32_t* fired;
     uint16_t* facet_choice;
 };
@@ -112,5 +112,6 @@ hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_
 hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s);
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s);
 uint32_t fast_fin_stride();
+bool lean_ok(const DevTables& t);   // the lean stage (tp_lean.h) can serve this configuration
 
 }  // namespace tp

@@ -799,6 +799,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         if (ld.should_drop(s)) f |= FL_DROP;
         if (s.size() >= 2) f |= FL_LEN2;
         if (Loader::has_looks_bad_phrase(lowered(s))) f |= FL_PHRASE;
+        if (s.find((wc)'`') != W::npos) f |= FL_FENCE;
         f |= ld.bucket_of(s, mask) << FL_BUCKET_SHIFT;
         if (mask & CM_HAIR) f |= FL_HAIR;
         if (mask & CM_EYES) f |= FL_EYES;
@@ -1089,7 +1090,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
                 bool leaf = true;
                 for (uint32_t k = 0; k < scnt; ++k) {
                     const uint32_t y = out.step_ids[so + k];
-                    if (out.next[y] != y || (out.flags[y] & (FL_BLANK | FL_EDGE))) leaf = false;
+                    if (out.next[y] != y || (out.flags[y] & FL_BLANK)) leaf = false;   // a step's own steps lie within the reach list, i.e. among these steps
                 }
                 if (leaf) {
                     r.flags |= FL_LEAF2;

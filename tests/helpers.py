@@ -51,6 +51,7 @@ def sim_lib():
         L.sim_run_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
         L.sim_run_scored.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result)]
         L.sim_run_lines_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(sim_result), C.POINTER(C.c_uint64)]
+        L.sim_run_lines_lean.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(sim_result), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.sim_release.argtypes = [C.POINTER(sim_result)]
         L.sim_run_scored_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64,
                                           C.POINTER(sim_result), C.POINTER(C.c_uint64)]
@@ -139,6 +140,24 @@ class HostSim:
     def run_texts_fast(self, texts):
         a, o = pack_lines(texts)
         return self.run_lines_fast(a, o)
+
+    def run_lines_lean(self, arena, offsets, details=True):
+        """The GPU flow with the lean stage in front (as the library runs it).  details=False: the run of a caller that
+        takes no detail arrays (the wave stages then do not count the evidence set: n_evidence is 0xFFFF for their files)."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        if arena.size == 0:
+            arena = np.zeros(1, np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = sim_result()
+        ng, nl = C.c_uint64(), C.c_uint64()
+        rc = self._L.sim_run_lines_lean(self._h, arena.ctypes.data, offsets.ctypes.data, len(offsets) - 1, 1 if details else 0, C.byref(res), C.byref(ng), C.byref(nl))
+        out = self._collect(res, rc)
+        out.n_general, out.n_lean = ng.value, nl.value
+        return out
+
+    def run_texts_lean(self, texts, details=True):
+        a, o = pack_lines(texts)
+        return self.run_lines_lean(a, o, details)
 
     def run_merged(self, arena, tag_offsets, tag_begin, secondary_begin, scores, secondary_cap):
         arena = np.ascontiguousarray(arena, dtype=np.uint8)

@@ -3,6 +3,7 @@
 // in this GPU-less container.  It is not part of the product: nothing under
 // imagecaptioner_amd/ loads it, the C ABI never routes here, and the GPU tests do not use it.
 // The lane-interleaved workspace layout is kept exactly as the kernel uses it (lane = file & 63).
+#define TP_LEAN_STATS 1
 #include <cstring>
 #include <memory>
 #include <string>
@@ -10,11 +11,14 @@
 
 #include "../../include/tagpipe.h"
 #include "../../imagecaptioner_amd/csrc/tp_fast.h"
+#include "../../imagecaptioner_amd/csrc/tp_lean.h"
 #include "../../imagecaptioner_amd/csrc/tp_pipeline.h"
 #include "wave_emu.h"
 #include "../../imagecaptioner_amd/csrc/tp_tables.hpp"
 
 using namespace tp;
+
+extern "C" { unsigned long long g_lean_declines[32]; }   // why the lean stage declined files (reason = position of the test in lean_file)
 
 static const uint8_t* cls_table() {
     struct Tab { uint8_t v[256]; Tab() { for (uint32_t i = 0; i < 256; ++i) v[i] = byte_class(i); } };
@@ -167,7 +171,19 @@ int sim_run_merged(void* h, const uint8_t* arena, const uint64_t* tag_offsets, c
 }
 // The GPU flow: every file first goes through the wave-per-file kernel body (tp_fast.h) on an emulated wavefront;
 // files it declines take the general pipeline.  *n_general receives how many did.
+static int run_lines_staged(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, sim_result* r, uint64_t* n_general, bool lean, bool details,
+                            uint64_t* n_lean);
 int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, sim_result* r, uint64_t* n_general) {
+    return run_lines_staged(h, arena_in, offsets, n, r, n_general, false, true, nullptr);
+}
+// The same with the lean stage (tp_lean.h) in front, as the library runs it.  details == 0: the run of a caller that takes
+// no detail arrays (the evidence set is then not counted: tp_verdict::n_evidence is 0xFFFF for files of the wave stages).
+// *n_lean receives how many files the lean stage took.
+int sim_run_lines_lean(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, int details, sim_result* r, uint64_t* n_general, uint64_t* n_lean) {
+    return run_lines_staged(h, arena_in, offsets, n, r, n_general, true, details != 0, n_lean);
+}
+static int run_lines_staged(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, sim_result* r, uint64_t* n_general, bool lean, bool details,
+                            uint64_t* n_lean) {
     g_err.clear();
     Sim& s = *(Sim*)h;
     const DevTables& t = s.dt;
@@ -183,7 +199,7 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
     o->fired.assign(std::max<size_t>(n * t.fired_words, 1), 0);
     o->facets.assign(n * t.n_facets, 0xFFFF);
     o->hist.assign((size_t)t.n_strings + 1, 0);
-    uint64_t slow = 0;
+    uint64_t slow = 0, n_lean_files = 0;
     emu::Shared sh;
     for (uint64_t f = 0; f < n; ++f) {
         static FastLds lds;
@@ -195,13 +211,29 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
         uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
         bool ok = t.fast_ok && len <= FAST_LINE_MAX;
         bool try_long = t.fast_ok && len <= LONG_LINE_MAX;
-        if (ok) {
+        uint32_t* fired_f = details ? o->fired.data() + f * t.fired_words : nullptr;
+        bool lean_done = false;
+        if (lean && lean_tables_ok(t) && len <= LEAN_LINE_MAX) {
+            static LeanLds llds;
+            static LeanShared lshared;
+            std::memset((void*)&llds, 0xCD, sizeof llds);
+            lean_shared_init(t, lshared, 0, 1);
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                done[lane] = lean_file(w, t, llds, lshared, t.rc, text, len, outs[lane], fin32.data(), fired_f, t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
+            });
+            for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the lean verdict"; }
+            lean_done = done[0];
+            if (lean_done) ++n_lean_files;
+        }
+        if (lean_done) ok = true;
+        else if (ok) {
             // first stage (one element per lane), then the second (two per lane) for what the first declines
             for (int stage = 1; stage <= 2; ++stage) {
                 std::memset(&lds, 0xCD, sizeof lds);
                 sh.run([&](int lane) {
                     emu::Wave w{&sh, (uint32_t)lane};
-                    uint32_t* fired = o->fired.data() + f * t.fired_words;
+                    uint32_t* fired = fired_f;
                     uint16_t* facets = t.n_facets ? &o->facets[f * t.n_facets] : nullptr;
                     done[lane] = stage == 1 ? fast_file<1, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), fired, facets)
                                             : fast_file<2, 2>(w, t, lds, t.rc, cls_table(), text, len, outs[lane], fin32.data(), fired, facets);
@@ -216,7 +248,7 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
             std::memset((void*)&big, 0xCD, sizeof big);
             sh.run([&](int lane) {
                 emu::Wave w{&sh, (uint32_t)lane};
-                done[lane] = long_file(w, t, big, t.rc, cls_table(), text, len, outs[lane], fin32.data(), o->fired.data() + f * t.fired_words,
+                done[lane] = long_file(w, t, big, t.rc, cls_table(), text, len, outs[lane], fin32.data(), fired_f,
                                        t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
             });
             for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the long-file verdict"; }
@@ -254,6 +286,7 @@ int sim_run_lines_fast(void* h, const uint8_t* arena_in, const uint64_t* offsets
         o->ctr.safe_rejected += (fl & TP_F_SAFE_REJECT) != 0;
     }
     if (n_general) *n_general = slow;
+    if (n_lean) *n_lean = n_lean_files;
     return finish(o, n, r);
 }
 
@@ -432,6 +465,9 @@ long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, 
     return (long long)all.size();
 }
 
+void sim_lean_declines(unsigned long long* out32, int reset) {
+    for (int k = 0; k < 32; ++k) { out32[k] = g_lean_declines[k]; if (reset) g_lean_declines[k] = 0; }
+}
 void sim_release(sim_result* r) { delete (SimOut*)r->opaque; r->opaque = nullptr; }
 
 }  // extern "C"

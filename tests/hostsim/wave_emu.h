@@ -107,6 +107,8 @@ struct Wave {
     void lds_min64(uint64_t* p, uint64_t v) { if (v < *p) *p = v; }
     void copy16(uint8_t* dst, const uint8_t* src) { std::memcpy(dst, src, 16); }
     void fill16(uint32_t* dst, uint32_t v) { for (int k = 0; k < 4; ++k) dst[k] = v; }
+    void load16(const uint8_t* src, uint32_t (&x)[4]) { std::memcpy(x, src, 16); }
+    void store16(uint8_t* dst, const uint32_t (&x)[4]) { std::memcpy(dst, x, 16); }
     void tick(int) {}
     uint32_t bcast(uint32_t v, uint32_t src) { return shfl(v, src); }
     uint32_t shift_up(uint32_t v, uint32_t fill) { uint32_t r = shfl(v, lane() == 0 ? 0 : lane() - 1); return lane() == 0 ? fill : r; }

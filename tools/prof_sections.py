@@ -20,6 +20,9 @@ from imagecaptioner_amd.tagpipe import load_library
 NAMES = ["S1 copy", "S2 scan", "S4 tokens+dedupe", "S5 candidates", "S6 buckets", "S7 coverage", "S8 evidence", "S9 closure", "S10 rules", "S11 facets", "S12 verdict"]
 
 
+LEAN_NAMES = ["between files", "load+scan", "tokens", "dedupe", "select", "evidence", "rules+facets", "position+final", "verdict"]
+
+
 def main():
     cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
@@ -54,6 +57,8 @@ def main():
     print("with histogram:", pipe.last_timing())
     for k, name in enumerate(NAMES):
         print("%-20s %6.2f %%  %8.0f cycles/file" % (name, 100.0 * buf[k + 1] / tot, buf[k + 1] / n))
+    for k, name in enumerate(LEAN_NAMES):
+        print("lean %-15s %6.2f %%  %8.0f cycles/file" % (name, 100.0 * buf[16 + k] / tot, buf[16 + k] / n))
 
 
 if __name__ == "__main__":
