@@ -73,6 +73,7 @@ struct tp_ctx {
     int device = 0;
     HostTables ht;
     DevTables dt;
+    DevBuf dt_dev;                   // dt again, in device memory (the lean stage reads it from there)
     std::vector<void*> table_mem;
     DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, scalars, workspace;
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
@@ -89,7 +90,7 @@ struct tp_ctx {
     ~tp_ctx() {
         (void)hipSetDevice(device);
         for (void* p : table_mem) (void)hipFree(p);
-        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
+        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &dt_dev, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
                           &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits})
             b->release();
@@ -167,7 +168,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
             c->slow_list0.need(n * 4);
             uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
             HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
-            fa.stage = 0; fa.slow_list = c->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0;
+            fa.stage = 0; fa.slow_list = c->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
             HIP_OK(launch_fast(c->dt, fa, s));
             fa.item_list = c->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
         }
@@ -535,12 +536,17 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.str_words = upload(c->table_mem, h.str_words);
         d.rc = upload(c->table_mem, h.rule_cache);
         d.slots = upload(c->table_mem, h.slots);
+        d.lslots = h.lslots.empty() ? nullptr : upload(c->table_mem, h.lslots);
+        d.attr2 = upload(c->table_mem, h.attr2);
+        d.crec = upload(c->table_mem, h.crec);
         d.step_off = upload(c->table_mem, h.step_off);
         d.step_ids = upload(c->table_mem, h.step_ids);
         d.reach_off = upload(c->table_mem, h.reach_off);
         d.reach_ent = upload(c->table_mem, h.reach_ent);
         compute_fallback(c.get());
         c->use_lean = lean_ok(c->dt);
+        c->dt_dev.need(sizeof(DevTables));
+        HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));
         if (const char* b = std::getenv("TAGPIPE_NO_LEAN")) if (b[0] == '1') c->use_lean = false;
         return TP_OK;
     });

@@ -60,6 +60,7 @@ enum : uint32_t {
     FL_SUBJ_MALE = 1u << 26,   //   it is in MaleSubjectTokens (Program.cs:30-32, 835)
     FL_SUBJ_GIRL = 1u << 27,   //   it holds "girl" (Program.cs:836)
     FL_SUBJ_MULTI = 1u << 28,  //   it starts with "multiple_" or matches ^\d+(girl|girls|boy|boys)$ (Program.cs:837; \d is the Unicode category Nd)
+    FL_FIX = 1u << 30,         // NormalizeTag leaves it alone and it is not blank
     FL_FENCE = 1u << 29,       // holds '`': StripCodeFences may act on a line with it (Program.cs:595, 1189-1210)
     FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone (whatever a step's own
                                // visit appends is among these steps): one ExpandImpliedTags round settles it; Rec::s0_flags .. s1_len
@@ -150,6 +151,32 @@ constexpr uint32_t SLOT_KEY_BASIC = 1u;   // the key is what NormalizeTag's step
 // Hash-table payload: what the alias lookup makes of the string in this slot, and where its bytes are (to verify a probe).
 struct HtInfo { uint32_t val, woff, slen, pad; };   // woff: first 8-byte word of the string in DevTables::str_words
 
+// One slot of the lean stage's lookup table (tp_lean.h), one cache line: a string of at most 32 bytes that the normalisation
+// before the alias lookup leaves alone (key) -> what the stage needs of the string NormalizeTag makes of it (val).  Every key
+// sits in one of the two slots its hash names (lean_slots()), so a lookup is one round of two independent loads.
+struct alignas(64) LeanSlot {
+    uint32_t key[8];     // the key's bytes, zero padded
+    uint32_t head;       // val | key length << 20 (0 in an unused slot) | min(step count, 3) << 26 | (NormalizeTag changes val) << 28
+    uint32_t flags;      // of val
+    uint32_t len;        // byte length of val
+    uint32_t lit;        // evidence-bitset index of val, NO_ID when no rule names it
+    uint32_t step0, step1;       // Rec::step0 / step1 of val (NO_ID when absent)
+    uint32_t s0_info, s1_info;   // Rec::s0_info / s1_info of val
+};
+constexpr uint32_t LEAN_KEY_MAX = 32;
+constexpr uint32_t LEAN_HEAD_ID_MASK = 0xFFFFFu;
+TP_HD uint32_t rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); }   // 0 < r < 32
+// The two slots of a key given as eight zero-padded little-endian words; mask = slots - 1.  Two accumulators with
+// different rotations, so that keys whose words merely trade places do not share both slots.
+TP_HD void lean_slots(const uint32_t k[8], uint32_t n, uint32_t mask, uint32_t& s1, uint32_t& s2) {
+    const uint32_t x = k[0] ^ rotl32(k[1], 5) ^ rotl32(k[2], 10) ^ rotl32(k[3], 15) ^ rotl32(k[4], 20) ^ rotl32(k[5], 25) ^ rotl32(k[6], 30) ^ rotl32(k[7], 3) ^ (n << 26);
+    const uint32_t y = k[0] ^ rotl32(k[1], 11) ^ rotl32(k[2], 22) ^ rotl32(k[3], 1) ^ rotl32(k[4], 12) ^ rotl32(k[5], 23) ^ rotl32(k[6], 2) ^ rotl32(k[7], 13) ^ n;
+    const uint32_t a = (x ^ (x >> 15)) * 2654435761u, b = (y ^ (y >> 13)) * 0x85EBCA77u;
+    s1 = (a >> 8) & mask;
+    s2 = (b >> 8) & mask;
+    if (s2 == s1) s2 = (s1 + 1) & mask;
+}
+
 constexpr uint32_t NO_ID = 0xFFFFFFFFu;
 constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
 constexpr int MAX_TOTAL_TAGS = 42;        // Program.cs:38
@@ -209,6 +236,10 @@ struct DevTables {
     const Slot* slots;           // ht_mask + 1
     const HtInfo* ht_info;       // per hash slot
     const uint64_t* str_words;   // every string again as zero-padded little-endian 8-byte words, for word-wise probe verification
+    const LeanSlot* lslots;      // the lean stage's lookup table, lslot_mask + 1 slots (null when it could not be built)
+    uint32_t lslot_mask;
+    const uint32_t* attr2;       // per id: flags, byte length (two words)
+    const uint32_t* crec;        // per id, eight words: flags, byte length, Rec::lit, min(step count, 3), step0, step1, s0_info, s1_info
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:
     const uint32_t* step_ids;    //   NormalizeTag(it), then the implied tags of that (Program.cs:1164-1175); empty when nothing can change
     const uint32_t* reach_off;   // n_strings + 1: every other string the closure of {it} holds, as pairs

@@ -169,46 +169,111 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast_triage(DevTables t, FastArgs a) { fast_body<1, true>(t, a); }
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2_triage(DevTables t, FastArgs a) { fast_body<2, true>(t, a); }
 
-// The lean stage (tp_lean.h) over the whole range; the files it declines go to a.slow_list for the stages above.
+// The lean stage (tp_lean.h) over the whole range, as two kernels: the front half (line scan, token lookup, Distinct) leaves
+// each file's candidates - interned ids - in the file's row of the id array and marks the file SLOT_LEAN; the back half takes
+// every file so marked from the candidates to the final tag ids.  Files either half declines go to a.slow_list for the
+// stages above.  The table image is read from device memory through the constant address space: its scalars come by scalar
+// loads at the places that use them instead of occupying registers for the whole kernel.
 constexpr int LEAN_WAVES_PER_BLOCK = 4;
-#ifndef TP_LEAN_WAVES_PER_SIMD
-#define TP_LEAN_WAVES_PER_SIMD 6
+#ifndef TP_LEAN_A_WAVES_PER_SIMD
+#define TP_LEAN_A_WAVES_PER_SIMD 8
 #endif
-__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_WAVES_PER_SIMD))) void k_lean(DevTables t, FastArgs a) {
+#ifndef TP_LEAN_B_WAVES_PER_SIMD
+#define TP_LEAN_B_WAVES_PER_SIMD 6
+#endif
+typedef const __attribute__((address_space(4))) DevTables ConstTables;
+__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_A_WAVES_PER_SIMD))) void k_lean_a(FastArgs a) {
+    __shared__ LeanFrontLds lds[LEAN_WAVES_PER_BLOCK];
+    __shared__ LeanShared shared;
+    __shared__ DeclineBuf dbuf[LEAN_WAVES_PER_BLOCK];
+    ConstTables& t = *(ConstTables*)(uintptr_t)a.tables;
+    lean_shared_init(t, shared, threadIdx.x, blockDim.x);
+    __syncthreads();
+    uint32_t n_declined = 0;
+    LeanFrontLds& L = lds[threadIdx.x >> 6];
+    DevWave w;
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_items = a.file_end - a.file0;
+    // Two files ahead the wave reads a file's offsets, one file ahead its piece of the line, so that neither load is
+    // waited for when its file's turn comes.
+    auto bounds = [&](uint64_t i, uint64_t& o, uint32_t& len) {
+        o = 0; len = 0xFFFFFFFFu;
+        if (i < n_items) { o = a.offsets[a.file0 + i]; const uint64_t l = a.offsets[a.file0 + i + 1] - o; len = l <= LEAN_LINE_MAX ? (uint32_t)l : 0xFFFFFFFFu; }
+    };
+    uint64_t o0, o1, o2;
+    uint32_t len0, len1, len2;
+    uint32_t x0[4], x1[4] = {0, 0, 0, 0};
+    bounds(wave_global, o0, len0);
+    bounds(wave_global + n_waves, o1, len1);
+    x0[0] = x0[1] = x0[2] = x0[3] = 0;
+    if (len0 != 0xFFFFFFFFu) lean_fetch(w, a.arena + o0, len0, x0);
+    for (uint64_t i = wave_global; i < n_items; i += n_waves) {
+        const uint64_t f = a.file0 + i;
+        bounds(i + 2 * n_waves, o2, len2);
+        if (len1 != 0xFFFFFFFFu) lean_fetch(w, a.arena + o1, len1, x1);
+        bool done = false;
+        uint32_t n_cand = 0;
+        if (len0 != 0xFFFFFFFFu) done = lean_front(w, t, L, shared, a.arena + o0, len0, x0, a.fin32 + i * FAST_FIN_MAX, n_cand);
+        o0 = o1; len0 = len1; o1 = o2; len1 = len2;
+        x0[0] = x1[0]; x0[1] = x1[1]; x0[2] = x1[2]; x0[3] = x1[3];
+        if (done) {
+            if (w.lane() == 0) { a.n_final[f] = n_cand; a.slot_of[f] = SLOT_LEAN; }
+        } else {
+            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
+        }
+        w.sync();
+    }
+    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
+#ifdef TP_PROF
+    w.flush();
+#endif
+}
+__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_B_WAVES_PER_SIMD))) void k_lean_b(FastArgs a) {
     __shared__ LeanLds lds[LEAN_WAVES_PER_BLOCK];
     __shared__ LeanShared shared;
+    __shared__ DeclineBuf dbuf[LEAN_WAVES_PER_BLOCK];
     extern __shared__ uint32_t rc_lds[];                        // the rule cache, t.rc_words words (dynamic LDS)
+    ConstTables& t = *(ConstTables*)(uintptr_t)a.tables;
     for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
     lean_shared_init(t, shared, threadIdx.x, blockDim.x);
     __syncthreads();
-    __shared__ DeclineBuf dbuf[LEAN_WAVES_PER_BLOCK];
     uint32_t n_declined = 0;
     LeanLds& L = lds[threadIdx.x >> 6];
     DevWave w;
     const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_items = a.file_end - a.file0;
+    // one file ahead: whether the front half passed the file, its candidate count and ids
+    auto peek = [&](uint64_t i, uint32_t& n_cand, uint32_t& id) {
+        n_cand = 0xFFFFFFFFu; id = NO_ID;
+        if (i < n_items && a.slot_of[a.file0 + i] == SLOT_LEAN) {
+            n_cand = a.n_final[a.file0 + i];
+            id = a.fin32[i * FAST_FIN_MAX + w.lane()];           // entries behind the count are never used
+        }
+    };
+    uint32_t n0, id0, n1, id1;
+    peek(wave_global, n0, id0);
     for (uint64_t i = wave_global; i < n_items; i += n_waves) {
         const uint64_t f = a.file0 + i;
-        const uint64_t o = a.offsets[f];
-        const uint64_t len64 = a.offsets[f + 1] - o;
-        bool done = false;
-        FastOut out;
-        if (len64 <= LEAN_LINE_MAX) {
-            done = lean_file(w, t, L, shared, rc_lds, a.arena + o, (uint32_t)len64, out, a.fin32 + i * FAST_FIN_MAX, a.fired ? a.fired + f * t.fired_words : nullptr,
-                             a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
-        }
-        if (done) {
-            if (w.lane() == 0) {
-                a.verdicts[f] = out.verdict;
-                a.n_final[f] = out.n_final;
-                a.cap_len[f] = out.caption_len;
-                a.slot_of[f] = SLOT_FAST;
+        peek(i + n_waves, n1, id1);
+        if (n0 != 0xFFFFFFFFu) {
+            FastOut out;
+            const bool done = lean_back(w, t, L, shared, rc_lds, w.lane() < n0 ? id0 : NO_ID, n0, out, a.fin32 + i * FAST_FIN_MAX,
+                                        a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+            if (done) {
+                if (w.lane() == 0) {
+                    a.verdicts[f] = out.verdict;
+                    a.n_final[f] = out.n_final;
+                    a.cap_len[f] = out.caption_len;
+                    a.slot_of[f] = SLOT_FAST;
+                }
+            } else {
+                decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
             }
-        } else {
-            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
+            w.sync();
         }
-        w.sync();
+        n0 = n1; id0 = id1;
     }
     decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
 #ifdef TP_PROF
@@ -543,7 +608,10 @@ struct EmitCounts {
 // One wavefront per file.  The caption is put together in LDS at the same 16-byte phase as its place in the output,
 // then stored with aligned 16-byte stores.  Two files ahead the wave loads a file's sizes and tag ids, one file ahead
 // the tags' string offsets, so that the dependent loads of three files are in flight at once.
-__global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_emit(DevTables t, EmitArgs a) {
+#ifndef TP_EMIT_WAVES_PER_SIMD
+#define TP_EMIT_WAVES_PER_SIMD 5
+#endif
+__global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu(TP_EMIT_WAVES_PER_SIMD))) void k_emit(DevTables t, EmitArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[EMIT_WAVES][EMIT_STAGE + 32];
     const uint32_t lane = threadIdx.x & 63;
     uint8_t* stage = stage_all[threadIdx.x >> 6];
@@ -774,9 +842,11 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     const bool tr = a.triage != 0;
     if (a.stage == 0) {
-        static const unsigned lean_blocks = [] { const char* e = getenv("TAGPIPE_LEAN_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
+        static const unsigned lean_blocks_a = [] { const char* e = getenv("TAGPIPE_LEAN_A_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
+        static const unsigned lean_blocks_b = [] { const char* e = getenv("TAGPIPE_LEAN_B_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
         want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK;
-        hipLaunchKernelGGL(k_lean, dim3((unsigned)(want < lean_blocks ? want : lean_blocks)), dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+        hipLaunchKernelGGL(k_lean_a, dim3((unsigned)(want < lean_blocks_a ? want : lean_blocks_a)), dim3(64 * LEAN_WAVES_PER_BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_lean_b, dim3((unsigned)(want < lean_blocks_b ? want : lean_blocks_b)), dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
     } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
@@ -816,7 +886,8 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (a.fin32 && a.fast_ran) {                            // the wave-per-file kernel ran: its files first
         uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
-        unsigned blocks = (unsigned)(want < 256 * 5 ? want : 256 * 5);   // five blocks (twenty wavefronts) per CU
+        static const unsigned per_cu = [] { const char* e = getenv("TAGPIPE_EMIT_BLOCKS_PER_CU"); return e ? (unsigned)atoi(e) : (unsigned)TP_EMIT_WAVES_PER_SIMD; }();
+        unsigned blocks = (unsigned)(want < 256 * per_cu ? want : 256 * per_cu);   // as many blocks (of four wavefronts) per CU as fit at once
         hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

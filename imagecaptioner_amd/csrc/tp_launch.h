@@ -9,6 +9,7 @@
 namespace tp {
 
 constexpr uint32_t SLOT_FAST = 0xFFFFFFFFu;   // slot_of[file]: the file was finished by the wave-per-file kernel
+constexpr uint32_t SLOT_LEAN = 0xFFFFFFFEu;   // ... the lean stage's front half has left the file's candidates for its back half
 
 // Wave-per-file kernel over files [file0, file_end) (line ingest only).
 struct FastArgs {
@@ -34,6 +35,7 @@ struct FastArgs {
     int stage;                    // 0: the lean stage (tp_lean.h); 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)
     uint32_t* fired;
     uint16_t* facet_choice;
+    const DevTables* tables;      // the lean stage: the table image in device memory (the other kernels take it as an argument)
 };
 
 // General kernel: items are files file0 + i, or slow_list[i] when a list is given.  Item i uses lane i & 63 of

@@ -53,38 +53,46 @@ extern "C" unsigned long long g_lean_declines[32];
 namespace tp {
 
 constexpr uint32_t LEAN_LINE_MAX = 1008;      // with the start's 16-byte phase at most 64 pieces of 16 bytes: one per lane
-constexpr uint32_t LEAN_TAB_BITS = 8;
-constexpr uint32_t LEAN_TAB = 1u << LEAN_TAB_BITS;   // slots per min-order table
+#ifndef LEAN_BACK_TAB_BITS
+#define LEAN_BACK_TAB_BITS 8
+#endif
 constexpr uint32_t LEAN_ID_BITS = 20;         // table values are order << 20 | id
 constexpr uint32_t LEAN_ID_MASK = (1u << LEAN_ID_BITS) - 1;
 constexpr uint32_t LEAN_DEAD = 0xFFFFFFFFu;   // no element
 constexpr uint32_t LEAN_ROUNDS = 5;
 constexpr uint32_t LEAN_FACETS_MAX = 64;      // one facet per lane
 constexpr uint32_t LEAN_LIT_WORDS = 64;       // evidence bitset words (2048 rule literals)
-constexpr uint32_t LEAN_CAND_WORDS = 12;      // words of a candidate's record in LDS
+constexpr uint32_t LEAN_CAND_WORDS = 8;       // words of a candidate's record in LDS
 
 // What the rest of the pipeline needs to know about a candidate, kept in LDS from the token lookup to the point where the
 // selected tags are put on the lanes by position (so that it does not occupy registers in between).
 struct LeanCand {
     uint32_t id, flags, len, step_cnt;
-    uint32_t step0, step1, s0_flags, s1_flags;   // the two steps of one ExpandImpliedTags visit (Rec) and, with FL_LEAF2, their flags ...
-    uint32_t s0_len, s1_len, pad0, pad1;         // ... and byte lengths
+    uint32_t step0, step1, pad0, pad1;       // the first two steps of one ExpandImpliedTags visit (Rec::step0 / step1), NO_ID when absent
 };
-static_assert(sizeof(LeanCand) == 4 * LEAN_CAND_WORDS, "three 16-byte pieces");
+static_assert(sizeof(LeanCand) == 4 * LEAN_CAND_WORDS, "two 16-byte pieces");
 // Tags one level further down (steps of a selected tag's steps), per position: two per lane.
 struct LeanDeep { uint32_t val, flags, len, pad; };
 
+// The front half's LDS state per wavefront (line scan, token lookup, Distinct) ...
+struct alignas(16) LeanFrontLds {
+    uint8_t line[16 + 1024 + 48];             // 16 spare bytes in front, 64 pieces, slack for 32-byte token reads
+    uint32_t cpos[68];                        // cpos[1 + k]: position of comma k in the text; cpos[0] = -1, cpos[T] = len
+    static constexpr uint32_t TAB_BITS = 8, TAB = 1u << TAB_BITS;   // slots per min-order table
+    uint32_t tab[2 * TAB];                    // two min-order tables
+};
+// ... and the back half's (everything from the candidates on).
 struct alignas(16) LeanLds {
     union {
-        uint8_t line[16 + 1024 + 48];         // 16 spare bytes in front, 64 pieces, slack for 32-byte token reads
-        LeanCand cand[64];                    // after the token lookup
-        LeanDeep deep[2][64];                 // after the selected tags are on the lanes
+        LeanCand cand[64];                    // the candidates' records, until the selected tags are on the lanes by position
+        LeanDeep deep[2][64];                 // after that
     };
-    uint32_t cpos[68];                        // cpos[1 + k]: position of comma k in the text; cpos[0] = -1, cpos[T] = len
-    uint32_t tab[2 * LEAN_TAB];               // two min-order tables
+    static constexpr uint32_t TAB_BITS = LEAN_BACK_TAB_BITS, TAB = 1u << TAB_BITS;   // slots per min-order table
+    uint32_t tab[2 * TAB];                    // two min-order tables
     uint32_t ebits[LEAN_LIT_WORDS];           // evidence bitset over the rule literals
     uint32_t fhit[FAST_FRULES_MAX / 32];      // bit p: facet rule p matches the evidence
     uint32_t inv[64];                         // selected position -> candidate lane
+    uint32_t act[64][4];                      // the tags the action rules offer, in rule order: val, flags, length
     uint32_t scratch[4];
 };
 // Per block: masks that cut a 32-byte read down to a token's length; the tags SelectTags adds before the candidates.
@@ -92,7 +100,8 @@ struct alignas(16) LeanShared {
     uint64_t tail_mask[33][4];
     uint32_t prefix_ids[MAX_TOTAL_TAGS], prefix_flags[MAX_TOTAL_TAGS], prefix_len[MAX_TOTAL_TAGS];
 };
-TP_HD void lean_shared_init(const DevTables& t, LeanShared& S, uint32_t tid, uint32_t nthreads) {
+template <class TT>
+TP_HD void lean_shared_init(const TT& t, LeanShared& S, uint32_t tid, uint32_t nthreads) {
     for (uint32_t k = tid; k < 33 * 4; k += nthreads) S.tail_mask[k >> 2][k & 3] = word_mask(k >> 2, k & 3);
     for (uint32_t k = tid; k < (uint32_t)MAX_TOTAL_TAGS; k += nthreads) {
         S.prefix_ids[k] = k < t.n_prefix ? t.prefix_ids[k] : NO_ID;
@@ -102,7 +111,7 @@ TP_HD void lean_shared_init(const DevTables& t, LeanShared& S, uint32_t tid, uin
 }
 // The tables fit this stage at all (checked once on the host).
 inline bool lean_tables_ok(const DevTables& t) {
-    return t.fast_ok && t.prefix_simple && t.n_strings <= LEAN_ID_MASK && t.n_facets <= LEAN_FACETS_MAX && t.n_prefix <= 8 && !t.rules_vacuous &&
+    return t.fast_ok && t.prefix_simple && t.lslots != nullptr && t.n_strings <= LEAN_ID_MASK && t.n_facets <= LEAN_FACETS_MAX && t.n_prefix <= 8 && !t.rules_vacuous &&
            t.lit_words <= LEAN_LIT_WORDS;
 }
 
@@ -120,27 +129,27 @@ TP_HD uint32_t lean_val(uint32_t order, uint32_t id, bool live) { return live ? 
 // First occurrences by min-order tables.  val[e] = order << 20 | id describes element e of this lane (orders are distinct
 // and below 2^12, ids below 2^20), LEAN_DEAD means no element.  Bit e of the result is set for the element with the lowest
 // order among those with its id; bit 31 is set when elements are left undecided after LEAN_ROUNDS rounds (wave-uniform).
-template <int NE, class W>
-TP_HD __attribute__((always_inline)) uint32_t lean_first(W& w, LeanLds& L, const uint32_t (&val)[NE]) {
+template <int NE, class W, class LDS>
+TP_HD __attribute__((always_inline)) uint32_t lean_first(W& w, LDS& L, const uint32_t (&val)[NE]) {
     uint32_t pend = 0, first = 0;
     TP_UNROLL for (int e = 0; e < NE; ++e) pend |= (uint32_t)(val[e] != LEAN_DEAD) << e;
     for (uint32_t round = 0; round < LEAN_ROUNDS; ++round) {
-        static_assert((2 * LEAN_TAB) % 256 == 0, "whole 16-byte stores per lane");
-        TP_UNROLL for (uint32_t k = 0; k < 2 * LEAN_TAB / 256; ++k) w.fill16(&L.tab[256 * k + 4 * w.lane()], 0xFFFFFFFFu);
+        static_assert((2 * LDS::TAB) % 256 == 0, "whole 16-byte stores per lane");
+        TP_UNROLL for (uint32_t k = 0; k < 2 * LDS::TAB / 256; ++k) w.fill16(&L.tab[256 * k + 4 * w.lane()], 0xFFFFFFFFu);
         w.sync();
         const uint32_t K = round == 0 ? 2654435761u : (round == 1 ? 0x85EBCA77u : (round == 2 ? 0xC2B2AE3Du : (round == 3 ? 0x27D4EB2Fu : 0x165667B1u)));
         uint32_t p[NE];
         TP_UNROLL for (int e = 0; e < NE; ++e) {
             p[e] = (val[e] & LEAN_ID_MASK) * K;
             if ((pend >> e) & 1u) {
-                w.lds_min(&L.tab[p[e] >> (32 - LEAN_TAB_BITS)], val[e]);
-                w.lds_min(&L.tab[LEAN_TAB + ((p[e] >> (32 - 2 * LEAN_TAB_BITS)) & (LEAN_TAB - 1))], val[e]);
+                w.lds_min(&L.tab[p[e] >> (32 - LDS::TAB_BITS)], val[e]);
+                w.lds_min(&L.tab[LDS::TAB + ((p[e] >> (32 - 2 * LDS::TAB_BITS)) & (LDS::TAB - 1))], val[e]);
             }
         }
         w.sync();
         TP_UNROLL for (int e = 0; e < NE; ++e) {
             if ((pend >> e) & 1u) {
-                const uint32_t va = L.tab[p[e] >> (32 - LEAN_TAB_BITS)], vb = L.tab[LEAN_TAB + ((p[e] >> (32 - 2 * LEAN_TAB_BITS)) & (LEAN_TAB - 1))];
+                const uint32_t va = L.tab[p[e] >> (32 - LDS::TAB_BITS)], vb = L.tab[LDS::TAB + ((p[e] >> (32 - 2 * LDS::TAB_BITS)) & (LDS::TAB - 1))];
                 const bool ma = ((va ^ val[e]) & LEAN_ID_MASK) == 0, mb = ((vb ^ val[e]) & LEAN_ID_MASK) == 0;
                 if (ma || mb) { first |= (uint32_t)((ma ? va : vb) == val[e]) << e; pend &= ~(1u << e); }
             }
@@ -181,11 +190,156 @@ TP_HD bool lean_rc_match(const uint32_t* ebits, const uint32_t* rc, uint32_t rec
     return ok_all && ok_any && ok_forb;
 }
 
-// The pipeline for one file; false = declined.  rc: the rule cache; fin32: the caption's tag ids (FAST_FIN_MAX entries);
-// fired (fired_words words) and facet_choice may be null; with fired the evidence set is counted (tp_verdict::n_evidence).
+// The rare parts of the pipeline are functions of their own (measured: as real calls they cost the usual path more, in
+// saved and restored registers, than they take off its register count; LEAN_X_NOINLINE builds them as calls).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LEAN_X_NOINLINE)
+#define TP_NOINLINE __attribute__((noinline))
+#else
+#define TP_NOINLINE
+#endif
+
+// What the final list's elements add up to: caption bytes, tags outside the vocabulary, the first safe-mode hit, bucket bits.
+struct LeanAcc { uint32_t bytes, unknown, safe_key, bits; };
+constexpr uint32_t LA_FACE = 1, LA_OUTFIT = 2, LA_SAFE = 4, LA_FOOT = 8;
+template <class TT>
+TP_HD void lean_emit(LeanAcc& a, const TT& t, uint32_t* fin32, bool first, uint32_t val, uint32_t fl, uint32_t ln, uint32_t at) {
+    if (first) {
+        const uint32_t bk = fl_bucket(fl), eid = val & LEAN_ID_MASK;
+        if (bk == B_FACE) a.bits |= LA_FACE;                        // MissingCoreBuckets, Program.cs:1097-1101
+        if (bk == B_OUTFIT) a.bits |= LA_OUTFIT;
+        if (fl & FL_SAFE) { a.bits |= LA_SAFE; const uint32_t key = (at << 8) | ((fl >> FL_SAFE_IDX_SHIFT) & 31u); a.safe_key = key < a.safe_key ? key : a.safe_key; }
+        if (eid == t.footjob_n) a.bits |= LA_FOOT;
+        a.bytes += ln;
+        a.unknown += (fl & FL_KNOWN) ? 0u : 1u;
+        fin32[at] = eid;
+    }
+}
+
+// InferActionTags (Program.cs:731-753) for a file whose evidence holds a literal some rule tests positively: the tags of
+// the rules and subtypes that match go to L.act in rule order, their bits to `fired` (when asked for).  Returns how many
+// tags there are, LEAN_DEAD when the file is not for this stage.
+template <class W, class TT>
+TP_HD TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uint32_t* rc, uint32_t* fired) {
+    const uint32_t lane = w.lane();
+    uint32_t* firedw = L.tab;                                       // the table area is idle here
+    static_assert(FAST_FIRED_WORDS <= 2 * LeanLds::TAB, "the fired bitmap fits the table area");
+    if (lane < t.fired_words) firedw[lane] = 0;
+    w.sync();
+    uint32_t n_act = 0;
+    bool changes = false;
+    for (uint32_t r0 = 0; r0 < t.n_rules; r0 += 64) {
+        const uint32_t ri = r0 + lane;
+        const bool hit = ri < t.n_rules && lean_rc_match(L.ebits, rc, ri * RC_REC_WORDS);   // MatchesActionRule, Program.cs:777-782
+        uint64_t m = w.ballot(hit);
+        if (hit) w.lds_or(&firedw[ri >> 5], 1u << (ri & 31));                              // "action:{parent}" (Program.cs:741)
+        while (m) {
+            const uint32_t* rr = rc + (r0 + ctz64(m)) * RC_REC_WORDS;
+            m &= m - 1;
+            const uint32_t sub_off = rr[1], sub_cnt = rr[3] >> 16;
+            if (rr[3] & 0x8000u) changes = true;                   // a tag NormalizeTag changes
+            if (n_act >= 64) return LEAN_DEAD;
+            if (lane == 0) { L.act[n_act][0] = lean_val(640 + n_act, rr[0], true); L.act[n_act][1] = rr[8]; L.act[n_act][2] = rr[9]; }
+            ++n_act;
+            for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
+                const uint32_t si = s0 + lane;
+                const uint32_t srec = t.rc_subs + (sub_off + (si < sub_cnt ? si : 0)) * RC_REC_WORDS;
+                const bool shit = si < sub_cnt && lean_rc_match(L.ebits, rc, srec);        // MatchesSubtypeRule, Program.cs:784-788
+                const uint64_t ms = w.ballot(shit);
+                if (n_act + popc64(ms) > 64) return LEAN_DEAD;
+                if (shit) {
+                    const uint32_t bit = t.n_rules + sub_off + si;                           // "subtype:{parent}:{tag}" (Program.cs:748)
+                    w.lds_or(&firedw[bit >> 5], 1u << (bit & 31));
+                    const uint32_t* sr = rc + srec;
+                    if (sr[3] & 0x8000u) changes = true;
+                    const uint32_t q = n_act + w.rank(ms);
+                    L.act[q][0] = lean_val(640 + q, sr[0], true); L.act[q][1] = sr[8]; L.act[q][2] = sr[9];
+                }
+                n_act += popc64(ms);
+            }
+        }
+    }
+    if (w.ballot(changes) != 0) return LEAN_DEAD;
+    w.sync();
+    if (fired && lane < t.fired_words) fired[lane] = firedw[lane];
+    w.sync();                                                       // the table area is read before its next use clears it
+    return n_act;
+}
+
+// A selected tag whose steps lead further (no FL_LEAF2): a step that is itself settled (FL_LEAF2) names the tags its visit
+// appends in the next round of ExpandImpliedTags (Program.cs:1160-1179); at most two steps, at most two of those tags per
+// selected tag, and nothing beyond them, or the file is not for this stage (returns true).  The tags go to L.deep.
+template <class W, class TT>
+TP_HD TP_NOINLINE bool lean_deep(W& w, const TT& t, LeanLds& L, bool deep, uint32_t k_cnt, uint32_t kv0, uint32_t kv1, uint32_t kf0, uint32_t kf1) {
+    const uint32_t lane = w.lane();
+    w.sync();                                                       // the candidates' records have been read: their place is taken by the deeper tags
+    bool bad_deep = deep && k_cnt > 2;
+    LeanDeep g0 = {LEAN_DEAD, 0, 0, 0}, g1 = {LEAN_DEAD, 0, 0, 0};
+    if (deep && !bad_deep) {
+        uint32_t ng = 0;
+        for (uint32_t c = 0; c < 2; ++c) {
+            const uint32_t kv = c ? kv1 : kv0, kf = c ? kf1 : kf0;
+            if (kv == LEAN_DEAD) continue;
+            if (!(kf & FL_FIX)) { bad_deep = true; continue; }     // a step NormalizeTag changes
+            if (!(kf & FL_EDGE)) continue;
+            const Rec rk = t.rec[kv & LEAN_ID_MASK];
+            if (!(rk.flags & FL_LEAF2) || ng + rk.step_cnt > 2) { bad_deep = true; continue; }
+            for (uint32_t j = 0; j < rk.step_cnt; ++j) {
+                LeanDeep g;
+                g.val = lean_val(320 + 4 * lane + 2 * c + j, j == 0 ? rk.step0 : rk.step1, true);
+                g.flags = j == 0 ? rk.s0_flags : rk.s1_flags; g.len = j == 0 ? rk.s0_len : rk.s1_len; g.pad = 0;
+                if (ng == 0) g0 = g; else g1 = g;
+                ++ng;
+            }
+        }
+    }
+    L.deep[0][lane] = g0; L.deep[1][lane] = g1;
+    w.sync();
+    return w.ballot(bad_deep) != 0;
+}
+
+// The first-occurrence pass of a file with deeper tags or action tags: seven elements per lane.
+struct LeanWide { uint32_t fb, grown2, nact; };
 template <class W>
-TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, const uint32_t* rc, const uint8_t* text, uint32_t len, FastOut& out,
-                     uint32_t* fin32, uint32_t* fired, uint16_t* facet_choice) {
+TP_HD TP_NOINLINE LeanWide lean_first_wide(W& w, LeanLds& L, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, bool any_deep, uint32_t n_act) {
+    const uint32_t lane = w.lane();
+    const uint32_t v7[7] = {v0, v1, v2, v3, any_deep ? L.deep[0][lane].val : LEAN_DEAD, any_deep ? L.deep[1][lane].val : LEAN_DEAD, lane < n_act ? L.act[lane][0] : LEAN_DEAD};
+    LeanWide r;
+    r.fb = lean_first<7>(w, L, v7);
+    r.grown2 = popc64(w.ballot(r.fb & 16u)) + popc64(w.ballot(r.fb & 32u));
+    r.nact = popc64(w.ballot(r.fb & 64u));
+    return r;
+}
+// ... and what its deeper tags (from position base_g on) and action tags (from base_a on) add to the final list.
+template <class W, class TT>
+TP_HD TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uint32_t* fin32, uint32_t fb, uint32_t base_g, uint32_t base_a, bool any_deep, uint32_t n_act) {
+    const uint32_t lane = w.lane();
+    LeanAcc a = {0, 0, 0xFFFFFFFFu, 0};
+    const uint64_t mg0 = w.ballot(fb & 16u), mg1 = w.ballot(fb & 32u), ma = w.ballot(fb & 64u);
+    if (any_deep) {
+        const LeanDeep g0 = L.deep[0][lane], g1 = L.deep[1][lane];
+        const uint32_t pos_g0 = base_g + w.rank(mg0) + w.rank(mg1);
+        lean_emit(a, t, fin32, (fb & 16u) != 0, g0.val, g0.flags, g0.len, pos_g0);
+        lean_emit(a, t, fin32, (fb & 32u) != 0, g1.val, g1.flags, g1.len, pos_g0 + ((fb >> 4) & 1u));
+    }
+    if (lane < n_act) lean_emit(a, t, fin32, (fb & 64u) != 0, L.act[lane][0], L.act[lane][1], L.act[lane][2], base_a + w.rank(ma));
+    return a;
+}
+
+// The piece of the line this lane scans: the aligned 16 bytes number `lane` from the 16-byte boundary at or before the
+// line's start (zeros behind the line's last piece).  A caller may fetch it well before lean_file needs it.
+template <class W>
+TP_HD void lean_fetch(W& w, const uint8_t* text, uint32_t len, uint32_t (&x)[4]) {
+    const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
+    x[0] = x[1] = x[2] = x[3] = 0;
+    if (len <= LEAN_LINE_MAX && 16 * w.lane() < shift + len) w.load16(text - shift + 16 * w.lane(), x);
+}
+
+// The front half for one file: line scan, token lookup, Distinct (Program.cs:589-602).  x: what lean_fetch(w, text, len, x)
+// gave.  On success the file's candidates - interned ids in candidate order - are in row[0 .. n_cand); false = declined.
+// TT: DevTables, or DevTables in the constant address space (the GPU kernels read the table scalars with scalar loads
+// where they are used).
+template <class W, class TT>
+TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, const uint8_t* text, uint32_t len, const uint32_t (&x)[4], uint32_t* row, uint32_t& n_cand) {
     const uint32_t lane = w.lane();
     if (len > LEAN_LINE_MAX || len == 0) return LEAN_NO(1);
     w.tick(16);
@@ -194,8 +348,6 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
     uint32_t T;
     {
         const uint32_t end = shift + len, pieces = (end + 15) >> 4;   // at most 64
-        uint32_t x[4] = {0, 0, 0, 0};
-        if (lane < pieces) w.load16(text - shift + 16 * lane, x);
         w.store16(L.line + 16 + 16 * lane, x);
         const uint32_t ne = ne_nibble(x[0], rep4(',')) | (ne_nibble(x[1], rep4(',')) << 4) | (ne_nibble(x[2], rep4(',')) << 8) | (ne_nibble(x[3], rep4(',')) << 12);
         const int lo16 = (int)shift - 16 * (int)lane, hi16 = (int)end - 16 * (int)lane;
@@ -215,11 +367,9 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
     }
     w.sync();
     w.tick(17);
-    LEAN_STOP(1, L.cpos[lane] ^ T)
 
     // ---- tokens -> interned ids (NormalizeRawTagLine's per-token steps and Distinct, Program.cs:598-602) -----------------
-    uint32_t id = NO_ID, f = FL_BLANK;                              // the candidate of this lane and its flags
-    uint32_t lit = NO_ID, s0_info = 0xFFFFFFu, s1_info = 0xFFFFFFu, ev_step[2] = {NO_ID, NO_ID};   // what the evidence step reads of its record
+    uint32_t id = NO_ID, f = FL_BLANK;                              // what NormalizeTag makes of this lane's token, and its flags
     bool kept = false;
     {
         const uint8_t* s = L.line + 16 + shift;
@@ -240,65 +390,86 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
             if (n > 32) decline = true;
         }
         if (w.ballot(tok && decline) != 0) return LEAN_NO(4);
-        LeanCand c;
-        c.id = NO_ID; c.flags = FL_BLANK; c.len = 0; c.step_cnt = 0; c.step0 = c.step1 = NO_ID; c.s0_flags = c.s1_flags = c.s0_len = c.s1_len = 0; c.pad0 = c.pad1 = 0;
+        bool hop = false;
         if (tok && n > 0) {
+            // the token's bytes as eight zero-padded words, its two slots, both keys at once; the payload of the slot that holds it
             const uint64_t* mk = S.tail_mask[n];
             const uint64_t w0 = ld64u(s + i2) & mk[0], w1 = ld64u(s + i2 + 8) & mk[1], w2 = ld64u(s + i2 + 16) & mk[2], w3 = ld64u(s + i2 + 24) & mk[3];
-            const uint64_t h = hash_finish(hash_word(hash_word(hash_word(hash_word(HASH_SEED, w0, 0), w1, 1), w2, 2), w3, 3), n);
-            uint32_t slot = (uint32_t)h & t.ht_mask;
-            for (;;) {
-                const Slot* sl = t.slots + slot;
-                const uint32_t slen = sl->slen, val = sl->val, kflags = sl->kflags;
-                uint64_t k[4];
-                __builtin_memcpy(k, sl->key, 32);
-                const Rec rr = sl->rec;
-                if (slen == SLOT_EMPTY) { miss = true; break; }
-                if (slen == n && ((k[0] ^ w0) | (k[1] ^ w1) | (k[2] ^ w2) | (k[3] ^ w3)) == 0) {
-                    if (kflags & SLOT_KEY_BASIC) {
-                        id = val; f = rr.flags; lit = rr.lit; s0_info = rr.s0_info; s1_info = rr.s1_info;
-                        const bool edge = (rr.flags & FL_EDGE) != 0;
-                        c.id = val; c.flags = rr.flags; c.len = rr.len; c.step_cnt = edge ? rr.step_cnt : 0;
-                        c.step0 = edge && rr.step_cnt > 0 ? rr.step0 : NO_ID; c.step1 = edge && rr.step_cnt > 1 ? rr.step1 : NO_ID;
-                        c.s0_flags = rr.s0_flags; c.s1_flags = rr.s1_flags; c.s0_len = rr.s0_len; c.s1_len = rr.s1_len;
-                        if (rr.next != val) c.pad0 = 1;            // NormalizeTag would change it again at the next site
-                    } else decline = true;                         // not its own normal form: the general stages normalise it
-                    break;
+            const uint32_t kw[8] = {(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32), (uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32)};
+            uint32_t s1, s2;
+            lean_slots(kw, n, t.lslot_mask, s1, s2);
+            const LeanSlot* A = t.lslots + s1;
+            const LeanSlot* B = t.lslots + s2;
+            uint64_t ka[4], kb[4];
+            __builtin_memcpy(ka, A->key, 32);
+            __builtin_memcpy(kb, B->key, 32);
+            const bool in_a = ((ka[0] ^ w0) | (ka[1] ^ w1) | (ka[2] ^ w2) | (ka[3] ^ w3)) == 0, in_b = ((kb[0] ^ w0) | (kb[1] ^ w1) | (kb[2] ^ w2) | (kb[3] ^ w3)) == 0;
+            miss = true;
+            if (in_a || in_b) {
+                const LeanSlot* P = in_a ? A : B;
+                uint32_t pay[2];
+                __builtin_memcpy(pay, &P->head, 8);
+                if (((pay[0] >> 20) & 63u) == n) {                  // the same length as well: the very string
+                    miss = false;
+                    id = pay[0] & LEAN_HEAD_ID_MASK; f = pay[1];
+                    hop = ((pay[0] >> 28) & 1u) != 0;
                 }
-                slot = (slot + 1) & t.ht_mask;
             }
         }
         if (w.ballot(miss) != 0) {
-            // in no table: dropped under strict vocabulary, provided it is plain; otherwise it may survive as a tag of its own
+            // in no table as it stands: dropped under strict vocabulary, provided it is plain (then normalisation leaves it
+            // alone and it is in no table at all); otherwise the general stages normalise it
             if (miss && !(t.drop_unknown && lean_plain_unknown(s + i2, n))) decline = true;
         }
         // LooksBad's phrases and code fences are looked for in the raw line (Program.cs:592-596): any token holding one declines
         if (id != NO_ID && (f & (FL_PHRASE | FL_FENCE))) decline = true;
         kept = id != NO_ID && (f & FL_LEN2) && !(f & FL_DROP);     // Length >= 2, !ShouldDropTag (Program.cs:600-601)
-        if (kept && c.pad0) decline = true;                        // tp_fast.h follows such hops
+        if (kept && hop) decline = true;                           // NormalizeTag would change it again at the next site: tp_fast.h follows such hops
         if (w.ballot(decline) != 0) return LEAN_NO(5);
-        ev_step[0] = c.step0; ev_step[1] = c.step1;
-        w.sync();                                                   // every lane has read its token: the records take the line's place
-        w.store16((uint8_t*)&L.cand[lane], (const uint32_t(&)[4])c.id);
-        w.store16((uint8_t*)&L.cand[lane] + 16, (const uint32_t(&)[4])c.step0);
-        w.store16((uint8_t*)&L.cand[lane] + 32, (const uint32_t(&)[4])c.s0_len);
     }
     w.tick(18);
-    LEAN_STOP(2, id ^ f ^ lit ^ s0_info ^ (uint32_t)kept)
-    bool act;
-    {
-        const uint32_t v1[1] = {lean_val(lane, id, kept)};
-        const uint32_t fb = lean_first<1>(w, L, v1);
-        if (fb >> 31) return LEAN_NO(6);
-        act = (fb & 1u) != 0;
-    }
-    if (!act) f = FL_BLANK;
+    // Distinct (Program.cs:602): first occurrences, handed on in candidate order
+    const uint32_t v1[1] = {lean_val(lane, id, kept)};
+    const uint32_t fb = lean_first<1>(w, L, v1);
+    if (fb >> 31) return LEAN_NO(6);
+    const bool act = (fb & 1u) != 0;
+    const uint64_t m_act = w.ballot(act);
+    n_cand = popc64(m_act);
+    if (act) row[w.rank(m_act)] = id;
     w.tick(19);
-    LEAN_STOP(3, id ^ (uint32_t)act ^ f ^ lit ^ s0_info)
+    return true;
+}
+
+// The back half for one file: everything from the candidates on (Program.cs:223-229, 292-329).  id: candidate number `lane`
+// of the file (lane < n_cand; NO_ID otherwise), as lean_front left it.  rc: the rule cache; fin32: the caption's tag ids
+// (FAST_FIN_MAX entries); fired (fired_words words) and facet_choice may be null; with fired the evidence set is counted
+// (tp_verdict::n_evidence).  false = declined.
+template <class W, class TT>
+TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const uint32_t* rc, uint32_t id, uint32_t n_cand, FastOut& out, uint32_t* fin32,
+                     uint32_t* fired, uint16_t* facet_choice) {
+    const uint32_t lane = w.lane();
+    const bool act = lane < n_cand;
+    const uint32_t ci = lane;
+    // the candidate's record: what NormalizeTag, ClassifyTag, the rules and ExpandImpliedTags need to know of the string
+    uint32_t f = FL_BLANK, lit = NO_ID, s0_info = 0xFFFFFFu, s1_info = 0xFFFFFFu, ev_step[2] = {NO_ID, NO_ID};
+    {
+        LeanCand c;
+        c.id = NO_ID; c.flags = FL_BLANK; c.len = 0; c.step_cnt = 0; c.step0 = c.step1 = NO_ID; c.pad0 = c.pad1 = 0;
+        if (act) {
+            uint32_t cr[8];
+            __builtin_memcpy(cr, t.crec + 8 * (size_t)id, 32);
+            f = cr[0]; lit = cr[2]; s0_info = cr[6]; s1_info = cr[7];
+            const bool edge = (f & FL_EDGE) != 0;
+            c.id = id; c.flags = f; c.len = cr[1]; c.step_cnt = edge ? cr[3] : 0;
+            c.step0 = edge ? cr[4] : NO_ID; c.step1 = edge ? cr[5] : NO_ID;
+            ev_step[0] = c.step0; ev_step[1] = c.step1;
+        }
+        w.store16((uint8_t*)&L.cand[lane], (const uint32_t(&)[4])c.id);
+        w.store16((uint8_t*)&L.cand[lane] + 16, (const uint32_t(&)[4])c.step0);
+    }
+    w.tick(20);
 
     // ---- candidates (Program.cs:625-655): scores fall with the candidate index, so sorted order is candidate order ----------
-    const uint64_t m_act = w.ballot(act);
-    const uint32_t n_cand = popc64(m_act), ci = w.rank(m_act);
     const bool nonblank = act && !(f & FL_BLANK);
     const bool bad = nonblank && (!(f & FL_VALID) || (f & FL_DROP));
     const uint32_t n_dropped = popc64(w.ballot(bad));               // "{n}:invalid_tag" / "{n}:policy_drop"
@@ -351,12 +522,10 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
     }
     w.sync();
     w.tick(21);
-    LEAN_STOP(5, id ^ f ^ L.ebits[lane & 1] ^ (uint32_t)ev_feet ^ (uint32_t)ev_penis ^ n_evidence)
 
     // ---- InferActionTags / EnsureRequiredFacets (Program.cs:731-775): both read the evidence only -------------------------
     bool frules_possible;
-    uint32_t a_val = LEAN_DEAD, a_fl = 0, a_len = 0;                // lane q: the q-th tag the action rules offer, in rule order
-    uint32_t n_act = 0;
+    uint32_t n_act = 0;                                             // tags the action rules offer (in L.act)
     {
         bool lit_r = false, lit_f = false;
         for (uint32_t k = lane; k < t.lit_words; k += 64) {
@@ -365,54 +534,11 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
             lit_f = lit_f || (e & rc[t.rc_frule_mask + k]) != 0;
         }
         frules_possible = t.frules_vacuous || w.ballot(lit_f) != 0;
-        bool rules_fired = false;
-        if (w.ballot(lit_r) != 0) {                                 // the evidence holds a literal some action rule tests positively: look closer
-            // offered tags and fired bits are put together in the (idle) table area: 3 words per tag, then the bitmap
-            uint32_t* acts = L.tab;
-            uint32_t* firedw = L.tab + 3 * 64;
-            static_assert(3 * 64 + FAST_FIRED_WORDS <= 2 * LEAN_TAB, "the action list fits the table area");
-            if (lane < t.fired_words) firedw[lane] = 0;
-            w.sync();
-            bool changes = false;
-            for (uint32_t r0 = 0; r0 < t.n_rules; r0 += 64) {
-                const uint32_t ri = r0 + lane;
-                const bool hit = ri < t.n_rules && lean_rc_match(L.ebits, rc, ri * RC_REC_WORDS);   // MatchesActionRule, Program.cs:777-782
-                uint64_t m = w.ballot(hit);
-                if (hit) w.lds_or(&firedw[ri >> 5], 1u << (ri & 31));                              // "action:{parent}" (Program.cs:741)
-                while (m) {
-                    rules_fired = true;
-                    const uint32_t* rr = rc + (r0 + ctz64(m)) * RC_REC_WORDS;
-                    m &= m - 1;
-                    const uint32_t sub_off = rr[1], sub_cnt = rr[3] >> 16;
-                    if (rr[3] & 0x8000u) changes = true;           // a tag NormalizeTag changes
-                    if (n_act >= 64) return LEAN_NO(11);
-                    if (lane == 0) { acts[3 * n_act] = rr[0]; acts[3 * n_act + 1] = rr[8]; acts[3 * n_act + 2] = rr[9]; }
-                    ++n_act;
-                    for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
-                        const uint32_t si = s0 + lane;
-                        const uint32_t srec = t.rc_subs + (sub_off + (si < sub_cnt ? si : 0)) * RC_REC_WORDS;
-                        const bool shit = si < sub_cnt && lean_rc_match(L.ebits, rc, srec);        // MatchesSubtypeRule, Program.cs:784-788
-                        const uint64_t ms = w.ballot(shit);
-                        if (n_act + popc64(ms) > 64) return LEAN_NO(11);
-                        if (shit) {
-                            const uint32_t bit = t.n_rules + sub_off + si;                           // "subtype:{parent}:{tag}" (Program.cs:748)
-                            w.lds_or(&firedw[bit >> 5], 1u << (bit & 31));
-                            const uint32_t* sr = rc + srec;
-                            if (sr[3] & 0x8000u) changes = true;
-                            const uint32_t q = n_act + w.rank(ms);
-                            acts[3 * q] = sr[0]; acts[3 * q + 1] = sr[8]; acts[3 * q + 2] = sr[9];
-                        }
-                        n_act += popc64(ms);
-                    }
-                }
-            }
-            if (w.ballot(changes) != 0) return LEAN_NO(11);
-            w.sync();
-            if (lane < n_act) { a_val = lean_val(640 + lane, acts[3 * lane], true); a_fl = acts[3 * lane + 1]; a_len = acts[3 * lane + 2]; }
-            if (fired && lane < t.fired_words) fired[lane] = firedw[lane];
-            w.sync();                                               // the table area is read before the next use clears it
-        }
-        if (fired && !rules_fired && lane < t.fired_words) fired[lane] = 0;
+        const bool rules_possible = w.ballot(lit_r) != 0;           // the evidence holds a literal some action rule tests positively: look closer
+        if (rules_possible) {
+            n_act = lean_actions(w, t, L, rc, fired);
+            if (n_act == LEAN_DEAD) return LEAN_NO(11);
+        } else if (fired && lane < t.fired_words) fired[lane] = 0;
     }
     uint32_t f_val = LEAN_DEAD, f_fl = 0, f_len = 0;               // lane q: the tag facet q asks for
     {
@@ -448,7 +574,6 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
         if (w.ballot(changes) != 0) return LEAN_NO(12);             // a facet tag NormalizeTag changes
     }
     w.tick(22);
-    LEAN_STOP(6, id ^ f ^ f_val ^ f_fl ^ f_len ^ a_val ^ a_fl ^ a_len)
 
     // ---- SelectTags' bucket fills (Program.cs:661-699) ------------------------------------------------------------------------
     uint32_t nr = t.n_prefix;
@@ -475,7 +600,6 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
     }
     w.sync();
     w.tick(20);
-    LEAN_STOP(4, id ^ nr ^ L.inv[lane] ^ n_dropped ^ n_cand ^ f_val ^ a_val)
 
     // ---- the selected tags by position; EvaluateCoverage (Program.cs:1056-1095) --------------------------------------------
     // position p < n_prefix: a prefix tag; else the candidate of lane inv[p]
@@ -488,7 +612,9 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
             const LeanCand& c = L.cand[L.inv[lane]];
             p_val = lean_val(lane, c.id, true); p_fl = c.flags; p_len = c.len; k_cnt = c.step_cnt;
             k_val[0] = lean_val(64 + 2 * lane, c.step0, c.step0 != NO_ID); k_val[1] = lean_val(65 + 2 * lane, c.step1, c.step1 != NO_ID);
-            k_fl[0] = c.s0_flags; k_fl[1] = c.s1_flags; k_len[0] = c.s0_len; k_len[1] = c.s1_len;
+            // the steps' flags and lengths: asked for here, used after the first-occurrence pass
+            if (c.step0 != NO_ID) { k_fl[0] = t.attr2[2 * c.step0]; k_len[0] = t.attr2[2 * c.step0 + 1]; }
+            if (c.step1 != NO_ID) { k_fl[1] = t.attr2[2 * c.step1]; k_len[1] = t.attr2[2 * c.step1 + 1]; }
         } else {
             p_val = lean_val(lane, S.prefix_ids[lane], true); p_fl = S.prefix_flags[lane]; p_len = S.prefix_len[lane];
         }
@@ -502,47 +628,20 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
                    (w.ballot(nb && (p_fl & FL_EYES)) ? TP_COV_EYES : 0) | (w.ballot(nb && fl_bucket(p_fl) == B_OUTFIT) ? TP_COV_OUTFIT : 0) |
                    (w.ballot(nb && fl_bucket(p_fl) == B_POSE) ? TP_COV_POSE_ACTION : 0) | (w.ballot(nb && fl_bucket(p_fl) == B_BACKGROUND) ? TP_COV_BACKGROUND : 0);
     }
-    // A selected tag whose steps lead further (no FL_LEAF2): the steps' own records give their flags and lengths and, when a
-    // step is itself settled (FL_LEAF2), the tags its visit appends in the next round of ExpandImpliedTags (Program.cs:1160-1179);
-    // at most two of those per selected tag, at most two steps, and nothing beyond them, or the file is declined.
+    // a selected tag with FL_LEAF2 has steps NormalizeTag leaves alone and that lead nowhere further; the others' steps are followed one level down
     const bool deep = in_sel && (p_fl & FL_EDGE) && !(p_fl & FL_LEAF2);
     const bool any_deep = w.ballot(deep) != 0;
-    if (any_deep) {
-        w.sync();                                                   // the candidates' records have been read: their place is taken by the deeper tags
-        bool bad_deep = deep && k_cnt > 2;
-        LeanDeep g[2] = {{LEAN_DEAD, 0, 0, 0}, {LEAN_DEAD, 0, 0, 0}};
-        if (deep && !bad_deep) {
-            uint32_t ng = 0;
-            for (uint32_t c = 0; c < 2; ++c) {
-                if (k_val[c] == LEAN_DEAD) continue;
-                const uint32_t kid = k_val[c] & LEAN_ID_MASK;
-                const Rec rk = t.rec[kid];
-                if (rk.next != kid || (rk.flags & FL_BLANK)) bad_deep = true;
-                k_fl[c] = rk.flags; k_len[c] = rk.len;
-                if (rk.flags & FL_EDGE) {
-                    if (!(rk.flags & FL_LEAF2) || ng + rk.step_cnt > 2) { bad_deep = true; continue; }
-                    for (uint32_t j = 0; j < rk.step_cnt; ++j) {
-                        g[ng].val = lean_val(320 + 4 * lane + 2 * c + j, j == 0 ? rk.step0 : rk.step1, true);
-                        g[ng].flags = j == 0 ? rk.s0_flags : rk.s1_flags; g[ng].len = j == 0 ? rk.s0_len : rk.s1_len;
-                        ++ng;
-                    }
-                }
-            }
-        }
-        if (w.ballot(bad_deep) != 0) return LEAN_NO(15);
-        L.deep[0][lane] = g[0]; L.deep[1][lane] = g[1];
-        w.sync();
-    }
+    if (any_deep && lean_deep(w, t, L, deep, k_cnt, k_val[0], k_val[1], k_fl[0], k_fl[1])) return LEAN_NO(15);
 
     // ---- the final set in the reference's insertion order (Program.cs:303-307): the selected tags, their implied tags by
     // position (and those one level further, by their parents' positions), the action tags by rule, the facet tags by
     // facet; an id already present is not added again.  Then the verdicts on the final list (Program.cs:309-329),
     // GetUnknownTags (:817-824) and the caption's length (:971-974), element by element ----------------------------------------
     const bool wide = any_deep || n_act != 0;                       // the usual file has the first four kinds of element only
-    uint32_t fb;
+    uint32_t fb, grown2 = 0, nact = 0;
     if (wide) {
-        const uint32_t v7[7] = {p_val, k_val[0], k_val[1], f_val, any_deep ? L.deep[0][lane].val : LEAN_DEAD, any_deep ? L.deep[1][lane].val : LEAN_DEAD, a_val};
-        fb = lean_first<7>(w, L, v7);
+        const LeanWide r = lean_first_wide(w, L, p_val, k_val[0], k_val[1], f_val, any_deep, n_act);
+        fb = r.fb; grown2 = r.grown2; nact = r.nact;
     } else {
         const uint32_t v4[4] = {p_val, k_val[0], k_val[1], f_val};
         fb = lean_first<4>(w, L, v4);
@@ -551,43 +650,22 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
     const uint64_t mk0 = w.ballot(fb & 2u), mk1 = w.ballot(fb & 4u), mf = w.ballot(fb & 8u);
     const uint32_t grown1 = popc64(mk0) + popc64(mk1), nfac = popc64(mf);
     const uint32_t pos_k0 = nr + w.rank(mk0) + w.rank(mk1), rank_f = w.rank(mf);
-    uint32_t grown2 = 0, nact = 0, pos_g0 = 0, rank_a = 0;
-    if (wide) {
-        const uint64_t mg0 = w.ballot(fb & 16u), mg1 = w.ballot(fb & 32u), ma = w.ballot(fb & 64u);
-        grown2 = popc64(mg0) + popc64(mg1); nact = popc64(ma);
-        pos_g0 = nr + grown1 + w.rank(mg0) + w.rank(mg1); rank_a = w.rank(ma);
-    }
     const uint32_t nf = nr + grown1 + grown2 + nact + nfac;
     if (nf > FAST_FIN_MAX) return LEAN_NO(14);
     w.tick(23);
-    LEAN_STOP(7, pos_k0 ^ rank_f ^ nf ^ coverage ^ k_val[0] ^ k_val[1] ^ k_fl[0] ^ k_len[1] ^ fb)
 
-    bool face = false, outfit = false, safe = false, foot = false;
-    uint32_t bytes = 0, unknown = 0, safe_key = 0xFFFFFFFFu;
-    auto emit = [&](bool first, uint32_t val, uint32_t fl, uint32_t ln, uint32_t at) {
-        if (first) {
-            const uint32_t bk = fl_bucket(fl), eid = val & LEAN_ID_MASK;
-            face |= bk == B_FACE;                                  // MissingCoreBuckets, Program.cs:1097-1101
-            outfit |= bk == B_OUTFIT;
-            if (fl & FL_SAFE) { safe = true; const uint32_t key = (at << 8) | ((fl >> FL_SAFE_IDX_SHIFT) & 31u); safe_key = key < safe_key ? key : safe_key; }
-            foot |= eid == t.footjob_n;
-            bytes += ln;
-            unknown += (fl & FL_KNOWN) ? 0u : 1u;
-            fin32[at] = eid;
-        }
-    };
-    emit((fb & 1u) != 0, p_val, p_fl, p_len, lane);
-    emit((fb & 2u) != 0, k_val[0], k_fl[0], k_len[0], pos_k0);
-    emit((fb & 4u) != 0, k_val[1], k_fl[1], k_len[1], pos_k0 + ((fb >> 1) & 1u));
+    LeanAcc acc = {0, 0, 0xFFFFFFFFu, 0};
+    lean_emit(acc, t, fin32, (fb & 1u) != 0, p_val, p_fl, p_len, lane);
+    lean_emit(acc, t, fin32, (fb & 2u) != 0, k_val[0], k_fl[0], k_len[0], pos_k0);
+    lean_emit(acc, t, fin32, (fb & 4u) != 0, k_val[1], k_fl[1], k_len[1], pos_k0 + ((fb >> 1) & 1u));
+    lean_emit(acc, t, fin32, (fb & 8u) != 0, f_val, f_fl, f_len, nr + grown1 + grown2 + nact + rank_f);
     if (wide) {
-        if (any_deep) {
-            const LeanDeep g0 = L.deep[0][lane], g1 = L.deep[1][lane];
-            emit((fb & 16u) != 0, g0.val, g0.flags, g0.len, pos_g0);
-            emit((fb & 32u) != 0, g1.val, g1.flags, g1.len, pos_g0 + ((fb >> 4) & 1u));
-        }
-        emit((fb & 64u) != 0, a_val, a_fl, a_len, nr + grown1 + grown2 + rank_a);
+        const LeanAcc wa = lean_emit_wide(w, t, L, fin32, fb, nr + grown1, nr + grown1 + grown2, any_deep, n_act);
+        acc.bytes += wa.bytes; acc.unknown += wa.unknown; acc.bits |= wa.bits; acc.safe_key = wa.safe_key < acc.safe_key ? wa.safe_key : acc.safe_key;
     }
-    emit((fb & 8u) != 0, f_val, f_fl, f_len, nr + grown1 + grown2 + nact + rank_f);
+    const bool face = (acc.bits & LA_FACE) != 0, outfit = (acc.bits & LA_OUTFIT) != 0, safe = (acc.bits & LA_SAFE) != 0, foot = (acc.bits & LA_FOOT) != 0;
+    uint32_t bytes = acc.bytes, unknown = acc.unknown;
+    const uint32_t safe_key = acc.safe_key;
     uint32_t flags = 0;
     if (!(w.ballot(face) && w.ballot(outfit))) flags |= TP_F_LOW;
     int safe_hit = -1;
@@ -616,6 +694,18 @@ TP_HD bool lean_file(W& w, const DevTables& t, LeanLds& L, const LeanShared& S, 
     out.caption_len = bytes + 2 * (nf - 1) + t.newline_len;
     w.tick(24);
     return out.caption_len <= FAST_CAPTION_MAX;
+}
+
+// Both halves in a row (the host-side logic test; the GPU runs them as two kernels with the candidates' ids in between).
+template <class W, class TT>
+TP_HD bool lean_file(W& w, const TT& t, LeanFrontLds& LF, LeanLds& L, const LeanShared& S, const uint32_t* rc, const uint8_t* text, uint32_t len, const uint32_t (&x)[4],
+                     uint32_t* row, FastOut& out, uint32_t* fin32, uint32_t* fired, uint16_t* facet_choice) {
+    uint32_t n_cand = 0;
+    if (!lean_front(w, t, LF, S, text, len, x, row, n_cand)) return false;
+    w.sync();
+    const uint32_t id = w.lane() < n_cand ? row[w.lane()] : NO_ID;
+    w.sync();
+    return lean_back(w, t, L, S, rc, id, n_cand, out, fin32, fired, facet_choice);
 }
 
 }  // namespace tp

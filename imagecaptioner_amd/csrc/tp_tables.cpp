@@ -1012,6 +1012,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         }
     }
     for (uint32_t i = 0; i < N; ++i) if (out.flags[out.next[i]] & FL_BLANK) out.flags[i] |= FL_NEXT_BLANK;
+    for (uint32_t i = 0; i < N; ++i) if (out.next[i] == i && !(out.flags[i] & FL_BLANK)) out.flags[i] |= FL_FIX;
     // step lists: one ExpandImpliedTags visit of a string appends NormalizeTag(it), then that string's implied tags
     out.step_off.assign(N + 1, 0);
     out.step_ids.clear();
@@ -1130,6 +1131,67 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         const std::string& str = out.strings[id];
         for (size_t b = 0; b < str.size() && b < 32; ++b) sl.key[b >> 2] |= (uint32_t)(unsigned char)str[b] << (8 * (b & 3));
         sl.rec = out.rec[sl.val];
+    }
+    // ---- the lean stage's lookup table: two-choice placement (cuckoo insertion), at most 40 % full ----
+    out.attr2.assign(2 * (size_t)N, 0);
+    for (uint32_t i = 0; i < N; ++i) { out.attr2[2 * i] = out.flags[i]; out.attr2[2 * i + 1] = out.str_off[i + 1] - out.str_off[i]; }
+    out.crec.assign(8 * (size_t)N, 0);
+    for (uint32_t i = 0; i < N; ++i) {
+        const Rec& rv = out.rec[i];
+        uint32_t* cr = &out.crec[8 * (size_t)i];
+        cr[0] = rv.flags; cr[1] = rv.len; cr[2] = rv.lit; cr[3] = std::min<uint32_t>(rv.step_cnt, 3); cr[4] = rv.step0; cr[5] = rv.step1; cr[6] = rv.s0_info; cr[7] = rv.s1_info;
+    }
+    out.lslots.clear();
+    sc.lslot_mask = 0;
+    if (N <= LEAN_HEAD_ID_MASK) {
+        std::vector<uint32_t> keys;
+        for (uint32_t i = 0; i < N; ++i) {
+            const uint32_t ln = out.str_off[i + 1] - out.str_off[i];
+            if (out.basic_fixed[i] && ln >= 1 && ln <= LEAN_KEY_MAX) keys.push_back(i);
+        }
+        auto key_words = [&](uint32_t id, uint32_t kw[8]) {
+            const std::string& str = out.strings[id];
+            for (int k = 0; k < 8; ++k) kw[k] = 0;
+            for (size_t b = 0; b < str.size(); ++b) kw[b >> 2] |= (uint32_t)(unsigned char)str[b] << (8 * (b & 3));
+        };
+        uint32_t lsl = 16;
+        while ((uint64_t)lsl * 2 < (uint64_t)keys.size() * 5 + 16) lsl <<= 1;
+        for (int attempt = 0; attempt < 3 && out.lslots.empty(); ++attempt, lsl <<= 1) {
+            std::vector<uint32_t> owner(lsl, NO_ID);               // slot -> string id
+            bool ok = true;
+            for (uint32_t id0 : keys) {
+                uint32_t id = id0, avoid = NO_ID;
+                bool placed = false;
+                for (int kick = 0; kick < 2000 && !placed; ++kick) {
+                    uint32_t kw[8], s1, s2;
+                    key_words(id, kw);
+                    lean_slots(kw, (uint32_t)out.strings[id].size(), lsl - 1, s1, s2);
+                    if (owner[s1] == NO_ID) { owner[s1] = id; placed = true; }
+                    else if (owner[s2] == NO_ID) { owner[s2] = id; placed = true; }
+                    else {                                          // evict: the slot it was not just thrown out of
+                        const uint32_t victim_slot = (s1 == avoid) ? s2 : s1;
+                        std::swap(id, owner[victim_slot]);
+                        avoid = victim_slot;
+                    }
+                }
+                if (!placed) { ok = false; break; }
+            }
+            if (!ok) continue;
+            out.lslots.assign(lsl, LeanSlot{});
+            for (uint32_t sidx = 0; sidx < lsl; ++sidx) {
+                const uint32_t id = owner[sidx];
+                if (id == NO_ID) continue;
+                LeanSlot& ls = out.lslots[sidx];
+                key_words(id, ls.key);
+                const uint32_t val = out.alias1[id];
+                const Rec& rv = out.rec[val];
+                ls.head = val | ((uint32_t)out.strings[id].size() << 20) | (std::min<uint32_t>(rv.step_cnt, 3) << 26) | ((out.next[val] != val ? 1u : 0u) << 28);
+                ls.flags = rv.flags; ls.len = rv.len; ls.lit = rv.lit;
+                ls.step0 = rv.step0; ls.step1 = rv.step1; ls.s0_info = rv.s0_info; ls.s1_info = rv.s1_info;
+            }
+            sc.lslot_mask = lsl - 1;
+        }
+        if (std::getenv("TAGPIPE_DEBUG_TABLES")) std::fprintf(stderr, "tagpipe tables: lean slots %zu keys in %zu slots\n", keys.size(), out.lslots.size());
     }
     // rule cache
     bool rc_ok = true;
@@ -1271,6 +1333,9 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.str_words = ht.str_words.data();
     t.rc = ht.rule_cache.data();
     t.slots = ht.slots.data();
+    t.lslots = ht.lslots.empty() ? nullptr : ht.lslots.data();
+    t.attr2 = ht.attr2.data();
+    t.crec = ht.crec.data();
     t.step_off = ht.step_off.data();
     t.step_ids = ht.step_ids.data();
     t.reach_off = ht.reach_off.data();

@@ -214,13 +214,18 @@ static int run_lines_staged(void* h, const uint8_t* arena_in, const uint64_t* of
         uint32_t* fired_f = details ? o->fired.data() + f * t.fired_words : nullptr;
         bool lean_done = false;
         if (lean && lean_tables_ok(t) && len <= LEAN_LINE_MAX) {
+            static LeanFrontLds flds;
             static LeanLds llds;
             static LeanShared lshared;
+            std::memset((void*)&flds, 0xCD, sizeof flds);
             std::memset((void*)&llds, 0xCD, sizeof llds);
             lean_shared_init(t, lshared, 0, 1);
+            std::vector<uint32_t> row(64, 0xDEADBEEF);
             sh.run([&](int lane) {
                 emu::Wave w{&sh, (uint32_t)lane};
-                done[lane] = lean_file(w, t, llds, lshared, t.rc, text, len, outs[lane], fin32.data(), fired_f, t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
+                uint32_t piece[4];
+                lean_fetch(w, text, len, piece);
+                done[lane] = lean_file(w, t, flds, llds, lshared, t.rc, text, len, piece, row.data(), outs[lane], fin32.data(), fired_f, t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
             });
             for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the lean verdict"; }
             lean_done = done[0];

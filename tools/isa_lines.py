@@ -8,6 +8,8 @@ import re
 import sys
 
 path, sym = sys.argv[1], sys.argv[2]
+import os
+FILE = os.environ.get("ISA_FILE", "tp_fast.h")
 ranges = [tuple(int(x) for x in r.split("-")) for r in sys.argv[3].split(",")]
 bucket = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 inside = False
@@ -27,7 +29,7 @@ for ln in open(path):
         cur = None
         for f, l in chain:
             l = int(l)
-            if f.endswith("tp_fast.h") and any(a <= l <= b for a, b in ranges):
+            if f.endswith(FILE) and any(a <= l <= b for a, b in ranges):
                 cur = l
                 break
         if cur is None:
