@@ -2,10 +2,14 @@
 """Benchmark of the batch tag pipeline on MI355X.
 
 One "step" is one pass of the whole hot path (tp_run_lines_device: workspace sizing, the per-file pipeline
-kernel, caption-offset scan, caption/histogram emit) over one resident shard of synthetic tag files, plus —
+kernels, caption-offset scan, caption/histogram emit) over one resident shard of synthetic tag files, plus —
 on more than one GPU — the RCCL all-reduce of the tag histogram and counters.  Inputs are in HBM before
 the timed region starts.  Weak scaling: every rank owns `--files` files (default 1,000,000: BASELINE
 config 2, "1M tag files, ~40 tags/file, 20k-entry lexicon, single MI355X").
+
+`--gpus N` with N > 1, started as a plain `python bench.py`, starts N child processes of this same script (one
+per GPU, before this process has imported torch or made any GPU call) and waits for them; started under
+torch.distributed.run (WORLD_SIZE already in the environment) the process is one of the ranks itself.
 
 Prints ONE JSON line on rank 0.
 """
@@ -36,7 +40,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=300_000, help="files of the same corpus timed on the host cores (rank 0, 1 GPU only); 0 = skip")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    ap.add_argument("--cpu-single-sample", type=int, default=20_000, help="files timed on ONE host thread; 0 = skip")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: be the launcher.  Nothing in this process has touched the GPU.
+        from imagecaptioner_amd.dist import spawn_ranks
+        raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -44,8 +54,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the tag pipeline has no CPU path")
+        raise SystemExit("bench.py rank %d of %d needs a GPU: the tag pipeline has no CPU path" % (rank, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -93,7 +105,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sel_ms, gen_ms, emit_ms, tot_ms, gen_files = [], [], [], [], 0
+    sel_ms, gen_ms, emit_ms, tot_ms, front_ms, back_ms, gen_files = [], [], [], [], [], [], 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -103,6 +115,7 @@ def main():
         cap_bytes = step()
         tm = pipe.last_timing()        # HIP events recorded by the library on the stream its kernels run on
         sel_ms.append(tm["select_ms"]); gen_ms.append(tm["general_ms"]); emit_ms.append(tm["emit_ms"]); tot_ms.append(tm["total_ms"])
+        front_ms.append(tm["lean_front_ms"]); back_ms.append(tm["lean_back_ms"])
         gen_files = tm["general_files"]
     torch.cuda.synchronize()
     if world > 1:
@@ -138,17 +151,20 @@ def main():
     value = files_total * args.steps / elapsed
     # algorithmic bytes per file: input line + input offset + caption line + caption offset + verdict record
     alg_bytes = in_bytes + 8 * n + int(cap_bytes) + 8 * n + 16 * n
-    # the dominant kernel: the wave-per-file pipeline kernel, or the general thread-per-file one when it took longer
-    fast_avg, gen_avg = float(np.mean(sel_ms)), float(np.mean(gen_ms))
-    dominant = "k_fast" if fast_avg >= gen_avg else "k_pipeline"
-    sel_avg = max(fast_avg, gen_avg)
-    achieved = alg_bytes / (sel_avg * 1e-3) / 1e9
+    # Roofline of the step: the files' algorithmic bytes over the time from the first kernel's start to the last kernel's
+    # end (every kernel of the step, HIP events on the stream the library launches on).  The longest kernel is named beside it.
+    mean = lambda v: float(np.mean(v))
+    kernel_ms = {"k_lean_a": mean(front_ms), "k_lean_b": mean(back_ms), "later_wave_stages": mean(sel_ms) - mean(front_ms) - mean(back_ms),
+                 "k_pipeline": mean(gen_ms), "k_emit+k_hist": mean(emit_ms), "first_to_last_kernel": mean(tot_ms)}
+    dominant = max((k for k in kernel_ms if k != "first_to_last_kernel"), key=lambda k: kernel_ms[k])
+    step_ms = kernel_ms["first_to_last_kernel"]
+    achieved = alg_bytes / (step_ms * 1e-3) / 1e9
     traffic = None
     try:
         with open(args.traffic_json) as f:
             tj = json.load(f)
         if tj.get("workload") == "%s:%d" % (args.config, n):
-            traffic = tj.get("hbm_bytes_per_launch")
+            traffic = tj.get("hbm_bytes_per_step")
     except Exception:
         pass
 
@@ -167,12 +183,15 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: %d tag files per GPU, %.0f input bytes/file" % (args.config, n, in_bytes / n),
                    "files_per_gpu": n, "input_bytes_per_file": in_bytes / n, "caption_bytes_per_file": cap_bytes / n,
-                   "kernel_ms": {"k_fast": fast_avg, "k_pipeline": gen_avg, "k_emit": float(np.mean(emit_ms)), "first_to_last_kernel": float(np.mean(tot_ms))},
+                   "kernel_ms": kernel_ms,
                    "files_in_general_kernel": int(gen_files),
                    "parallelism": "files sharded by rank; histogram all-reduce (RCCL)" if world > 1 else "single GPU",
                    "corpus_gen_s": gen_s},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sel_avg},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": step_ms,
+                     "definition": "algorithmic bytes of one step (input lines, both offset arrays, captions, verdicts) / first-to-last kernel time of "
+                                   "the step, all kernels; traffic = HBM bytes of all kernels of one step from the FETCH_SIZE/WRITE_SIZE passes",
+                     "longest_kernel": dominant, "longest_kernel_ms": kernel_ms[dominant]},
     }
 
     if world == 1 and args.cpu_sample > 0:
@@ -183,6 +202,13 @@ def main():
         dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": m / dt, "unit": "files/s", "cores": threads, "kind": "port",
                                "sample": "first %d files of the same corpus, C++ restatement of Program.cs (not the .NET binary), %d threads, %.1f s" % (m, threads, dt)}
+        m1 = min(n, args.cpu_single_sample)
+        if m1 > 0:
+            t1 = time.perf_counter()
+            oracle.run_lines(corpus.arena, corpus.offsets[:m1 + 1], threads=1)
+            dt1 = time.perf_counter() - t1
+            out["cpu_baseline"]["single_thread"] = {"value": m1 / dt1, "unit": "files/s", "cores": 1,
+                                                    "sample": "first %d files of the same corpus, same restatement, 1 thread, %.1f s" % (m1, dt1)}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

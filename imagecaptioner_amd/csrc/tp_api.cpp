@@ -124,6 +124,8 @@ struct RunState {
     int audit_chunk = 0;
     size_t ev = 2;               // next free event
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fast_ev, pipe_ev, emit_ev;
+    struct Lean { hipEvent_t begin, mid, end; };
+    std::vector<Lean> lean_ev;     // lean stage: front kernel between begin and mid, back kernel between mid and end
 };
 
 int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
@@ -169,7 +171,10 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
             uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
             HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
             fa.stage = 0; fa.slow_list = c->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
-            HIP_OK(launch_fast(c->dt, fa, s));
+            hipEvent_t pm = c->event(st.ev++), pe = c->event(st.ev++);
+            HIP_OK(launch_fast(c->dt, fa, s, pm));
+            HIP_OK(hipEventRecord(pe, s));
+            st.lean_ev.push_back({p0, pm, pe});
             fa.item_list = c->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
         }
         fa.stage = 1; fa.slow_list = c->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
@@ -318,6 +323,10 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_byt
     HIP_OK(hipEventElapsedTime(&ms, e_begin, e_end));
     c->timing.total_ms = ms;
     for (auto& p : st.fast_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.select_ms += ms; }
+    for (auto& p : st.lean_ev) {
+        HIP_OK(hipEventElapsedTime(&ms, p.begin, p.mid)); c->timing.lean_front_ms += ms;
+        HIP_OK(hipEventElapsedTime(&ms, p.mid, p.end)); c->timing.lean_back_ms += ms;
+    }
     for (auto& p : st.pipe_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.general_ms += ms; }
     for (auto& p : st.emit_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.emit_ms += ms; }
     c->timing.other_ms = c->timing.total_ms - c->timing.select_ms - c->timing.general_ms - c->timing.emit_ms;

@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
 uint32_t fast_fin_stride() { return FAST_FIN_MAX; }
 bool lean_ok(const DevTables& t) { return lean_tables_ok(t); }
 
-hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
+hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
     uint64_t want = (n + FAST_WAVES_PER_BLOCK - 1) / FAST_WAVES_PER_BLOCK;
@@ -846,6 +846,7 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s) {
         static const unsigned lean_blocks_b = [] { const char* e = getenv("TAGPIPE_LEAN_B_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
         want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK;
         hipLaunchKernelGGL(k_lean_a, dim3((unsigned)(want < lean_blocks_a ? want : lean_blocks_a)), dim3(64 * LEAN_WAVES_PER_BLOCK), 0, s, a);
+        if (between) { hipError_t e = hipEventRecord(between, s); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(k_lean_b, dim3((unsigned)(want < lean_blocks_b ? want : lean_blocks_b)), dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
     } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);

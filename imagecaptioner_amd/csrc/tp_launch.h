@@ -104,7 +104,8 @@ struct EmitArgs {
     tp_counters* counters;        // accumulated; may be null
 };
 
-hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s);
+// `between`: when not null and the stage launches two kernels (stage 0), recorded on the stream after the first of them.
+hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between = nullptr);
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,
                              uint64_t file0, uint64_t n_items, uint32_t fpw, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s);
 hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s);

@@ -30,3 +30,64 @@ def allreduce_sum_(tensors, group=None):
     for t in tensors:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return tensors
+
+
+def free_port():
+    """A TCP port on 127.0.0.1 that was free a moment ago (for MASTER_PORT)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(world, argv, env=None, timeout=None, grace=5.0):
+    """Start `world` fresh child processes running `argv`, one per GPU, and wait for all of them.
+
+    Every child gets RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1 and one common MASTER_PORT in its
+    environment, the variables torch.distributed's env:// rendezvous reads.  The caller must not have touched the
+    GPU: the children are started as ordinary child processes (never by replacing this one), and this process
+    only waits.  Rank 0 inherits stdout, so the one line it prints is this command's output; the other ranks'
+    stdout goes to stderr.  When a rank fails the rest get `grace` seconds to end by themselves (they may be about to
+    report the same trouble) and are then terminated (the very processes started here, by pid).
+    Returns the first non-zero exit status, or 0.
+    """
+    import os
+    import subprocess
+    import sys
+    import time
+    if world < 1:
+        raise ValueError("world must be at least 1")
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base.get("MASTER_PORT") or free_port()))
+    procs = []
+    for r in range(world):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    status = 0
+    failed_at = None
+    live = set(range(world))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and status == 0:
+                status = rc
+                failed_at = time.monotonic()
+        if live and ((status != 0 and time.monotonic() - failed_at > grace) or (deadline is not None and time.monotonic() > deadline)):
+            if status == 0:
+                status = 124
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            break
+        if live:
+            time.sleep(0.05)
+    return status

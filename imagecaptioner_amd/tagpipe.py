@@ -214,7 +214,7 @@ class TagPipe:
         t = tp_timing()
         self._check(self._L.tp_get_last_timing(self._h, C.byref(t)))
         return {"total_ms": t.total_ms, "select_ms": t.select_ms, "general_ms": t.general_ms, "emit_ms": t.emit_ms, "other_ms": t.other_ms,
-                "general_files": int(t.general_files)}
+                "general_files": int(t.general_files), "lean_front_ms": t.lean_front_ms, "lean_back_ms": t.lean_back_ms}
 
     # ---- host-buffer runs -----------------------------------------------------------------------
     def audit_header(self):

@@ -228,7 +228,12 @@ void tp_release(tp_ctx* ctx, tp_result* res);
  * GPUs).  fired / facet_choice may be NULL.  Work is enqueued on `stream`
  * (a hipStream_t, NULL = default stream); the call synchronises the stream
  * once to learn the caption size.  If caption_capacity is too small the call
- * returns TP_E_CAPACITY and *caption_bytes holds the required size.
+ * returns TP_E_CAPACITY and *caption_bytes holds the required size.  Files are
+ * worked through in ranges of up to 2^24: by the time a later range finds the
+ * caption buffer full, earlier ranges have written their captions and added
+ * their tags to histogram and counters.  After TP_E_CAPACITY the outputs are
+ * therefore unspecified, and a caller that retries with a larger buffer must
+ * set histogram and counters back to what they held before the failed call.
  */
 typedef struct tp_device_io {
     const uint8_t*  arena;            /* in; 16 bytes past offsets[n_files] must be readable (the kernels fetch texts in aligned pieces) */
@@ -267,11 +272,13 @@ int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* ou
 /* Timing of the most recent run on this context (milliseconds, from HIP events on the run's stream). */
 typedef struct tp_timing {
     float total_ms;     /* first kernel start to last kernel end */
-    float select_ms;    /* wave-per-file pipeline kernel (k_fast) */
+    float select_ms;    /* all wave-per-file kernels: the lean stage (k_lean_a, k_lean_b) and the stages behind it (k_fast, k_fast2, k_long) */
     float general_ms;   /* thread-per-file pipeline kernel (k_pipeline) over the files k_fast declined */
     float emit_ms;      /* caption bytes, histogram, counters (k_emit) */
     float other_ms;     /* sizing, scans, host round trips between kernels */
     uint64_t general_files; /* how many files took the thread-per-file kernel */
+    float lean_front_ms; /* part of select_ms: k_lean_a (scan of the line, table lookup of every tag, Distinct) */
+    float lean_back_ms;  /* part of select_ms: k_lean_b (selection, implied tags, rules, facets, the final tag ids) */
 } tp_timing;
 /*
  * firedRules of every file as AppendAudit joins them (Program.cs:334, 966:

@@ -60,3 +60,60 @@ def test_two_rank_shards_reproduce_single_process(tmp_path):
     vocab = sorted(whole.histogram)
     assert list(np.load(tmp_path / "hist.npy")) == [whole.histogram[t] for t in vocab]
     assert list(np.load(tmp_path / "ctr.npy")) == [whole.counters[k] for k in sorted(whole.counters)]
+
+
+# ---- the launcher behind `bench.py --gpus N`: fresh child processes, one per rank, env:// rendezvous ----
+
+_LAUNCH = """
+import sys
+sys.path.insert(0, %r)
+from imagecaptioner_amd.dist import spawn_ranks
+raise SystemExit(spawn_ranks(2, [sys.executable, %r] + sys.argv[1:], timeout=240))
+"""
+
+
+def _run_launcher(tmp_path, n_files, *extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "dist_rank_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    return subprocess.run([sys.executable, "-c", _LAUNCH % (root, worker), str(n_files), str(tmp_path)] + [str(x) for x in extra],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_launcher_two_ranks_join_and_sum(tmp_path):
+    import json
+    n_files = 257
+    p = _run_launcher(tmp_path, n_files)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # rank 0 alone prints the line
+    got = json.loads(lines[0])
+    assert got["world"] == 2 and got["joined"] == [1, 2]          # both ranks joined the one group and were summed
+    c = make_corpus("c1", n_files, seed=11)
+    whole = Oracle(Config(**c.config_kwargs)).run_lines(c.arena, c.offsets)
+    assert got["hist"] == [whole.histogram[t] for t in sorted(whole.histogram)]
+    assert got["ctr"] == [whole.counters[k] for k in sorted(whole.counters)]
+    caps = np.concatenate([np.load(tmp_path / ("cap%d.npy" % r)) for r in range(2)])
+    assert np.array_equal(caps, whole.captions)
+
+
+def test_launcher_reports_a_failing_rank(tmp_path):
+    p = _run_launcher(tmp_path, 16, 1)           # rank 1 exits with status 7 after the collective
+    assert p.returncode == 7
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="on a GPU box this would start a real two-GPU run")
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`bench.py --gpus 2` outside a launcher starts two ranks of itself; without a GPU each of them stops with the
+    message that names its rank, and the launcher hands the failure on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--files", "64", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "rank 0 of 2 needs a GPU" in p.stderr and "rank 1 of 2 needs a GPU" in p.stderr
+    assert p.stdout.strip() == ""

@@ -44,9 +44,23 @@ def main():
         if not k.startswith("k_"):
             continue
         kernels[k] = {c: {"avg": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()}
-    dom = "k_fast" if "k_fast" in kernels else sorted(kernels)[0]
+    # HBM bytes of one step: every kernel's (2 x FETCH + WRITE) x launches, over the number of steps (k_emit runs once a step)
+    steps = kernels.get("k_emit", {}).get("FETCH_SIZE", {}).get("launches", 0)
+    if steps:
+        total = 0.0
+        per_kernel = {}
+        for k, cs in kernels.items():
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                b = (2.0 * cs["FETCH_SIZE"]["avg"] * cs["FETCH_SIZE"]["launches"] + cs["WRITE_SIZE"]["avg"] * cs["WRITE_SIZE"]["launches"]) * 1024.0 / steps
+                per_kernel[k] = b
+                total += b
+    dom = max(per_kernel, key=per_kernel.get) if steps and per_kernel else sorted(kernels)[0]
     kd = kernels[dom]
     res = {"workload": workload, "kernel": dom, "kernels": kernels}
+    if steps and per_kernel:
+        res["hbm_bytes_per_step"] = total
+        res["hbm_bytes_per_step_by_kernel"] = per_kernel
+        res["steps"] = steps
     if "FETCH_SIZE" in kd and "WRITE_SIZE" in kd:
         fetch_raw = kd["FETCH_SIZE"]["avg"] * 1024.0
         write = kd["WRITE_SIZE"]["avg"] * 1024.0
