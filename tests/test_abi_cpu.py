@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_abi.tp_verdict) == 16
     assert C.sizeof(_abi.tp_counters) == 64
     assert C.sizeof(_abi.tp_source) == 24
-    assert C.sizeof(_abi.tp_timing) == 32
+    assert C.sizeof(_abi.tp_timing) == 40
     assert C.sizeof(_abi.tp_device_io) == 12 * 8
     # compile a probe with the real header and compare sizes / a few offsets
     import subprocess, tempfile, textwrap
