@@ -24,12 +24,17 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
 struct HipFail { hipError_t e; const char* what; };
 #define HIP_OK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) throw HipFail{e__, #expr}; } while (0)
 
-// Grow-only device buffer.
+struct ScratchFull { size_t bytes, cap; };
+
+// Grow-only device buffer.  A bound one is a piece of memory that someone else owns: it cannot grow and is never freed.
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool bound = false;
+    void bind(void* q, size_t bytes) { p = q; cap = bytes; bound = true; }
     void need(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
         if (bytes <= cap) return;
+        if (bound) throw ScratchFull{bytes, cap};
         size_t want = std::max(bytes, cap + cap / 2);
         want = (want + 255) & ~(size_t)255;
         void* q = nullptr;
@@ -42,7 +47,7 @@ struct DevBuf {
         p = q;
         cap = want;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !bound) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
 
@@ -69,13 +74,25 @@ struct HostResult {
 
 }  // namespace
 
+// What one run works in besides the caller's inputs and outputs.
+struct WorkBufs {
+    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, scalars, workspace;
+    void release() {
+        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &scalars, &workspace})
+            b->release();
+    }
+};
+
 struct tp_ctx {
     int device = 0;
     HostTables ht;
     DevTables dt;
     DevBuf dt_dev;                   // dt again, in device memory (the lean stage reads it from there)
     std::vector<void*> table_mem;
-    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, scalars, workspace;
+    WorkBufs own;                    // grown with hipMalloc as runs need them
+    WorkBufs fixed;                  // pieces of this device's static scratch array: tp_run_lines_device_noalloc works in these
+    WorkBufs* w = &own;
+    uint64_t* host_scalars = nullptr;   // pinned host words the runs read device scalars back into
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
     DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets, out_review_bits;
@@ -90,7 +107,9 @@ struct tp_ctx {
     ~tp_ctx() {
         (void)hipSetDevice(device);
         for (void* p : table_mem) (void)hipFree(p);
-        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &dt_dev, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &scalars, &workspace, &in_arena, &in_offsets, &in_tag_begin,
+        own.release();
+        if (host_scalars) (void)hipHostFree(host_scalars);
+        for (DevBuf* b : {&dt_dev, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
                           &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits})
             b->release();
@@ -123,6 +142,7 @@ struct RunState {
     uint64_t audit_total = 0;    // bytes of audit text so far
     int audit_chunk = 0;
     size_t ev = 2;               // next free event
+    bool timed = true;           // false: no events are created or recorded (the run must not allocate)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fast_ev, pipe_ev, emit_ev;
     struct Lean { hipEvent_t begin, mid, end; };
     std::vector<Lean> lean_ev;     // lean stage: front kernel between begin and mid, back kernel between mid and end
@@ -131,35 +151,37 @@ struct RunState {
 int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     hipStream_t s = io.stream;
     const uint64_t n = f1 - f0;
-    uint64_t* d_total = c->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
+    auto next_event = [&]() -> hipEvent_t { return st.timed ? c->event(st.ev++) : nullptr; };
+    auto record = [&](hipEvent_t e) { if (e) HIP_OK(hipEventRecord(e, s)); };
+    uint64_t* d_total = c->w->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
     uint32_t* d_status = (uint32_t*)(d_total + 2);
     uint32_t* d_slow_count = d_status + 1;
     const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast && !io.audit;   // tagger replies: the wave kernel's scored front
     const bool use_fast = use_scored || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast && !io.audit);
 
-    c->cap_len.need(n * 4); c->n_final.need(n * 4); c->slot_of.need(n * 4);
-    uint32_t* cap_len = c->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
-    uint32_t* n_final = c->n_final.as<uint32_t>() - f0;
-    uint32_t* slot_of = c->slot_of.as<uint32_t>() - f0;
+    c->w->cap_len.need(n * 4); c->w->n_final.need(n * 4); c->w->slot_of.need(n * 4);
+    uint32_t* cap_len = c->w->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
+    uint32_t* n_final = c->w->n_final.as<uint32_t>() - f0;
+    uint32_t* slot_of = c->w->slot_of.as<uint32_t>() - f0;
     uint32_t n_slow = (uint32_t)n;
     const uint32_t* item_list = nullptr;
     if (use_fast) {
-        c->fin32.need(n * fast_fin_stride() * 4);
-        c->slow_list.need(n * 4);
-        c->slow_list1.need(n * 4);
-        c->slow_list2.need(n * 4);
+        c->w->fin32.need(n * fast_fin_stride() * 4);
+        c->w->slow_list.need(n * 4);
+        c->w->slow_list1.need(n * 4);
+        c->w->slow_list2.need(n * 4);
         uint32_t* d_slow_count1 = d_slow_count + 1;
         uint32_t* d_slow_count2 = d_slow_count + 2;
         HIP_OK(hipMemsetAsync(d_slow_count, 0, 12, s));
         FastArgs fa{};
         fa.arena = io.arena; fa.offsets = io.offsets; fa.file0 = f0; fa.file_end = f1;
-        fa.verdicts = io.verdicts; fa.n_final = n_final; fa.cap_len = cap_len; fa.fin32 = c->fin32.as<uint32_t>(); fa.slot_of = slot_of;
+        fa.verdicts = io.verdicts; fa.n_final = n_final; fa.cap_len = cap_len; fa.fin32 = c->w->fin32.as<uint32_t>(); fa.slot_of = slot_of;
         fa.fired = io.fired; fa.facet_choice = io.facet_choice; fa.triage = io.mode == 2 ? 1 : 0;
-        hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
-        HIP_OK(hipEventRecord(p0, s));
+        hipEvent_t p0 = next_event(), p1 = next_event();
+        record(p0);
         if (use_scored) {
             fa.tag_begin = io.tag_begin; fa.scores = io.scores; fa.sources = io.sources; fa.secondary_begin = io.secondary_begin; fa.secondary_cap = io.secondary_cap;
-            fa.stage = 4; fa.slow_list = c->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.item_list = nullptr; fa.item_count = nullptr;
+            fa.stage = 4; fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.item_list = nullptr; fa.item_count = nullptr;
             HIP_OK(launch_fast(c->dt, fa, s));
         } else {
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
@@ -167,33 +189,34 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         fa.item_list = nullptr; fa.item_count = nullptr;
         if (c->use_lean && io.mode == 0) {
             // stage 0: the lean stage takes the common shape of a file; the stages below see what it declines
-            c->slow_list0.need(n * 4);
+            c->w->slow_list0.need(n * 4);
             uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
             HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
-            fa.stage = 0; fa.slow_list = c->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
-            hipEvent_t pm = c->event(st.ev++), pe = c->event(st.ev++);
+            fa.stage = 0; fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
+            hipEvent_t pm = next_event(), pe = next_event();
             HIP_OK(launch_fast(c->dt, fa, s, pm));
-            HIP_OK(hipEventRecord(pe, s));
-            st.lean_ev.push_back({p0, pm, pe});
-            fa.item_list = c->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+            record(pe);
+            if (st.timed) st.lean_ev.push_back({p0, pm, pe});
+            fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
         }
-        fa.stage = 1; fa.slow_list = c->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
+        fa.stage = 1; fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
         HIP_OK(launch_fast(c->dt, fa, s));
-        fa.stage = 2; fa.item_list = c->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
-        fa.slow_list = c->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
+        fa.stage = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
+        fa.slow_list = c->w->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
         HIP_OK(launch_fast(c->dt, fa, s));
-        fa.stage = 3; fa.item_list = c->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
-        fa.slow_list = c->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
+        fa.stage = 3; fa.item_list = c->w->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
+        fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
         HIP_OK(launch_fast(c->dt, fa, s));
         }
-        HIP_OK(hipEventRecord(p1, s));
-        st.fast_ev.emplace_back(p0, p1);
-        HIP_OK(hipMemcpyAsync(&n_slow, d_slow_count, 4, hipMemcpyDeviceToHost, s));
+        record(p1);
+        if (st.timed) st.fast_ev.emplace_back(p0, p1);
+        HIP_OK(hipMemcpyAsync(&c->host_scalars[0], d_slow_count, 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
-        item_list = c->slow_list.as<uint32_t>();
+        n_slow = (uint32_t)c->host_scalars[0];
+        item_list = c->w->slow_list.as<uint32_t>();
     }
     const bool want_ids = use_fast || (io.histogram != nullptr && io.mode == 0);   // rows of tag ids: the wave kernels' output, and what the histogram kernel counts
-    if (want_ids && !use_fast) c->fin32.need(n * fast_fin_stride() * 4);
+    if (want_ids && !use_fast) c->w->fin32.need(n * fast_fin_stride() * 4);
     c->last_slow += n_slow;
     if (n_slow) {
         // The general kernel runs one file per lane, and the lanes of a wavefront wait for one another at every branch where
@@ -206,14 +229,16 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         uint32_t status = 0;
         for (;;) {
             n_waves = ((uint64_t)n_slow + fpw - 1) / fpw;
-            c->wave_T.need(n_waves * 4); c->wave_LB.need(n_waves * 4); c->wave_bytes.need(n_waves * 8); c->wave_off.need((n_waves + 1) * 8);
-            c->tile_sums.need(scan_tiles_needed(std::max<uint64_t>(n, n_waves)) * 8);
-            HIP_OK(launch_wave_sizes(c->dt, io.arena, io.offsets, io.tag_begin, item_list, f0, n_slow, fpw, c->wave_T.as<uint32_t>(), c->wave_LB.as<uint32_t>(),
-                                     c->wave_bytes.as<uint64_t>(), d_status, s));
-            HIP_OK(launch_scan_u64(c->wave_bytes.as<uint64_t>(), n_waves, c->wave_off.as<uint64_t>(), c->tile_sums.as<uint64_t>(), nullptr, nullptr, s));
-            HIP_OK(hipMemcpyAsync(&ws_bytes, c->wave_off.as<uint64_t>() + n_waves, 8, hipMemcpyDeviceToHost, s));
-            HIP_OK(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, s));
+            c->w->wave_T.need(n_waves * 4); c->w->wave_LB.need(n_waves * 4); c->w->wave_bytes.need(n_waves * 8); c->w->wave_off.need((n_waves + 1) * 8);
+            c->w->tile_sums.need(scan_tiles_needed(std::max<uint64_t>(n, n_waves)) * 8);
+            HIP_OK(launch_wave_sizes(c->dt, io.arena, io.offsets, io.tag_begin, item_list, f0, n_slow, fpw, c->w->wave_T.as<uint32_t>(), c->w->wave_LB.as<uint32_t>(),
+                                     c->w->wave_bytes.as<uint64_t>(), d_status, s));
+            HIP_OK(launch_scan_u64(c->w->wave_bytes.as<uint64_t>(), n_waves, c->w->wave_off.as<uint64_t>(), c->w->tile_sums.as<uint64_t>(), nullptr, nullptr, s));
+            HIP_OK(hipMemcpyAsync(&c->host_scalars[1], c->w->wave_off.as<uint64_t>() + n_waves, 8, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(&c->host_scalars[2], d_status, 4, hipMemcpyDeviceToHost, s));
             HIP_OK(hipStreamSynchronize(s));
+            ws_bytes = c->host_scalars[1];
+            status = (uint32_t)c->host_scalars[2];
             if (status || fpw == 64 || ws_bytes <= spread_budget) break;
             fpw <<= 1;                                             // too much memory for so thin a spread
         }
@@ -225,32 +250,33 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
             if (rc != TP_OK && rc != TP_E_CAPACITY) return rc;
             return run_range(c, io, mid, f1, st);
         }
-        c->workspace.need(ws_bytes);
+        c->w->workspace.need(ws_bytes);
         PipelineArgs pa{};
         pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
         pa.secondary_begin = io.secondary_begin; pa.secondary_cap = io.secondary_cap;
         pa.item_list = item_list; pa.file0 = f0; pa.n_items = n_slow; pa.fpw = fpw;
-        pa.wave_T = c->wave_T.as<uint32_t>(); pa.wave_LB = c->wave_LB.as<uint32_t>(); pa.wave_off = c->wave_off.as<uint64_t>();
-        pa.workspace = c->workspace.as<uint8_t>();
+        pa.wave_T = c->w->wave_T.as<uint32_t>(); pa.wave_LB = c->w->wave_LB.as<uint32_t>(); pa.wave_off = c->w->wave_off.as<uint64_t>();
+        pa.workspace = c->w->workspace.as<uint8_t>();
         pa.verdicts = io.verdicts; pa.n_final = n_final; pa.cap_len = cap_len; pa.slot_of = slot_of;
         pa.fired = io.fired; pa.facet_choice = io.facet_choice; pa.mode = io.audit ? 3 : io.mode;
         if (io.audit) {
             c->audit_cnt.need(n * AUDIT_COLS * 4); c->audit_len.need(n * AUDIT_COLS * 4);
             pa.audit_cnt = c->audit_cnt.as<uint32_t>(); pa.audit_len = c->audit_len.as<uint32_t>(); pa.review_bits = io.review_bits + f0;
         }
-        hipEvent_t p0 = c->event(st.ev++), p1 = c->event(st.ev++);
-        HIP_OK(hipEventRecord(p0, s));
+        hipEvent_t p0 = next_event(), p1 = next_event();
+        record(p0);
         HIP_OK(launch_pipeline(c->dt, pa, s));
-        HIP_OK(hipEventRecord(p1, s));
-        st.pipe_ev.emplace_back(p0, p1);
+        record(p1);
+        if (st.timed) st.pipe_ev.emplace_back(p0, p1);
     } else {
-        c->tile_sums.need(scan_tiles_needed(n) * 8);
+        c->w->tile_sums.need(scan_tiles_needed(n) * 8);
     }
     // caption offsets of the range, continuing the running total
-    HIP_OK(launch_scan_u32(c->cap_len.as<uint32_t>(), n, io.caption_offsets + f0, c->tile_sums.as<uint64_t>(), d_total + (st.chunk & 1),
+    HIP_OK(launch_scan_u32(c->w->cap_len.as<uint32_t>(), n, io.caption_offsets + f0, c->w->tile_sums.as<uint64_t>(), d_total + (st.chunk & 1),
                            d_total + ((st.chunk + 1) & 1), s));
-    HIP_OK(hipMemcpyAsync(&st.total, d_total + ((st.chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(&c->host_scalars[3], d_total + ((st.chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    st.total = c->host_scalars[3];
     ++st.chunk;
     if (io.mode != 0) return TP_OK;
     if (io.grow_captions) {
@@ -262,42 +288,43 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     if (st.over_capacity) return TP_E_CAPACITY;
     EmitArgs ea{};
     ea.file0 = f0; ea.file_end = f1;
-    ea.wave_T = c->wave_T.as<uint32_t>(); ea.wave_LB = c->wave_LB.as<uint32_t>(); ea.wave_off = c->wave_off.as<uint64_t>(); ea.workspace = c->workspace.as<uint8_t>();
-    ea.fin32 = want_ids ? c->fin32.as<uint32_t>() : nullptr; ea.fast_ran = use_fast ? 1 : 0; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
+    ea.wave_T = c->w->wave_T.as<uint32_t>(); ea.wave_LB = c->w->wave_LB.as<uint32_t>(); ea.wave_off = c->w->wave_off.as<uint64_t>(); ea.workspace = c->w->workspace.as<uint8_t>();
+    ea.fin32 = want_ids ? c->w->fin32.as<uint32_t>() : nullptr; ea.fast_ran = use_fast ? 1 : 0; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
     ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
     ea.histogram = io.histogram; ea.counters = io.counters;
-    hipEvent_t q0 = c->event(st.ev++), q1 = c->event(st.ev++);
-    HIP_OK(hipEventRecord(q0, s));
+    hipEvent_t q0 = next_event(), q1 = next_event();
+    record(q0);
     HIP_OK(launch_emit(c->dt, ea, s));
-    HIP_OK(hipEventRecord(q1, s));
-    st.emit_ev.emplace_back(q0, q1);
+    record(q1);
+    if (st.timed) st.emit_ev.emplace_back(q0, q1);
     if (io.audit && n_slow) {
         // offsets of the range's audit columns, continuing the running total, then their text out of the workspaces
         uint64_t* d_atotal = d_total + 4;
-        c->tile_sums.need(scan_tiles_needed(n * AUDIT_COLS) * 8);
-        HIP_OK(launch_scan_u32(c->audit_len.as<uint32_t>(), n * AUDIT_COLS, io.audit_offsets + f0 * AUDIT_COLS, c->tile_sums.as<uint64_t>(),
+        c->w->tile_sums.need(scan_tiles_needed(n * AUDIT_COLS) * 8);
+        HIP_OK(launch_scan_u32(c->audit_len.as<uint32_t>(), n * AUDIT_COLS, io.audit_offsets + f0 * AUDIT_COLS, c->w->tile_sums.as<uint64_t>(),
                                d_atotal + (st.audit_chunk & 1), d_atotal + ((st.audit_chunk + 1) & 1), s));
-        HIP_OK(hipMemcpyAsync(&st.audit_total, d_atotal + ((st.audit_chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&c->host_scalars[4], d_atotal + ((st.audit_chunk + 1) & 1), 8, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        st.audit_total = c->host_scalars[4];
         ++st.audit_chunk;
         c->out_audit.need(std::max<uint64_t>(st.audit_total, 16), true, s);
         AuditArgs aa{};
         aa.file0 = f0; aa.n_items = n_slow; aa.item_list = item_list; aa.slot_of = slot_of;
-        aa.wave_T = c->wave_T.as<uint32_t>(); aa.wave_LB = c->wave_LB.as<uint32_t>(); aa.wave_off = c->wave_off.as<uint64_t>(); aa.workspace = c->workspace.as<uint8_t>();
+        aa.wave_T = c->w->wave_T.as<uint32_t>(); aa.wave_LB = c->w->wave_LB.as<uint32_t>(); aa.wave_off = c->w->wave_off.as<uint64_t>(); aa.workspace = c->w->workspace.as<uint8_t>();
         aa.audit_cnt = c->audit_cnt.as<uint32_t>(); aa.offsets = io.audit_offsets; aa.text = c->out_audit.as<uint8_t>();
         HIP_OK(launch_audit(c->dt, aa, s));
     }
     return TP_OK;
 }
 
-int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_bytes = nullptr) {
+int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_bytes = nullptr, bool timed = true) {
     HIP_OK(hipSetDevice(c->device));
     hipStream_t s = io.stream;
     const uint64_t n = io.n_files;
     c->timing = tp_timing{};
     c->last_slow = 0;
-    c->scalars.need(64);
-    HIP_OK(hipMemsetAsync(c->scalars.p, 0, 64, s));
+    c->w->scalars.need(64);
+    HIP_OK(hipMemsetAsync(c->w->scalars.p, 0, 64, s));
     if (n == 0) {
         if (io.audit) HIP_OK(hipMemsetAsync(io.audit_offsets, 0, 8, s));
         if (audit_bytes) *audit_bytes = 0;
@@ -307,8 +334,9 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_byt
         return TP_OK;
     }
     RunState st;
-    hipEvent_t e_begin = c->event(0), e_end = c->event(1);
-    HIP_OK(hipEventRecord(e_begin, s));
+    st.timed = timed;
+    hipEvent_t e_begin = timed ? c->event(0) : nullptr, e_end = timed ? c->event(1) : nullptr;
+    if (timed) HIP_OK(hipEventRecord(e_begin, s));
     int rc = TP_OK;
     const uint64_t range_max = (uint64_t)1 << 24;              // files per range: bounds the per-range index buffers
     for (uint64_t f0 = 0; f0 < n; f0 += range_max) {
@@ -316,11 +344,11 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_byt
         if (r != TP_OK) rc = r;
         if (r != TP_OK && r != TP_E_CAPACITY) break;
     }
-    HIP_OK(hipEventRecord(e_end, s));
+    if (timed) HIP_OK(hipEventRecord(e_end, s));
     HIP_OK(hipStreamSynchronize(s));
     if (rc != TP_OK && rc != TP_E_CAPACITY) return rc;
     float ms = 0;
-    HIP_OK(hipEventElapsedTime(&ms, e_begin, e_end));
+    if (timed) HIP_OK(hipEventElapsedTime(&ms, e_begin, e_end));
     c->timing.total_ms = ms;
     for (auto& p : st.fast_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.select_ms += ms; }
     for (auto& p : st.lean_ev) {
@@ -337,10 +365,36 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_byt
     return TP_OK;
 }
 
+// Cuts this device's static working memory into the pieces a run of at most TP_NOALLOC_MAX_FILES files works in;
+// what is left over is the general kernel's workspace.  The device of the context is current.
+void bind_fixed(tp_ctx* c) {
+    void* base = nullptr;
+    size_t bytes = 0;
+    HIP_OK(noalloc_scratch(c->device, &base, &bytes));
+    size_t o = 0;
+    auto take = [&](DevBuf& b, size_t sz) {
+        sz = (sz + 255) & ~(size_t)255;
+        if (o + sz > bytes) throw std::bad_alloc();
+        b.bind((uint8_t*)base + o, sz);
+        o += sz;
+    };
+    const size_t N = TP_NOALLOC_MAX_FILES;
+    WorkBufs& w = c->fixed;
+    take(w.scalars, 64);
+    for (DevBuf* b : {&w.cap_len, &w.n_final, &w.slot_of, &w.slow_list, &w.slow_list0, &w.slow_list1, &w.slow_list2, &w.wave_T, &w.wave_LB}) take(*b, N * 4);
+    take(w.wave_bytes, N * 8);
+    take(w.wave_off, (N + 1) * 8);
+    take(w.tile_sums, scan_tiles_needed(N) * 8);
+    take(w.fin32, N * fast_fin_stride() * 4);
+    take(w.workspace, (bytes - o) & ~(size_t)255);
+}
+
 template <class F>
 int guarded(F&& body) {
     try {
         return body();
+    } catch (const ScratchFull& f) {
+        return fail(TP_E_NOMEM, "this input needs " + std::to_string(f.bytes) + " bytes in a piece of the fixed working memory that holds " + std::to_string(f.cap));
     } catch (const HipFail& h) {
         return fail(TP_E_DEVICE, std::string("HIP error: ") + hipGetErrorString(h.e) + " in " + h.what);
     } catch (const ConfigError& e) {
@@ -467,20 +521,20 @@ void compute_fallback(tp_ctx* c) {
     c->dt = saved;
     if (rc != TP_OK) throw ConfigError("could not evaluate the minimal fallback line: " + g_error);
     uint32_t nfin = 0;
-    HIP_OK(hipMemcpy(&nfin, c->n_final.p, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&nfin, c->w->n_final.p, 4, hipMemcpyDeviceToHost));
     tp_verdict v{};
     HIP_OK(hipMemcpy(&v, c->out_verdicts.p, sizeof v, hipMemcpyDeviceToHost));
     if (v.flags & TP_F_UNSUPPORTED) throw ConfigError("the minimal fallback line holds text this build does not process");
     if (nfin > (uint32_t)MAX_FALLBACK) throw ConfigError("internal: fallback selection too long");
     // the final list of file 0 sits in lane 0 of the first wavefront's workspace
     uint32_t T = 0, LB = 0;
-    HIP_OK(hipMemcpy(&T, c->wave_T.p, 4, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(&LB, c->wave_LB.p, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&T, c->w->wave_T.p, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&LB, c->w->wave_LB.p, 4, hipMemcpyDeviceToHost));
     WsLayout lay = ws_layout(T, LB, c->dt.final_cap, c->dt.evidence_grow, c->dt.lit_words);
     std::vector<uint32_t> ids(nfin);
     for (uint32_t k = 0; k < nfin; ++k) {
         uint64_t h = 0;
-        HIP_OK(hipMemcpy(&h, c->workspace.as<uint8_t>() + lay.o_fin + (size_t)k * 64 * 8, 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(&h, c->w->workspace.as<uint8_t>() + lay.o_fin + (size_t)k * 64 * 8, 8, hipMemcpyDeviceToHost));
         if (h >> 32) throw ConfigError("internal: fallback tag outside the tables");
         ids[k] = (uint32_t)h;
     }
@@ -519,6 +573,9 @@ tp_ctx* tp_create(const tp_config* cfg) {
         HIP_OK(hipSetDevice(c->device));
         if (const char* b = std::getenv("TAGPIPE_WORKSPACE_BYTES")) { unsigned long long v = std::strtoull(b, nullptr, 10); if (v >= (1ull << 20)) c->ws_budget = (size_t)v; }
         if (const char* b = std::getenv("TAGPIPE_NO_FAST")) c->no_fast = b[0] == '1';
+        HIP_OK(hipHostMalloc((void**)&c->host_scalars, 64, hipHostMallocDefault));
+        std::memset(c->host_scalars, 0, 64);
+        bind_fixed(c.get());
         compile_tables(*cfg, c->ht);
         const HostTables& h = c->ht;
         DevTables& d = c->dt;
@@ -694,6 +751,27 @@ int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_b
         r.caption_offsets = io->caption_offsets; r.verdicts = io->verdicts; r.histogram = io->histogram; r.counters = io->counters;
         r.fired = io->fired; r.facet_choice = io->facet_choice; r.stream = (hipStream_t)io->stream; r.mode = 0;
         return run_device(ctx, r, caption_bytes);
+    });
+}
+
+int tp_run_lines_device_noalloc(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes) {
+    if (!ctx || !io || !io->offsets || !io->caption_offsets || (io->n_files && (!io->verdicts || !io->captions))) return fail(TP_E_INVALID_ARG, "null argument");
+    if (io->n_files > TP_NOALLOC_MAX_FILES)
+        return fail(TP_E_INVALID_ARG, "tp_run_lines_device_noalloc takes at most " + std::to_string((unsigned long long)TP_NOALLOC_MAX_FILES) + " files a call, got " +
+                                      std::to_string((unsigned long long)io->n_files));
+    // the run works in the pieces of the static array instead of the context's own buffers, and within that workspace
+    struct Swap {
+        tp_ctx* c; WorkBufs* w; size_t budget;
+        explicit Swap(tp_ctx* c_) : c(c_), w(c_->w), budget(c_->ws_budget) { c->w = &c->fixed; c->ws_budget = c->fixed.workspace.cap; }
+        ~Swap() { c->w = w; c->ws_budget = budget; }
+    } swap(ctx);
+    return guarded([&]() {
+        RunIo r{};
+        r.arena = io->arena; r.offsets = io->offsets; r.n_files = io->n_files;
+        r.captions = io->captions; r.caption_capacity = io->caption_capacity; r.grow_captions = false;
+        r.caption_offsets = io->caption_offsets; r.verdicts = io->verdicts; r.histogram = io->histogram; r.counters = io->counters;
+        r.fired = io->fired; r.facet_choice = io->facet_choice; r.stream = (hipStream_t)io->stream; r.mode = 0;
+        return run_device(ctx, r, caption_bytes, nullptr, /*timed=*/false);
     });
 }
 

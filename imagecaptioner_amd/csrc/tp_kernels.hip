@@ -13,7 +13,9 @@
 //                  tag histogram (block-private LDS counters for the low, frequent ids; global atomics for the tail),
 //                  batch counters.
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "tp_fast.h"
 #include "tp_lean.h"
@@ -828,6 +830,35 @@ __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Working memory of the entry point that may not allocate: one array per GPU, part of the code object, held until the
+// process ends.  In host code the array's name is only a handle for hipGetSymbolAddress; its address on a device is
+// asked for once per device, with that device current, and kept.  Kernels get that address as an argument.
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+hipError_t noalloc_scratch(int device, void** ptr, size_t* bytes) {
+    static std::mutex mu;
+    static void* known[NOALLOC_MAX_DEVICES];       // known[d]: address of `scratch` on device d, null until asked
+    *ptr = nullptr;
+    *bytes = NOALLOC_SCRATCH_BYTES;
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!known[device]) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) return e;
+        if (current != device) return hipErrorInvalidDevice;      // the caller makes the device current first
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p || ((uintptr_t)p & 255)) return hipErrorInvalidSymbol;
+        known[device] = p;
+    }
+    *ptr = known[device];
+    return hipSuccess;
+}
+
 uint32_t fast_fin_stride() { return FAST_FIN_MAX; }
 bool lean_ok(const DevTables& t) { return lean_tables_ok(t); }
 

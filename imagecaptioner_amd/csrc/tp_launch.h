@@ -104,6 +104,11 @@ struct EmitArgs {
     tp_counters* counters;        // accumulated; may be null
 };
 
+// Address and size of this device's static working memory (see tp_kernels.hip); `device` must be the current device.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)16 << 20;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+hipError_t noalloc_scratch(int device, void** ptr, size_t* bytes);
+
 // `between`: when not null and the stage launches two kernels (stage 0), recorded on the stream after the first of them.
 hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between = nullptr);
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,

@@ -18,10 +18,13 @@ _LIB = None
 
 EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
-    "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_format_top_tags", "tp_get_last_timing",
+    "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_run_lines_device_noalloc", "tp_format_top_tags", "tp_get_last_timing",
     "tp_triage_lines", "tp_run_merged", "tp_format_fired_rules", "tp_needtag_text", "tp_format_side_files",
     "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows", "tp_review_csv_header", "tp_format_review_rows",
 )
+
+
+NOALLOC_MAX_FILES = 16384     # TP_NOALLOC_MAX_FILES
 
 
 class TagPipeError(RuntimeError):
@@ -54,6 +57,8 @@ def load_library():
     L.tp_release.argtypes = [C.c_void_p, C.POINTER(tp_result)]
     L.tp_release.restype = None
     L.tp_run_lines_device.argtypes = [C.c_void_p, C.POINTER(tp_device_io), C.POINTER(C.c_uint64)]
+    L.tp_run_lines_device_noalloc.restype = C.c_int
+    L.tp_run_lines_device_noalloc.argtypes = [C.c_void_p, C.POINTER(tp_device_io), C.POINTER(C.c_uint64)]
     L.tp_format_top_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tp_get_last_timing.argtypes = [C.c_void_p, C.POINTER(tp_timing)]
     L.tp_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(tp_result)]
@@ -374,11 +379,12 @@ class TagPipe:
         return self._collect(res, audit)
 
     # ---- device-resident run ---------------------------------------------------------------------
-    def run_lines_device(self, io: tp_device_io):
+    def run_lines_device(self, io: tp_device_io, noalloc=False):
         """tp_run_lines_device: every pointer in `io` is a device pointer.  Returns the caption byte count;
-        raises TagPipeError(code TP_E_CAPACITY) when the caption buffer is too small."""
+        raises TagPipeError(code TP_E_CAPACITY) when the caption buffer is too small.  noalloc=True calls
+        tp_run_lines_device_noalloc instead (at most NOALLOC_MAX_FILES files, no device allocation during the call)."""
         nbytes = C.c_uint64()
-        rc = self._L.tp_run_lines_device(self._h, C.byref(io), C.byref(nbytes))
+        rc = (self._L.tp_run_lines_device_noalloc if noalloc else self._L.tp_run_lines_device)(self._h, C.byref(io), C.byref(nbytes))
         if rc != TP_OK:
             err = TagPipeError(rc, self._L.tp_last_error().decode("utf-8", "replace"))
             err.required = nbytes.value

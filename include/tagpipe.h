@@ -252,6 +252,24 @@ typedef struct tp_device_io {
 int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes);
 
 /*
+ * tp_run_lines_device for callers that cannot allocate device memory while they
+ * run (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Same arguments, outputs and
+ * return codes, but the call makes no hipMalloc / hipFree / event creation:
+ * everything it needs besides the caller's buffers lives in one static array
+ * of 16 MiB that each GPU the library runs on holds until the process ends.
+ * Limits: at most TP_NOALLOC_MAX_FILES files a call (more: TP_E_INVALID_ARG);
+ * files that need the general kernel share about 6 MiB of workspace, 64 files
+ * at a time at the least (does not fit: TP_E_NOMEM, nothing useful written).
+ * tp_get_last_timing reports zeros after this call.  Every context on a GPU
+ * shares that GPU's array: calls that overlap in time on one GPU race, also
+ * from different contexts or streams; the array keeps the last call's contents
+ * and the call clears what it needs cleared.
+ */
+#define TP_NOALLOC_MAX_FILES 16384
+int tp_run_lines_device_noalloc(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes);
+
+/*
  * Existing-caption triage (Program.cs:203-210 with --reprocess-bad-existing): for every file's text, would the
  * reference regenerate the caption?  bad[i] = 1 when LooksBad(NormalizeRawTagLine(text_i)) (the file is deleted and the
  * image captioned again, Program.cs:207-209), 0 when the existing caption is kept (the image is skipped), 2 when the text
