@@ -242,7 +242,7 @@ def _picks(total, pool_n, seed, zipf_s=None):
 
 
 def make_corpus(name, n_files, seed=1234):
-    """One of the benchmark configurations (c1..c5) as a Corpus."""
+    """One of the benchmark configurations (c1..c5, and c3c: c3 with the alias chains inside the vocabulary) as a Corpus."""
     name = name.lower()
     if name == "c1":
         with open(os.path.join(REFERENCE_DATA, "top_tags.txt"), "r", encoding="utf-8") as f:
@@ -262,13 +262,17 @@ def make_corpus(name, n_files, seed=1234):
         picks = _picks(int(counts.sum()), len(pool), seed, zipf_s=1.1 if name == "c4" else None)
         cfg = dict(lexicon=json.dumps(lex).encode(), vocabulary=("\n".join(vocab) + "\n").encode(), vocabulary_is_json=0,
                    minimal_subject_tags="1girl, solo")
-    elif name == "c3":
+    elif name in ("c3", "c3c"):
         vocab = make_vocabulary(50000, seed=1)
         lex = make_lexicon(vocab, 100000, seed=2, chains=True)
         pool = vocab + list(lex["aliases"].keys())[:20000]
         counts = _tag_counts("poisson40", n_files, seed)
         picks = _picks(int(counts.sum()), len(pool), seed)
-        cfg = dict(lexicon=json.dumps(lex).encode(), vocabulary=("\n".join(vocab) + "\n").encode(), vocabulary_is_json=0,
+        # c3: the vocabulary file holds the plain tags only, so strict vocabulary (which a vocabulary file switches on,
+        # Program.cs:999-1002) drops every chain member at ingest (Program.cs:601).  c3c: the chain and cycle members are
+        # in the vocabulary file too, so a tag moves one alias hop at each NormalizeTag site and the chains are walked.
+        known = vocab + ([k for k in lex["aliases"] if k.startswith(("syn", "cyc"))] if name == "c3c" else [])
+        cfg = dict(lexicon=json.dumps(lex).encode(), vocabulary=("\n".join(known) + "\n").encode(), vocabulary_is_json=0,
                    minimal_subject_tags="1girl, solo")
     elif name == "c5":
         vocab = make_vocabulary(20000, seed=1)

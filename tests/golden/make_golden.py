@@ -23,7 +23,7 @@ CONFIGS = {
     "shipped_nonstrict": lambda: shipped_config(strict_known=False, strict_known_explicit=True),
     "builtin": lambda: Config(trigger="trigger_token", minimal_subject_tags="1girl", no_profile=True),
 }
-CORPORA = {"c1": 1000, "c2": 1000, "c3": 500, "c4": 500, "c5": 300}
+CORPORA = {"c1": 1000, "c2": 1000, "c3": 500, "c3c": 500, "c4": 500, "c5": 300}
 
 
 def main():

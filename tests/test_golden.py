@@ -22,7 +22,7 @@ def test_edge_lines_oracle_matches_golden(name):
         assert [int(x) for x in r.verdicts[i]] == exp["verdict"], (name, i, g["lines"][i])
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c3c", "c4", "c5"])
 def test_corpus_digests_oracle_matches_golden(name):
     with open(os.path.join(GOLDEN, "corpus_digests.json")) as f:
         g = json.load(f)[name]

@@ -52,7 +52,7 @@ def test_replies_match_committed_golden(name):
     check_replies_golden(p.run_scored, p.run_merged, p.triage_texts, name, g)
 
 
-@pytest.mark.parametrize("name,n", [("c1", 4000), ("c2", 6000), ("c3", 3000), ("c4", 3000), ("c5", 1500)])
+@pytest.mark.parametrize("name,n", [("c1", 4000), ("c2", 6000), ("c3", 3000), ("c3c", 4000), ("c4", 3000), ("c5", 1500)])
 def test_benchmark_corpora(name, n):
     from imagecaptioner_amd.corpus import make_corpus
     c = make_corpus(name, n, seed=4242)
@@ -61,9 +61,16 @@ def test_benchmark_corpora(name, n):
     got, want = p.run_lines(c.arena, c.offsets), Oracle(cfg).run_lines(c.arena, c.offsets, threads=16)
     assert got.counters["unsupported"] == 0
     assert_same_results(got, want, p.histogram_dict(got.histogram), name)
+    if name == "c3c":
+        # the alias chains (depth 2-8) and 2-cycles are inside the vocabulary here: tags move one hop per NormalizeTag site
+        from test_pipeline_logic_cpu import check_chains_are_walked
+        check_chains_are_walked(c, got)
+        general = p.last_timing()["general_files"]
+        print("c3c: %d of %d files in the general kernel" % (general, n))
+        assert general <= n // 50
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c3c", "c4", "c5"])
 def test_corpus_digests_match_committed_golden(name):
     from imagecaptioner_amd.corpus import make_corpus
     with open(os.path.join(GOLDEN, "corpus_digests.json")) as f:

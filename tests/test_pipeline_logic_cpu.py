@@ -68,7 +68,20 @@ def test_edge_and_fuzz_lines(name):
     assert_same_results(got, want, s.histogram_dict(got.histogram), name)
 
 
-@pytest.mark.parametrize("name,n", [("c1", 600), ("c2", 800), ("c3", 500), ("c4", 500), ("c5", 200)])
+def chain_tags(text):
+    """Members of c3c's alias chains and cycles among the tags of a line."""
+    return [t for t in text.strip().split(", ") if t.startswith(("syn", "cyc"))]
+
+
+def check_chains_are_walked(corpus, result):
+    """c3c: chain members occur in the input, many of them reach the plain tag at the end of their chain on the way
+    through the NormalizeTag sites, and some are still chain members in the caption."""
+    n_in = sum(len(chain_tags(corpus.line(i).decode())) for i in range(corpus.n_files))
+    n_out = sum(len(chain_tags(result.caption(i).decode())) for i in range(corpus.n_files))
+    assert n_in > corpus.n_files and 0 < n_out < n_in, (n_in, n_out)
+
+
+@pytest.mark.parametrize("name,n", [("c1", 600), ("c2", 800), ("c3", 500), ("c3c", 500), ("c4", 500), ("c5", 200)])
 def test_benchmark_corpora(name, n):
     c = make_corpus(name, n, seed=77)
     cfg = Config(**c.config_kwargs)
@@ -76,6 +89,8 @@ def test_benchmark_corpora(name, n):
     want, got = o.run_lines(c.arena, c.offsets, threads=8), s.run_lines(c.arena, c.offsets)
     assert got.counters["unsupported"] == 0
     assert_same_results(got, want, s.histogram_dict(got.histogram), name)
+    if name == "c3c":
+        check_chains_are_walked(c, want)
 
 
 def scored_inputs(seed, n_files):
@@ -161,15 +176,51 @@ def test_wave_kernel_edge_and_fuzz_lines(name):
     assert_same_results(got, want, s.histogram_dict(got.histogram), name + " wave kernel")
 
 
-@pytest.mark.parametrize("name,n", [("c1", 250), ("c2", 250), ("c3", 250), ("c4", 250), ("c5", 120)])
+@pytest.mark.parametrize("name,n", [("c1", 250), ("c2", 250), ("c3", 250), ("c3c", 400), ("c4", 250), ("c5", 120)])
 def test_wave_kernel_benchmark_corpora(name, n):
     c = make_corpus(name, n, seed=91)
     cfg = Config(**c.config_kwargs)
     o, s = Oracle(cfg), HostSim(cfg)
     want, got = o.run_lines(c.arena, c.offsets, threads=8), s.run_lines_fast(c.arena, c.offsets)
     assert_same_results(got, want, s.histogram_dict(got.histogram), name + " wave kernel")
-    if name in ("c2", "c3", "c4"):
+    if name in ("c2", "c3", "c3c", "c4"):
         assert got.n_general <= n // 20, "the wave-per-file kernel should take nearly every file of %s (declined %d)" % (name, got.n_general)
+    if name == "c3c":
+        check_chains_are_walked(c, got)
+
+
+# ---- the lean stage (tp_lean.h) in front of the wave stages, on an emulated wavefront ---------------------------------
+@pytest.mark.parametrize("details", [False, True])
+@pytest.mark.parametrize("name,n,least", [("c1", 300, 0.85), ("c2", 400, 0.95), ("c3", 300, 0.9), ("c3c", 300, 0.0), ("c4", 300, 0.8), ("c5", 150, 0.6)])
+def test_lean_stage_benchmark_corpora(name, n, least, details):
+    """The flow the library runs: lean stage, then the wave stages for what it declines, then the general kernel.  Without the
+    detail arrays (details=False: fired / facet_choice null) the evidence set is not counted and more files stay lean."""
+    c = make_corpus(name, n, seed=123)
+    cfg = Config(**c.config_kwargs)
+    o, s = Oracle(cfg), HostSim(cfg)
+    want, got = o.run_lines(c.arena, c.offsets, threads=8), s.run_lines_lean(c.arena, c.offsets, details)
+    if not details:
+        skipped = got.verdicts["n_evidence"] == 0xFFFF          # only the emulation's general pipeline counts it regardless
+        assert int(skipped.sum()) >= n - got.n_general
+        got.verdicts["n_evidence"][skipped] = want.verdicts["n_evidence"][skipped]
+        got.fired = want.fired
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "%s lean stage" % name)
+    if not details:
+        assert got.n_lean >= least * n, "the lean stage should take most files of %s (took %d of %d)" % (name, got.n_lean, n)
+    assert got.n_general <= n // 10
+
+
+def test_lean_stage_edge_fuzz_and_spellings():
+    for name in sorted(CONFIGS):
+        cfg = CONFIGS[name]()
+        o, s = Oracle(cfg), HostSim(cfg)
+        lines = EDGE_LINES + fuzz_lines(29, 300)
+        want, got = o.run_texts(lines), s.run_texts_lean(lines)
+        assert_same_results(got, want, s.histogram_dict(got.histogram), name + " lean stage")
+    for lines, cfg in (spelling_variants(200, seed=8), multi_line_texts(200, seed=9)):
+        o, s = Oracle(cfg), HostSim(cfg)
+        want, got = o.run_texts(lines), s.run_texts_lean(lines)
+        assert_same_results(got, want, s.histogram_dict(got.histogram), "respelled lines, lean stage")
 
 
 def spelling_variants(n, seed=3):
