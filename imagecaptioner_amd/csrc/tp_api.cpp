@@ -778,19 +778,10 @@ int tp_run_lines_device_noalloc(tp_ctx* ctx, const tp_device_io* io, uint64_t* c
 int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* out, uint64_t capacity, uint64_t* needed) {
     if (!ctx || !histogram || !needed) return fail(TP_E_INVALID_ARG, "null argument");
     return guarded([&]() {
-        const HostTables& h = ctx->ht;
-        std::vector<uint32_t> ids;
-        for (uint32_t i = 0; i < ctx->dt.n_strings; ++i) if (histogram[i]) ids.push_back(i);
-        std::sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
-            if (histogram[a] != histogram[b]) return histogram[a] > histogram[b];
-            return h.strings[a] < h.strings[b];
-        });
-        uint64_t size = 0;
-        for (uint32_t i : ids) size += h.strings[i].size() + 1;
-        *needed = size;
-        if (!out || capacity < size) return size ? fail(TP_E_CAPACITY, "output buffer too small") : TP_OK;
-        uint64_t o = 0;
-        for (uint32_t i : ids) { std::memcpy(out + o, h.strings[i].data(), h.strings[i].size()); o += h.strings[i].size(); out[o++] = '\n'; }
+        const std::string text = top_tags_text(ctx->ht, histogram);
+        *needed = text.size();
+        if (!out || capacity < text.size()) return text.empty() ? TP_OK : fail(TP_E_CAPACITY, "output buffer too small");
+        std::memcpy(out, text.data(), text.size());
         return TP_OK;
     });
 }

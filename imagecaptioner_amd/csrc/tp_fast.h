@@ -1024,7 +1024,6 @@ template <int NT, int NF, class W, class Front = LineFront>
 TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
                      uint32_t* fired, uint16_t* facet_choice, bool triage = false, Front* front = nullptr) {
     static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
-    constexpr uint32_t FIN_MAX = 64u * NF;
     const uint32_t lane = w.lane();
     int nblk = 1;
     uint32_t n = 0;

@@ -1309,6 +1309,18 @@ void set_fallback(const HostTables& ht, DevTables& dt, const uint32_t* ids, uint
     }
 }
 
+std::string top_tags_text(const HostTables& h, const uint64_t* histogram) {
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < (uint32_t)h.strings.size(); ++i) if (histogram[i]) ids.push_back(i);
+    std::sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
+        if (histogram[a] != histogram[b]) return histogram[a] > histogram[b];
+        return h.strings[a] < h.strings[b];
+    });
+    std::string text;
+    for (uint32_t i : ids) { text += h.strings[i]; text += '\n'; }
+    return text;
+}
+
 DevTables bind_host_pointers(const HostTables& ht) {
     DevTables t = ht.scalars;
     t.str_bytes = ht.str_bytes.data();

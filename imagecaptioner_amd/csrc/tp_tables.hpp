@@ -59,6 +59,10 @@ void set_fallback(const HostTables& ht, DevTables& dt, const uint32_t* ids, uint
 // a < b under StringComparer.OrdinalIgnoreCase (UTF-16 code units, upper-cased the invariant way), both UTF-8.
 bool less_ordinal_ignore_case(const std::string& a, const std::string& b);
 
+// The corpus-wide tag table as a file LoadKnownTagDictionary reads (one tag per line, Program.cs:1021-1028): tags with a
+// non-zero count, by count descending, then by the tag's bytes ascending.  `histogram` has one count per interned string.
+std::string top_tags_text(const HostTables& ht, const uint64_t* histogram);
+
 // A DevTables whose pointers address the HostTables vectors themselves (host-side logic checks).
 DevTables bind_host_pointers(const HostTables& ht);
 

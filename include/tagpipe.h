@@ -197,7 +197,12 @@ int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uin
  * arena[tag_offsets[t] .. tag_offsets[t+1]), with score scores[t] and source
  * sources[t] (TP_SRC_*).  Each tag is normalised once, blank ones are skipped,
  * order is the running index, and the list is sorted by score descending then
- * order (Program.cs:483-487) before SelectTags.
+ * order (Program.cs:483-487) before SelectTags.  Scores must be finite: a NaN
+ * or an infinity anywhere in `scores` fails the call with TP_E_INVALID_ARG
+ * before anything runs (the reference's JSON ingest cannot produce either, and
+ * its comparisons and Math.Max / Math.Abs steps are left undefined for them
+ * here); tp_run_merged does the same.  Everything finite is taken as it is:
+ * negative, above 1, -0.0, denormal.
  */
 int tp_run_scored(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin,
                   const double* scores, const uint8_t* sources, uint64_t n_files, tp_result* out);

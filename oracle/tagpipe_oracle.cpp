@@ -1449,6 +1449,8 @@ int orc_run_scored(void* ctx, const uint8_t* arena, const uint64_t* tag_offsets,
     try {
         Ctx* cx = (Ctx*)ctx;
         if (!cx || !out) { g_err = "invalid argument"; return TP_E_INVALID_ARG; }
+        for (uint64_t t = 0, nt = n ? tag_begin[n] : 0; t < nt; ++t)
+            if (!(scores[t] - scores[t] == 0.0)) { g_err = "scores must be finite"; return TP_E_INVALID_ARG; }   // NaN / infinity: not reachable through the reference's JSON ingest, left undefined
         std::unique_ptr<Batch> b(new Batch());
         tp_counters ctr;
         ScoredInput si{arena, tag_offsets, tag_begin, scores, sources, nullptr, 0};
@@ -1462,6 +1464,8 @@ int orc_run_merged(void* ctx, const uint8_t* arena, const uint64_t* tag_offsets,
     try {
         Ctx* cx = (Ctx*)ctx;
         if (!cx || !out || !secondary_begin) { g_err = "invalid argument"; return TP_E_INVALID_ARG; }
+        for (uint64_t t = 0, nt = n ? tag_begin[n] : 0; t < nt; ++t)
+            if (!(scores[t] - scores[t] == 0.0)) { g_err = "scores must be finite"; return TP_E_INVALID_ARG; }   // NaN / infinity: not reachable through the reference's JSON ingest, left undefined
         std::unique_ptr<Batch> b(new Batch());
         tp_counters ctr;
         ScoredInput si{arena, tag_offsets, tag_begin, scores, nullptr, secondary_begin, secondary_cap};

@@ -96,6 +96,16 @@ class HostSim:
         nz = np.nonzero(np.asarray(histogram)[:len(s)])[0]
         return {s[int(i)]: int(histogram[int(i)]) for i in nz}
 
+    def format_top_tags(self, histogram):
+        hist = np.ascontiguousarray(histogram, dtype=np.uint64)
+        assert len(hist) >= self.info.n_strings
+        self._L.sim_format_top_tags.restype = C.c_uint64
+        self._L.sim_format_top_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        need = self._L.sim_format_top_tags(self._h, hist.ctypes.data, None, 0)
+        buf = np.zeros(max(need, 1), dtype=np.uint8)
+        self._L.sim_format_top_tags(self._h, hist.ctypes.data, buf.ctypes.data, need)
+        return bytes(buf[:need])
+
     def _collect(self, res, rc):
         if rc != 0:
             raise RuntimeError(self._L.sim_last_error().decode())
@@ -416,3 +426,35 @@ def triage_lines(seed, n):
             line = rng.choice(["POSITIVE: ", "```\n", " ", "NEGATIVE: "]) + line + rng.choice(["", "\n```", "\nNEGATIVE: bad", "\r\n"])
         out.append(line)
     return out
+
+
+def check_top_tags_file(make_engine):
+    """tp_format_top_tags: tags by count descending then bytes ascending, zero counts left out, and the text read back as
+    the vocabulary file (LoadKnownTagDictionary's line format, Program.cs:1021-1028) makes every counted tag a known tag.
+
+    Parity unpinned: the reference never writes this file and holds no fixture of it; what is checked is the stated
+    order, the reader's contract, and captions against the oracle when the written file is the vocabulary."""
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus("c1", 400, seed=21)
+    cfg = Config(**c.config_kwargs)
+    eng = make_engine(cfg)
+    r = eng.run_lines(c.arena, c.offsets)
+    hist = eng.histogram_dict(r.histogram)
+    assert Oracle(cfg).run_lines(c.arena, c.offsets).histogram == hist
+    text = eng.format_top_tags(r.histogram)
+    assert text.endswith(b"\n") and b"\r" not in text and b"," not in text
+    lines = text.decode("utf-8").split("\n")[:-1]
+    assert len(lines) == len(set(lines)) and set(lines) == set(hist)          # every counted tag once; none with count zero
+    keys = [(-hist[t], t.encode("utf-8")) for t in lines]
+    assert keys == sorted(keys) and len({k[0] for k in keys}) < len(keys)      # ties exist and are ordered by bytes
+    assert eng.format_top_tags(np.zeros_like(np.asarray(r.histogram))) == b""
+    # read back as the vocabulary
+    kw = dict(c.config_kwargs)
+    kw.update(vocabulary=text, vocabulary_is_json=0)
+    o = Oracle(Config(**kw))
+    assert o.info.known_found == 1 and o.info.strict_known == 1 and o.info.n_known_tags == len(lines)
+    assert not [t for t in lines if o.should_drop_tag(t)]
+    eng2 = make_engine(Config(**kw))
+    got, want = eng2.run_lines(c.arena, c.offsets), o.run_lines(c.arena, c.offsets)
+    assert_same_results(got, want, eng2.histogram_dict(got.histogram), "written top_tags as vocabulary")
+    assert set(eng2.histogram_dict(got.histogram)) <= set(lines)               # strict vocabulary: nothing new appears

@@ -138,6 +138,13 @@ int sim_info(void* h, tp_table_info* out) {
     out->fired_words = s->dt.fired_words; out->n_known_tags = s->ht.n_known; out->strict_known = s->ht.strict; out->known_found = s->ht.known_found;
     return 0;
 }
+// tp_format_top_tags' text (the same top_tags_text the library calls); returns the full size, writes at most `capacity` bytes
+uint64_t sim_format_top_tags(void* h, const uint64_t* histogram, uint8_t* out, uint64_t capacity) {
+    const std::string text = top_tags_text(((Sim*)h)->ht, histogram);
+    if (out && capacity) std::memcpy(out, text.data(), std::min<uint64_t>(capacity, text.size()));
+    return text.size();
+}
+
 const char* sim_string(void* h, uint32_t id) { return ((Sim*)h)->ht.strings[id].c_str(); }
 
 struct sim_result {

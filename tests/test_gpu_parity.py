@@ -518,3 +518,61 @@ def test_full_size_properties():
     want = Oracle(cfg).run_lines(c.arena, c.offsets[:m + 1], threads=16)
     assert np.array_equal(whole.captions[:int(whole.caption_offsets[m])], want.captions)
     assert whole.verdicts[:m].tobytes() == want.verdicts.tobytes()
+
+
+# ---- table files in every shape the reference's loaders accept (shapes and reference lines: loader_shapes.py) ----
+def _shape_names():
+    from loader_shapes import SHAPES
+    return sorted(SHAPES)
+
+
+@pytest.mark.parametrize("name", _shape_names())
+def test_loader_shapes_match_the_oracle(name):
+    from loader_shapes import SHAPES, shape_lines
+    cfg = SHAPES[name]()
+    p = pipe_for(cfg)
+    lines = shape_lines()
+    got, want = p.run_texts(lines), Oracle(cfg).run_texts(lines)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name)
+
+
+@pytest.mark.parametrize("name", ["case_mapping_twins", "trigger_with_comma", "always_add_with_comma"])
+def test_tables_this_build_refuses(name):
+    """Tables the reference loads and this build cannot represent: tp_create fails with TP_E_CONFIG and says why."""
+    from imagecaptioner_amd import TagPipeError
+    from imagecaptioner_amd._abi import TP_E_CONFIG
+    from loader_shapes import REJECTED
+    with pytest.raises(TagPipeError) as e:
+        pipe_for(REJECTED[name]())
+    assert e.value.code == TP_E_CONFIG and "not representable" in str(e.value)
+
+
+def test_top_tags_file_order_and_round_trip():
+    """tp_format_top_tags through the C ABI, with the histogram the kernels counted."""
+    from helpers import check_top_tags_file
+    check_top_tags_file(pipe_for)
+
+
+@pytest.mark.parametrize("kind", ["nan", "inf", "-inf"])
+def test_non_finite_scores_are_refused(kind):
+    """A NaN or an infinity in `scores` fails tp_run_scored / tp_run_merged with TP_E_INVALID_ARG before anything runs."""
+    from imagecaptioner_amd import TagPipeError
+    from imagecaptioner_amd._abi import TP_E_INVALID_ARG
+    from test_pipeline_logic_cpu import odd_scores
+    arena, offs, begin, scores, sources = odd_scores(kind)
+    p = pipe_for(CONFIGS["shipped"]())
+    with pytest.raises(TagPipeError) as e:
+        p.run_scored(arena, offs, begin, scores, sources)
+    assert e.value.code == TP_E_INVALID_ARG and "finite" in str(e.value)
+    with pytest.raises(TagPipeError) as e:
+        p.run_merged(arena, offs, begin, begin[:-1].copy(), scores, 15)
+    assert e.value.code == TP_E_INVALID_ARG
+
+
+def test_unusual_finite_scores():
+    from test_pipeline_logic_cpu import odd_scores
+    cfg = CONFIGS["shipped"]()
+    args = odd_scores("finite")
+    p = pipe_for(cfg)
+    got, want = p.run_scored(*args), Oracle(cfg).run_scored(*args)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "finite scores")

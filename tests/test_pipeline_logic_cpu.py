@@ -286,3 +286,39 @@ def test_wave_kernel_multi_line_texts():
     assert_same_results(got, want, s.histogram_dict(got.histogram), "multi-line")
     assert got.n_general == 0                                   # "\r\n" inside is taken out of the LDS copy, line feeds are blanks
     assert (want.verdicts["flags"] & 0x10).any()                # the refusals split by a line feed are rejected
+
+
+def odd_scores(kind):
+    """scored_inputs with a few scores replaced: 'finite' keeps them finite but unusual, the others plant one bad value."""
+    arena, offs, begin, scores, sources = scored_inputs(13, 300)
+    scores = scores.copy()
+    if kind == "finite":
+        scores[::7] = [(-0.0, 5e-324, 1.5, -3.0, 1e308, 0.28, 0.6)[i % 7] for i in range(len(scores[::7]))]
+    else:
+        scores[len(scores) // 2] = {"nan": float("nan"), "inf": float("inf"), "-inf": float("-inf")}[kind]
+    return arena, offs, begin, scores, sources
+
+
+@pytest.mark.parametrize("kind", ["nan", "inf", "-inf"])
+def test_non_finite_scores_are_refused(kind):
+    """NaN and the infinities cannot come out of the reference's JSON ingest; both the library (TP_E_INVALID_ARG, GPU test of
+    the same name) and the oracle refuse them instead of defining an order for them."""
+    from oracle.oracle_py import OracleError
+    arena, offs, begin, scores, sources = odd_scores(kind)
+    o = Oracle(CONFIGS["shipped"]())
+    with pytest.raises(OracleError) as e:
+        o.run_scored(arena, offs, begin, scores, sources)
+    assert "finite" in str(e.value)
+    with pytest.raises(OracleError):
+        o.run_merged(arena, offs, begin, begin[:-1].copy(), scores, 15)
+
+
+def test_unusual_finite_scores():
+    cfg = CONFIGS["shipped"]()
+    args = odd_scores("finite")
+    o, s = Oracle(cfg), HostSim(cfg)
+    want = o.run_scored(*args)
+    got = s.run_scored(*args)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "finite scores")
+    got = s.run_scored_fast(*args)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "finite scores, wave kernel")
