@@ -94,6 +94,85 @@ TP_HD bool is_tag_rest8(uint8_t c) {
     return is_tag_first8(c) || c == '_' || c == '(' || c == ')' || c == '!' || c == '\'' || c == '/' || c == '-';
 }
 
+// ---- text outside ASCII ---------------------------------------------------------------------------------
+// char.IsWhiteSpace for a character of the Basic Multilingual Plane (also what the regex class \s matches)
+TP_HD bool is_space16(uint32_t c) {
+    return c == 0x20 || (c >= 0x09 && c <= 0x0D) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 ||
+           c == 0x202F || c == 0x205F || c == 0x3000;
+}
+constexpr uint8_t WS_STAND_IN = 0x0C;     // the ASCII white-space byte a white-space character outside ASCII is rewritten to (not ' ', which phrases hold)
+
+// UTF-16 code units of valid UTF-8 text: every byte but the continuation bytes, and one more for each four-byte sequence.
+TP_HD uint32_t utf16_units(const uint8_t* p, uint32_t n) {
+    uint32_t u = 0;
+    for (uint32_t i = 0; i < n; ++i) u += ((p[i] & 0xC0) != 0x80) + (p[i] >= 0xF0);
+    return u;
+}
+// The end of text[i .. j) without its trailing run of [;。、\.] (Program.cs:1151; U+3002 and U+3001 are three bytes each).
+TP_HD uint32_t strip_tail_punct(const uint8_t* s, uint32_t i, uint32_t j) {
+    for (;;) {
+        if (j > i && (s[j - 1] == ';' || s[j - 1] == '.')) --j;
+        else if (j >= i + 3 && s[j - 3] == 0xE3 && s[j - 2] == 0x80 && (s[j - 1] == 0x82 || s[j - 1] == 0x81)) j -= 3;
+        else return j;
+    }
+}
+
+// Text with bytes outside ASCII, made ready for the byte-wise steps of the pipeline: src[0 .. n) must be well-formed UTF-8
+// (shortest forms, no surrogates, at most U+10FFFF).  Every white-space character outside ASCII becomes WS_STAND_IN (one
+// UTF-16 unit either way), every other character of the Basic Multilingual Plane becomes its ToLowerInvariant image,
+// characters beyond it are copied (char-wise lower-casing leaves surrogates alone), "\r\n" becomes "\n" when drop_crlf.
+// Returns the bytes written, or 0xFFFFFFFF when the text is not well-formed, does not fit `cap`, or - with refuse_twins -
+// holds a character whose lower-case form shares its capital with another (the reference's ordinal-ignore-case sets would
+// take two strings that differ in such characters for one; this code compares bytes).
+template <class TT>
+TP_HD uint32_t utf8_prepare(const TT& t, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, bool drop_crlf, bool refuse_twins) {
+    uint32_t i = 0, m = 0;
+    while (i < n) {
+        const uint8_t c = src[i];
+        if (c < 0x80) {
+            if (drop_crlf && c == '\r' && i + 1 < n && src[i + 1] == '\n') { ++i; continue; }
+            if (m >= cap) return 0xFFFFFFFFu;
+            dst[m++] = c; ++i;
+            continue;
+        }
+        uint32_t len, cp;
+        if (c >= 0xC2 && c <= 0xDF) { len = 2; cp = c & 0x1Fu; }
+        else if (c >= 0xE0 && c <= 0xEF) { len = 3; cp = c & 0x0Fu; }
+        else if (c >= 0xF0 && c <= 0xF4) { len = 4; cp = c & 0x07u; }
+        else return 0xFFFFFFFFu;
+        if (i + len > n) return 0xFFFFFFFFu;
+        for (uint32_t k = 1; k < len; ++k) {
+            const uint8_t d = src[i + k];
+            if ((d & 0xC0) != 0x80) return 0xFFFFFFFFu;
+            cp = (cp << 6) | (d & 0x3Fu);
+        }
+        if ((len == 3 && cp < 0x800) || (len == 4 && (cp < 0x10000 || cp > 0x10FFFF)) || (cp >= 0xD800 && cp <= 0xDFFF)) return 0xFFFFFFFFu;
+        uint32_t out = cp;
+        if (len < 4) {
+            if (is_space16(cp)) out = WS_STAND_IN;
+            else {
+                uint32_t lo = 0, hi = t.n_case_map;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((t.case_map[mid] >> 16) < cp) lo = mid + 1; else hi = mid; }
+                if (lo < t.n_case_map && (t.case_map[lo] >> 16) == cp) out = t.case_map[lo] & 0xFFFFu;
+                if (refuse_twins && out >= 0x80) {
+                    const uint32_t* tw = t.case_map + t.n_case_map;
+                    lo = 0; hi = t.n_case_twin;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (tw[mid] < out) lo = mid + 1; else hi = mid; }
+                    if (lo < t.n_case_twin && tw[lo] == out) return 0xFFFFFFFFu;
+                }
+            }
+        }
+        const uint32_t olen = out < 0x80 ? 1u : out < 0x800 ? 2u : out < 0x10000 ? 3u : 4u;
+        if (m + olen > cap) return 0xFFFFFFFFu;
+        if (olen == 1) dst[m] = (uint8_t)out;
+        else if (olen == 2) { dst[m] = (uint8_t)(0xC0 | (out >> 6)); dst[m + 1] = (uint8_t)(0x80 | (out & 0x3F)); }
+        else if (olen == 3) { dst[m] = (uint8_t)(0xE0 | (out >> 12)); dst[m + 1] = (uint8_t)(0x80 | ((out >> 6) & 0x3F)); dst[m + 2] = (uint8_t)(0x80 | (out & 0x3F)); }
+        else { dst[m] = src[i]; dst[m + 1] = src[i + 1]; dst[m + 2] = src[i + 2]; dst[m + 3] = src[i + 3]; }
+        m += olen; i += len;
+    }
+    return m;
+}
+
 // ---- hashing (equality is always verified on bytes; the hash only places and pre-filters) ----------------
 // The string is taken as little-endian 8-byte words (the last one zero-padded).  Word k is rotated by 13k bits and
 // folded in with xor, so absent (zero) words cost nothing and the words can be folded in any order; two multiply /
@@ -238,6 +317,10 @@ struct DevTables {
     const uint64_t* str_words;   // every string again as zero-padded little-endian 8-byte words, for word-wise probe verification
     const LeanSlot* lslots;      // the lean stage's lookup table, lslot_mask + 1 slots (null when it could not be built)
     uint32_t lslot_mask;
+    const uint32_t* case_map;    // n_case_map entries sorted by character: character << 16 | what ToLowerInvariant makes of it, for every character outside
+    uint32_t n_case_map;         //   ASCII that it changes; then n_case_twin lower-case characters, sorted, that share their capital with another
+    uint32_t n_case_twin;        //   lower-case character (ordinal-ignore-case comparison takes the two for one, byte comparison does not)
+    uint32_t tables_hold_twins;  // some table string holds such a character
     const uint32_t* attr2;       // per id: flags, byte length (two words)
     const uint32_t* crec;        // per id, eight words: flags, byte length, Rec::lit, min(step count, 3), step0, step1, s0_info, s1_info
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:

@@ -177,15 +177,17 @@ TP_HD uint32_t lfind_idx(const FileWs& ws, const LaneArr<H>& arr, uint32_t n, H 
     return n;
 }
 
-// Attributes of a string that is in no table (ASCII, already normalised).
+// Attributes of a string that is in no table (already normalised; bytes outside ASCII make it an invalid tag, Program.cs:40).
 TP_HD uint32_t classify_dyn(const DevTables& t, const uint8_t* p, uint32_t n) {
     bool valid = n > 0 && is_tag_first8(p[0]);
+    uint32_t units = 0;                                // string.Length (Program.cs:600): UTF-16 units
     uint32_t state = 0, mask = 0;
     // CharacterNameRegex ^[a-z0-9]+(_[a-z0-9]+){1,3}$ (Program.cs:47)
     uint32_t segs = 0, seglen = 0;
     bool name_ok = true;
     for (uint32_t i = 0; i < n; ++i) {
         uint8_t c = p[i];
+        units += ((c & 0xC0) != 0x80) + (c >= 0xF0);
         if (i > 0 && !is_tag_rest8(c)) valid = false;
         state = t.dfa_next[state * DFA_SYMS + dfa_sym(c)];
         mask |= t.dfa_out[state];
@@ -199,7 +201,7 @@ TP_HD uint32_t classify_dyn(const DevTables& t, const uint8_t* p, uint32_t n) {
                       : (mask & CM_BACKGROUND) ? B_BACKGROUND : (mask & CM_STYLE) ? B_STYLE : B_OTHER;                           // ClassifyTag, Program.cs:1103-1111
     bool rating = n >= 6 && p[0] == 'r' && p[1] == 'a' && p[2] == 't' && p[3] == 'i' && p[4] == 'n' && p[5] == 'g';
     bool drop = !valid || (mask & CM_SORRY) || (t.allow_nonempty && (rating || (mask & CM_WATERMARK))) || t.drop_unknown;    // ShouldDropTag, Program.cs:1121-1133
-    return (valid ? (uint32_t)FL_VALID : 0u) | (drop ? (uint32_t)FL_DROP : 0u) | (n >= 2 ? (uint32_t)FL_LEN2 : 0u) | (bucket << FL_BUCKET_SHIFT) |
+    return (valid ? (uint32_t)FL_VALID : 0u) | (drop ? (uint32_t)FL_DROP : 0u) | (units >= 2 ? (uint32_t)FL_LEN2 : 0u) | (bucket << FL_BUCKET_SHIFT) |
            ((mask & CM_HAIR) ? (uint32_t)FL_HAIR : 0u) | ((mask & CM_EYES) ? (uint32_t)FL_EYES : 0u);
 }
 
@@ -213,6 +215,20 @@ TP_HD bool has_word(const uint8_t* p, uint32_t n, const char* w, uint32_t wl) {
     }
     return false;
 }
+// Bytes of the decimal digit (Unicode category Nd, which is what \d matches) at p[i], or 0: ASCII digits, and the ten characters
+// from each of the Basic Multilingual Plane's other digit zeros.
+TP_HD uint32_t nd_len(const uint8_t* p, uint32_t n, uint32_t i) {
+    const uint8_t c = p[i];
+    if (c >= '0' && c <= '9') return 1;
+    if (c < 0xC2 || c > 0xEF) return 0;
+    const uint32_t len = c < 0xE0 ? 2u : 3u;
+    if (i + len > n) return 0;
+    const uint32_t cp = len == 2 ? ((c & 0x1Fu) << 6) | (p[i + 1] & 0x3Fu) : ((c & 0x0Fu) << 12) | ((p[i + 1] & 0x3Fu) << 6) | (p[i + 2] & 0x3Fu);
+    const uint16_t zeros[36] = {0x0660, 0x06F0, 0x07C0, 0x0966, 0x09E6, 0x0A66, 0x0AE6, 0x0B66, 0x0BE6, 0x0C66, 0x0CE6, 0x0D66, 0x0DE6, 0x0E50, 0x0ED0, 0x0F20, 0x1040, 0x1090,
+                                0x17E0, 0x1810, 0x1946, 0x19D0, 0x1A80, 0x1A90, 0x1B50, 0x1BB0, 0x1C40, 0x1C50, 0xA620, 0xA8D0, 0xA900, 0xA9D0, 0xA9F0, 0xAA50, 0xABF0, 0xFF10};
+    for (int k = 0; k < 36; ++k) if (cp >= zeros[k] && cp < zeros[k] + 10u) return len;
+    return 0;
+}
 TP_HD uint32_t subject_bits_dyn(const uint8_t* p, uint32_t n) {
     const bool girls = has_word(p, n, "girls", 5);
     if (!girls && !has_word(p, n, "boys", 4)) return 0;
@@ -220,7 +236,7 @@ TP_HD uint32_t subject_bits_dyn(const uint8_t* p, uint32_t n) {
     if (girls || has_word(p, n, "girl", 4)) bits |= FL_SUBJ_GIRL;
     bool multi = n >= 9 && has_word(p, 9, "multiple_", 9);
     uint32_t d = 0;
-    while (d < n && p[d] >= '0' && p[d] <= '9') ++d;
+    for (uint32_t l; d < n && (l = nd_len(p, n, d)) != 0;) d += l;          // ^\d+(girl|girls|boy|boys)$, Program.cs:837
     if (d > 0) {
         const uint32_t r = n - d;
         const uint8_t* q = p + d;
@@ -301,50 +317,29 @@ struct NormIt {
 // One raw token -> the handle NormalizeTag (Program.cs:1149-1158) gives it.  Returns false when the token is empty
 // after trimming (Split's RemoveEmptyEntries, Program.cs:1183-1185).  `final_nl_rule` applies the regex `$` rule of
 // Program.cs:1151 (it also matches before a final '\n'): only scored ingest can see a real '\n' there.
+// `raw_utf8`: the bytes are as the caller gave them; otherwise utf8_prepare has been over them.
 TP_HD bool make_token(const DevTables& t, FileWs& ws, uint32_t& norm_used, const uint8_t* s, uint32_t i, uint32_t j, bool final_nl_rule,
-                      H& out, bool& unsupported) {
+                      H& out, bool& unsupported, bool raw_utf8 = false) {
     while (i < j && is_ws8(s[i])) ++i;                 // TrimEntries / Trim()
     while (j > i && is_ws8(s[j - 1])) --j;
     if (i == j) return false;
-    {
-        // Characters outside ASCII need Unicode white-space, case and punctuation rules, which this code does not carry.  One case
-        // needs none of them: the bytes are, as they stand, an interned string that the steps before the alias lookup leave alone
-        // (such a string holds no white space, capital, or quote or punctuation at its ends): then they are the normalised string.
-        bool high = false;
-        for (uint32_t p = i; p < j; ++p) high |= s[p] >= 0x80;
-        if (high) {
-            Hasher hs;
-            for (uint32_t p = i; p < j; ++p) hs.add(s[p]);
-            const uint32_t n = j - i;
-            const uint64_t hsh = hs.done();
-            uint32_t slot = (uint32_t)hsh & t.ht_mask;
-            for (;;) {
-                const uint64_t hh = t.ht_hash[slot];
-                if (hh == 0) break;
-                if (hh == hsh) {
-                    const uint32_t id = t.ht_id[slot];
-                    if (str_len(t, id) == n) {
-                        const uint8_t* q = str_ptr(t, id);
-                        uint32_t k = 0;
-                        while (k < n && q[k] == s[i + k]) ++k;
-                        if (k == n) {
-                            if (t.slots[slot].kflags & SLOT_KEY_BASIC) { out = t.alias1[id]; return true; }
-                            break;
-                        }
-                    }
-                }
-                slot = (slot + 1) & t.ht_mask;
-            }
-            unsupported = true;
-            return false;
-        }
+    bool high = false;
+    for (uint32_t p = i; p < j; ++p) high |= s[p] >= 0x80;
+    if (high && raw_utf8) {
+        // a token straight from the caller's arena: white space and capitals outside ASCII are rewritten first (the line ingest
+        // has done that to the whole line already), into the line buffer, which the scored ingest does not use otherwise
+        const uint32_t m = utf8_prepare(t, s + i, j - i, ws.line, ws.cap_norm, false, true);   // tagger replies keep unknown tags (dropped list): always refuse
+        if (m == 0xFFFFFFFFu) { unsupported = true; return false; }
+        s = ws.line; i = 0; j = m;
+        while (i < j && is_ws8(s[i])) ++i;
+        while (j > i && is_ws8(s[j - 1])) --j;
+        if (i == j) return false;
     }
     while (i < j && is_quote8(s[i])) ++i;              // Trim('"', '\'', '`')
     while (j > i && is_quote8(s[j - 1])) --j;
     uint32_t tail = j;                                 // [;。、\.]+$
     if (final_nl_rule && j > i && s[j - 1] == '\n') {
-        uint32_t q = j - 1;
-        while (q > i && is_punct8(s[q - 1])) --q;
+        const uint32_t q = strip_tail_punct(s, i, j - 1);
         // the punctuation run before the final newline goes, the newline stays (and becomes '_')
         if (q < j - 1) {
             // normalise [i,q) followed by the newline: handled by hashing the two pieces in sequence below
@@ -380,11 +375,11 @@ TP_HD bool make_token(const DevTables& t, FileWs& ws, uint32_t& norm_used, const
         norm_used += n;
         return true;
     }
-    while (tail > i && is_punct8(s[tail - 1])) --tail;
+    tail = strip_tail_punct(s, i, tail);
     j = tail;
     // The usual token holds nothing the steps above and below change (no capital, white space, doubled underscore, and by now
     // no quote or punctuation at its ends): its bytes are the normalised string, looked up as four words in one probe.
-    if (j - i <= 32 && !is_quote8(s[i])) {
+    if (j - i <= 32 && !high && !is_quote8(s[i])) {              // (the word-wise tests below are for bytes under 0x80)
         const uint32_t n = j - i;
         uint64_t w[4], changed = 0, prev_us = 0;
         for (uint32_t k = 0; k < 4; ++k) {
@@ -448,7 +443,7 @@ TP_HD H norm_hop(const DevTables& t, const FileWs& ws, H h) {
     const uint8_t* p = ws.norm + h_off(h);
     uint32_t n = h_len(h);
     while (n > 0 && is_quote8(p[n - 1])) --n;
-    while (n > 0 && is_punct8(p[n - 1])) --n;
+    n = strip_tail_punct(p, 0, n);
     if (n == 0) return t.alias1[EMPTY_ID];
     Hasher hs;
     for (uint32_t k = 0; k < n; ++k) hs.add(p[k]);
@@ -521,8 +516,8 @@ TP_HD void trim_span(const uint8_t* s, uint32_t& a, uint32_t& b) {
     while (a < b && is_ws8(s[a])) ++a;
     while (b > a && is_ws8(s[b - 1])) --b;
 }
-// DropTagsContains (Program.cs:56-58) over a line whose '\n' count as ' ' (Program.cs:595); the U+2019 entry cannot
-// occur in ASCII input.
+// DropTagsContains (Program.cs:56-58) over a line whose '\n' count as ' ' (Program.cs:595); the entry with U+2019 is
+// matched on its UTF-8 bytes.
 TP_HD bool has_refusal_phrase(const uint8_t* s, uint32_t a, uint32_t b) {
     for (uint32_t p = a; p < b; ++p) {
         switch (lower8(s[p])) {
@@ -532,7 +527,8 @@ TP_HD bool has_refusal_phrase(const uint8_t* s, uint32_t a, uint32_t b) {
             case 'i':
                 if (p + 1 < b && (s[p + 1] == ' ' || s[p + 1] == '\n' || s[p + 1] == '\'')) {
                     if (match_ci(s, p, b, "i can't", 7, true) || match_ci(s, p, b, "i cannot", 8, true) ||
-                        match_ci(s, p, b, "i'm not able", 12, true) || match_ci(s, p, b, "i won't", 7, true)) return true;
+                        match_ci(s, p, b, "i'm not able", 12, true) || match_ci(s, p, b, "i won't", 7, true) ||
+                        match_ci(s, p, b, "i won\xE2\x80\x99t", 9, true)) return true;
                 }
                 break;
             case 'c': if (match_ci(s, p, b, "cannot provide", 14, true)) return true; break;
@@ -574,7 +570,8 @@ TP_HD bool has_refusal_phrase_nocolon(const uint8_t* s, uint32_t a, uint32_t b) 
             const uint32_t q = p + pl_low(sp);
             sp &= sp - 1;
             if (q <= a || !is_letter8(s[q - 1])) continue;
-            if (match_ci(s, q - 1, b, "i can't", 7, true) || match_ci(s, q - 1, b, "i cannot", 8, true) || match_ci(s, q - 1, b, "i won't", 7, true)) return true;
+            if (match_ci(s, q - 1, b, "i can't", 7, true) || match_ci(s, q - 1, b, "i cannot", 8, true) || match_ci(s, q - 1, b, "i won't", 7, true) ||
+                match_ci(s, q - 1, b, "i won\xE2\x80\x99t", 9, true)) return true;
             if (q >= a + 2 && match_ci(s, q - 2, b, "as an ai", 8, true)) return true;
             if (q >= a + 3 && match_ci(s, q - 3, b, "i'm not able", 12, true)) return true;
             if (q >= a + 6 && (match_ci(s, q - 6, b, "cannot provide", 14, true) || match_ci(s, q - 6, b, "unable to", 9, true))) return true;
@@ -620,7 +617,14 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
                 prev_cr = (cr >> 63) != 0;
             }
         }
-        if (has_crlf) {                                         // raw.Replace("\r\n", "\n")
+        if (has_high) {
+            // white space and capitals outside ASCII are rewritten once, here (and "\r\n" collapsed in the same pass): every
+            // step below then works on bytes, with ASCII white space only and nothing left for ToLowerInvariant to change
+            const uint32_t k = utf8_prepare(t, s, b, ws.line, ws.cap_norm, true, t.tables_hold_twins != 0);   // unknown tags outside ASCII are dropped here
+            if (k == 0xFFFFFFFFu) { v.flags = TP_F_UNSUPPORTED; return; }
+            s = ws.line;
+            b = k;
+        } else if (has_crlf) {                                  // raw.Replace("\r\n", "\n")
             uint32_t k = 0;
             for (uint32_t p = 0; p < b; ++p) {
                 if (s[p] == '\r' && p + 1 < b && s[p + 1] == '\n') continue;
@@ -674,10 +678,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             uint32_t commas = 0;
             for (uint32_t p = a; p < b; p += 8) commas += (uint32_t)__builtin_popcountll(pl_eq8(pl_ld8(s + p), ',') & pl_first(b - p));
             if (has_colon ? has_refusal_phrase(s, a, b) : has_refusal_phrase_nocolon(s, a, b)) rejected = true;
-            else if (commas < 2 && (b - a) > 40) {
-                if (has_high) unsupported = true;               // LooksBad counts UTF-16 units (Program.cs:1145), which are fewer than these bytes
-                else rejected = true;
-            }
+            else if (commas < 2 && (has_high ? utf16_units(s + a, b - a) : b - a) > 40) rejected = true;   // s.Length: UTF-16 units (Program.cs:1146)
         }
         if (!rejected) {
             // SplitTags -> NormalizeTag -> Length >= 2 -> !ShouldDropTag -> Distinct (Program.cs:598-602); the join and the second
@@ -735,7 +736,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
                 const uint8_t* s = in.arena + in.tag_offsets[k];
                 uint32_t len = (uint32_t)(in.tag_offsets[k + 1] - in.tag_offsets[k]);
                 H h;
-                bool nonempty = make_token(t, ws, norm_used, s, 0, len, true, h, unsupported);
+                bool nonempty = make_token(t, ws, norm_used, s, 0, len, true, h, unsupported, true);
                 if (unsupported) break;
                 if (!nonempty) h = t.alias1[EMPTY_ID];                // NormalizeTag("") still goes through the alias lookup
                 if (hflags(t, h) & FL_BLANK) continue;

@@ -1132,6 +1132,24 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         for (size_t b = 0; b < str.size() && b < 32; ++b) sl.key[b >> 2] |= (uint32_t)(unsigned char)str[b] << (8 * (b & 3));
         sl.rec = out.rec[sl.val];
     }
+    {   // what ToLowerInvariant does outside ASCII, for the kernels (DevTables::case_map)
+        std::map<wc, std::vector<wc>> by_capital;        // lower-case characters by the capital ordinal-ignore-case comparison folds them to
+        for (uint32_t c = 0; c < 0x10000; ++c) if (lower_invariant((wc)c) == (wc)c) by_capital[upper_ordinal((wc)c)].push_back((wc)c);
+        out.case_map.clear();
+        for (uint32_t c = 0x80; c < 0x10000; ++c) {
+            if (c >= 0xD800 && c <= 0xDFFF) continue;
+            const wc l = lower_invariant((wc)c);
+            if (l != (wc)c) out.case_map.push_back(c << 16 | l);
+        }
+        sc.n_case_map = (uint32_t)out.case_map.size();
+        std::vector<uint32_t> twins;
+        for (auto& kv : by_capital) if (kv.second.size() > 1) for (wc c : kv.second) if (c >= 0x80) twins.push_back(c);
+        std::sort(twins.begin(), twins.end());
+        sc.n_case_twin = (uint32_t)twins.size();
+        out.case_map.insert(out.case_map.end(), twins.begin(), twins.end());
+        sc.tables_hold_twins = 0;
+        for (const W& w : in.text) for (wc c : w) if (c >= 0x80 && std::binary_search(twins.begin(), twins.end(), (uint32_t)c)) sc.tables_hold_twins = 1;
+    }
     // ---- the lean stage's lookup table: two-choice placement (cuckoo insertion), at most 40 % full ----
     out.attr2.assign(2 * (size_t)N, 0);
     for (uint32_t i = 0; i < N; ++i) { out.attr2[2 * i] = out.flags[i]; out.attr2[2 * i + 1] = out.str_off[i + 1] - out.str_off[i]; }
@@ -1347,6 +1365,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.slots = ht.slots.data();
     t.lslots = ht.lslots.empty() ? nullptr : ht.lslots.data();
     t.attr2 = ht.attr2.data();
+    t.case_map = ht.case_map.data();
     t.crec = ht.crec.data();
     t.step_off = ht.step_off.data();
     t.step_ids = ht.step_ids.data();

@@ -32,6 +32,7 @@ struct HostTables {
     std::vector<Slot> slots;
     std::vector<LeanSlot> lslots;           // empty when the two-choice placement failed
     std::vector<uint32_t> attr2, crec;
+    std::vector<uint32_t> case_map;         // DevTables::case_map
     std::vector<uint8_t> basic_fixed;       // per id: the string is a fixed point of the normalisation before the alias lookup
     std::vector<HtInfo> ht_info;
     std::vector<uint64_t> str_words;

@@ -43,9 +43,13 @@ extern "C" {
 #define TP_F_FOOTJOB       0x04u  /* ... and the final tags have footjob, Program.cs:311 */
 #define TP_F_FALLBACK      0x08u  /* fewer than 3 selected tags: minimal fallback line used, Program.cs:297-298 */
 #define TP_F_LINE_REJECTED 0x10u  /* NormalizeRawTagLine returned "" (blank or LooksBad), Program.cs:590, 596 */
-#define TP_F_UNSUPPORTED   0x20u  /* input this build does not process: a tag with characters outside ASCII that is not, as written, a known string
-                                     that normalisation leaves alone (such tags need Unicode case mapping and white-space rules), or a per-file
-                                     list that outgrew its workspace; nothing is written for the file */
+#define TP_F_UNSUPPORTED   0x20u  /* input this build does not process; nothing is written for the file.  Text outside ASCII is processed (Trim,
+                                     \s and ToLowerInvariant over UTF-16 as in Program.cs:1150-1154, characters beyond the Basic Multilingual Plane
+                                     copied as they are); what is refused: text that is not well-formed UTF-8 (the reference would read U+FFFD
+                                     there); a lower-case character that shares its capital with another one (medial and final sigma, micro sign
+                                     and mu, ...) in a tagger reply, or in a line when some table string holds such a character, because the
+                                     reference's ordinal-ignore-case sets take two such spellings for one tag; a line that lower-casing makes
+                                     longer than its buffer (U+023A, U+023E); a per-file list that outgrew its workspace */
 #define TP_F_SAFE_REJECT   0x40u  /* DetectSafeModeRejectReason hit, Program.cs:329, 942-945 */
 #define TP_F_TRIAGE_BAD    0x80u  /* tp_triage_lines only: LooksBad(NormalizeRawTagLine(text)), Program.cs:206-207 */
 

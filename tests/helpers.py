@@ -111,7 +111,7 @@ class HostSim:
             raise RuntimeError(self._L.sim_last_error().decode())
         n = int(res.n_files)
         total = int(res.offsets[n]) if n else 0
-        caps = np.ctypeslib.as_array(res.captions, shape=(max(total, 1),))[:total].copy()
+        caps = np.ctypeslib.as_array(res.captions, shape=(total,)).copy() if total else np.zeros(0, np.uint8)
         offs = np.ctypeslib.as_array(res.offsets, shape=(n + 1,)).copy()
         ver = np.frombuffer(C.string_at(res.verdicts, 16 * n), dtype=VERDICT_DTYPE).copy() if n else np.zeros(0, VERDICT_DTYPE)
         ns, fw, nf = self.info.n_strings, self.info.fired_words, self.info.n_facets
@@ -360,38 +360,84 @@ EDGE_LINES = [
 ]
 
 
-# Tags outside ASCII: the wave-per-file kernel takes a token with such bytes when it is, as it stands, a known string that
-# normalisation leaves alone; everything else with such bytes is reported as unsupported.
-NON_ASCII_VOCAB = ["1girl", "solo", "smile", "dress", "caf\u00e9", "\u9752\u3044\u9aea", "pok\u00e9mon_(creature)", "long_hair", "\u00dcber_tag"]
+# Text outside ASCII.  The wave-per-file kernels take a token with such bytes when it is, as it stands, a known string that
+# normalisation leaves alone, and hand every other such file to the general kernel, which rewrites white space and capitals
+# outside ASCII first (Trim / \\s / ToLowerInvariant of Program.cs:1150-1154 over UTF-16) and then works on bytes.
+NON_ASCII_VOCAB = ["1girl", "solo", "smile", "dress", "caf\u00e9", "\u9752\u3044\u9aea", "pok\u00e9mon_(creature)", "long_hair", "\u00dcber_tag",
+                   "\u00fcber_tag", "\uff46\uff55\uff4c\uff4c", "na\u00efve_girl", "\U0001f600_face", "k_pop"]
 NON_ASCII_LINES = [
-    ("1girl, caf\u00e9, dress, smile", True),
-    ("1girl, \u9752\u3044\u9aea, pok\u00e9mon_(creature), long_hair, smile", True),
-    ("caf\u00e9,1girl,solo,\u9752\u3044\u9aea,dress", True),
-    ("1girl, CAF\u00c9, dress, smile", False),                 # upper case outside ASCII: lower-casing needed
-    ("1girl,\u3000caf\u00e9, dress, smile", False),           # U+3000 is white space to Trim()
-    ("1girl, caf\u00e9\u3002, dress, smile", False),           # trailing ideographic full stop is stripped
-    ("1girl, caf\u00e9 au lait, dress, smile", False),         # blank inside a token with bytes outside ASCII
-    ("1girl, \u00dcber_tag, dress, smile", False),             # in the vocabulary as written, but normalisation lower-cases it
-    ("1girl, smile, dress, unknown\u00e9", False),             # not a known string as it stands
+    "1girl, caf\u00e9, dress, smile",
+    "1girl, \u9752\u3044\u9aea, pok\u00e9mon_(creature), long_hair, smile",
+    "caf\u00e9,1girl,solo,\u9752\u3044\u9aea,dress",
+    "1girl, CAF\u00c9, dress, smile",                          # upper case outside ASCII: lower-casing needed
+    "1girl,\u3000caf\u00e9, dress, smile",                    # U+3000 is white space to Trim()
+    "1girl, caf\u00e9\u3002, dress, smile",                    # trailing ideographic full stop is stripped
+    "1girl, caf\u00e9\u3001\u3002.;\u3001, dress, smile",
+    "1girl, caf\u00e9 au lait, dress, smile",                  # blank inside a token with bytes outside ASCII
+    "1girl, \u00dcber_tag, dress, smile",                      # in the vocabulary as written, but normalisation lower-cases it
+    "1girl, smile, dress, unknown\u00e9",                      # not a known string as it stands
+    "1girl, \uff26\uff35\uff2c\uff2c, smile, dress",          # full-width capitals lower-case to a vocabulary entry
+    "1girl, NA\u00cfVE\u00a0GIRL, smile, dress",              # no-break space inside a token becomes '_'
+    "1girl, na\u00efve\u2003\u2003_\u3000girl, smile, dress",  # runs of white space and underscores collapse
+    "\u2028 1girl, smile\u2029, dress \u0085",                 # line and paragraph separators, NEL: white space to Trim()
+    "1girl, \U0001f600_face, \U0001f600 FACE, smile, dress",   # beyond the Basic Multilingual Plane: copied as it is
+    "1girl, \u212a_pop, smile, dress",                         # KELVIN SIGN lower-cases to an ASCII k
+    "1girl, \u9752, \u00e9, x\u00e9, smile, dress",            # one UTF-16 unit: shorter than two (Program.cs:600)
+    "smile, i won\u2019t do that, dress, 1girl",               # the refusal phrase with U+2019
+    "1girl, I WON\u2019T, dress, smile",
+    "i\u00a0can't, 1girl, dress, smile",                       # a no-break space is not the blank of the phrase
+    "caf\u00e9 " + "\u9752" * 38,                              # 44 UTF-16 units, under two commas: LooksBad
+    "caf\u00e9 " + "\u9752" * 35,                              # 40 units (110 bytes): not too long
+    "\U0001f600" * 20 + "," + "\u9752",                       # 42 units (20 pairs + 2), one comma: LooksBad
+    "\U0001f600" * 19 + "," + "\u9752",                       # 40 units
+    "```\u3000\n1girl, caf\u00e9, smile, dress\n```\u3000",
+    "POSITIVE:\u3000caf\u00e9, 1girl, smile, dress\nNEGATIVE: \u9752",
+    "caf\u00e9,\r\n1girl,\r\nsmile, dress\r\n",
+    "1girl, \u00b5m, smile, dress, \u0131x, \u017fx, \u0130x",   # characters whose case mappings are special
+    "1girl, \u03c3\u03c2, \u03a3\u03a3, smile, dress",           # medial and final sigma share their capital (no table string holds either here)
 ]
+# what stays unsupported (TP_F_UNSUPPORTED, empty caption): malformed UTF-8
+NON_ASCII_UNSUPPORTED = [b"1girl, caf\xe9, smile, dress", b"1girl, \xc0\xaf, smile", b"1girl, \xed\xa0\x80x, smile", b"1girl, \xf4\x90\x80\x80, smile",
+                         b"1girl, smile, \xe9\x9d"]
+# ... and, when some table string holds one, lower-case characters that share their capital with another lower-case character
+# (medial and final sigma, the micro sign and mu): ordinal-ignore-case comparison takes two such strings for one, byte comparison does not
+TWIN_VOCAB = NON_ASCII_VOCAB + ["\u03c3\u03b9\u03b3\u03bc\u03b1"]
+TWIN_LINES = [("1girl, \u03c3\u03b9\u03b3\u03bc\u03b1, smile, dress", True), ("1girl, \u03a3\u03b9\u03b3\u03bc\u03b1, smile", True), ("1girl, \u00b5m, smile", True),
+              ("1girl, caf\u00e9, smile, dress", False), ("1girl, \u03b1\u03b3, smile, dress", False)]
 
 
-def non_ascii_config():
+def non_ascii_config(**kw):
     vocab = ("\n".join(NON_ASCII_VOCAB) + "\n").encode("utf-8")
-    return shipped_config(vocabulary=vocab, vocabulary_is_json=0)
+    return shipped_config(vocabulary=vocab, vocabulary_is_json=0, **kw)
 
 
-def check_non_ascii(run_fast, oracle):
-    """run_fast(texts) -> result of the implementation's GPU flow; oracle: Oracle for non_ascii_config()."""
-    texts = [t for t, _ in NON_ASCII_LINES]
-    got, want = run_fast(texts), oracle.run_texts(texts)
-    for i, (text, taken) in enumerate(NON_ASCII_LINES):
-        if taken:
-            assert got.caption(i) == want.caption(i) and got.caption(i) != b"", (text, got.caption(i), want.caption(i))
-            assert got.verdicts[i].tobytes() == want.verdicts[i].tobytes(), text
-        else:
-            assert got.verdicts["flags"][i] & 0x20 and got.caption(i) == b"", text
-    assert got.counters["unsupported"] == sum(1 for _, taken in NON_ASCII_LINES if not taken)
+def check_non_ascii(run, oracle, histogram_dict):
+    """run(arena, offsets) -> result of the implementation's flow; oracle: Oracle for the same configuration."""
+    a, o = pack_lines(NON_ASCII_LINES)
+    got, want = run(a, o), oracle.run_lines(a, o)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, histogram_dict(got.histogram), "text outside ASCII")
+    assert sum(1 for i in range(len(NON_ASCII_LINES)) if want.caption(i) and (want.verdicts["flags"][i] & 0x10) == 0) >= 20   # most lines are captioned, not rejected
+    blobs = [x for x in NON_ASCII_UNSUPPORTED]
+    offs = np.zeros(len(blobs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in blobs])
+    got = run(np.frombuffer(b"".join(blobs), dtype=np.uint8).copy(), offs)
+    assert got.counters["unsupported"] == len(blobs)
+    assert all(got.caption(i) == b"" and got.verdicts["flags"][i] & 0x20 for i in range(len(blobs)))
+
+
+def check_case_twins(make_engine):
+    """With a table string that holds a sigma, lines with characters of that kind are reported, not guessed; others are taken."""
+    cfg = shipped_config(vocabulary=("\n".join(TWIN_VOCAB) + "\n").encode("utf-8"), vocabulary_is_json=0)
+    eng, o = make_engine(cfg), Oracle(cfg)
+    texts = [t for t, _ in TWIN_LINES]
+    got, want = eng.run_texts(texts), o.run_texts(texts)
+    assert got.verdicts["flags"][1] & 0x20 and got.verdicts["flags"][2] & 0x20
+    for i, (text, refused) in enumerate(TWIN_LINES):
+        if refused and (got.verdicts["flags"][i] & 0x20):
+            assert got.caption(i) == b"", text
+        else:        # (the wave kernels take the table string itself when it is spelled exactly as the table spells it)
+            assert got.caption(i) == want.caption(i) and got.verdicts[i].tobytes() == want.verdicts[i].tobytes(), text
 
 
 def triage_lines(seed, n):

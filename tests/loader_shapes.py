@@ -66,7 +66,7 @@ VOCABULARY_JSON = _j({
 
 _SHAPE_LINES = [
     "1girl, solo, Bare Foot, smile, dress",
-    "1girl, overwritten, grin, eye contact, staring",
+    "1girl, overwritten, grin, ＦＵＬＬ, eye contact, staring",
     "1girl, gown, frock, not_an_array, skipped, blush",
     "1girl, footjob, feet, penis, toes, solejob, two-footed footjob",
     "1girl, pedal play, handjob, hand, penis, 2girls, double handjob",

@@ -217,23 +217,24 @@ def test_oracle_review_row_known_answer():
     assert res.review_jsonl == [b""] and res.review_csv == [b""]
 
 
-def test_general_kernel_takes_known_non_ascii_tags():
-    """Audit mode runs every file through the thread-per-file code: it takes a tag with characters outside ASCII under the same
-    condition as the wave kernels (a known string, as written, that normalisation leaves alone) and reports the rest as unsupported."""
-    from helpers import NON_ASCII_LINES, check_non_ascii, check_review_facts, non_ascii_config
+def test_general_kernel_takes_text_outside_ascii():
+    """Audit mode runs every file through the thread-per-file code, which carries the Unicode half of NormalizeTag
+    (Program.cs:1150-1154): the audit lists of such lines match the oracle's too."""
+    from helpers import NON_ASCII_LINES, assert_same_results, check_non_ascii, check_review_facts, non_ascii_config
     cfg = non_ascii_config()
     sim, orc = HostSim(cfg), Oracle(cfg)
-    check_non_ascii(sim.run_texts, orc)
-    texts = [t for t, taken in NON_ASCII_LINES if taken]
-    arena, offsets = pack_lines(texts)
-    want = orc.run_lines(arena, offsets, detail=True, audit=review_args(len(texts)))
+    check_non_ascii(sim.run_lines, orc, sim.histogram_dict)
+    arena, offsets = pack_lines(NON_ASCII_LINES)
+    want = orc.run_lines(arena, offsets, detail=True, audit=review_args(len(NON_ASCII_LINES)))
     lists, ver = sim.run_audit(arena, offsets)
     assert [l[:3] for l in lists] == oracle_audit_lists(want)
     check_review_facts(lists, sim.review_bits, ver, want)
-    # a line of one long tag: LooksBad counts UTF-16 units, fewer than the bytes (Program.cs:1145): left alone
+    # a line of one long tag: LooksBad counts UTF-16 units, fewer than the bytes (Program.cs:1146)
     long_one = "青" * 20
-    got = HostSim(shipped_config(vocabulary=(long_one + "\n").encode("utf-8"), vocabulary_is_json=0)).run_texts([long_one, "1girl, smile, dress"])
-    assert got.verdicts["flags"][0] & 0x20 and not got.verdicts["flags"][1] & 0x20
+    cfg = shipped_config(vocabulary=(long_one + "\n").encode("utf-8"), vocabulary_is_json=0)
+    got, want = HostSim(cfg).run_texts([long_one, "1girl, smile, dress", long_one * 3]), Oracle(cfg).run_texts([long_one, "1girl, smile, dress", long_one * 3])
+    assert_same_results(got, want, HostSim(cfg).histogram_dict(got.histogram), "long tag outside ASCII")
+    assert not (got.verdicts["flags"] & 0x20).any() and (got.verdicts["flags"][2] & 0x10)
 
 
 def test_multi_person_digits_are_unicode_digits():
@@ -256,3 +257,39 @@ def test_multi_person_digits_are_unicode_digits():
     check_review_facts(lists, sim.review_bits, ver, want)
     assert "multi_person" in json.loads(want.review_jsonl[0])["Reasons"] and "multi_person" not in json.loads(want.review_jsonl[1])["Reasons"]
     assert lists[0][2] == (tag + ":invalid_tag").encode("utf-8")
+
+
+def unicode_reply_tags():
+    """Tagger-reply tags with characters outside ASCII that are in no table: the scored ingest keeps them as candidates
+    (Program.cs:473-487), SelectTags drops them as invalid, and the audit row's dropped list spells them as NormalizeTag left them."""
+    files = [
+        ["1girl", "CAFÉ AU　LAIT", "smile", "２Girls", "dress", "café au lait。", "long_hair"],
+        ["ÜBER TAG", "1girl", "٣boys.", "smile", "dress", "\U0001f600 Face", "Kelvin", "x、"],
+        ["smile", "　", "  ", "dress", "1girl", "青", "青い"],
+    ]
+    tags = [t for f in files for t in f]
+    arena, toffs = pack_lines(tags)
+    begin = np.cumsum([0] + [len(f) for f in files]).astype(np.uint64)
+    scores = np.array([round(0.95 - 0.03 * (i % 9), 2) for i in range(len(tags))])
+    return arena, toffs, begin, scores, np.zeros(len(tags), np.uint8)
+
+
+def test_tagger_reply_tags_outside_ascii():
+    from helpers import assert_same_results, check_review_facts, non_ascii_config
+    cfg = non_ascii_config()
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    arena, toffs, begin, scores, src = unicode_reply_tags()
+    want = orc.run_scored(arena, toffs, begin, scores, src, detail=True, audit=review_args(len(begin) - 1))
+    got = sim.run_scored(arena, toffs, begin, scores, src)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, sim.histogram_dict(got.histogram), "reply tags outside ASCII")
+    got = sim.run_scored_fast(arena, toffs, begin, scores, src)
+    assert_same_results(got, want, sim.histogram_dict(got.histogram), "reply tags outside ASCII, wave kernel first")
+    lists, ver = sim.run_audit(arena, toffs, tag_begin=begin, scores=scores, sources=src)
+    assert [l[:3] for l in lists] == oracle_audit_lists(want)
+    check_review_facts(lists, sim.review_bits, ver, want)
+    assert "café_au_lait:invalid_tag".encode("utf-8") in lists[0][2] and "２girls:invalid_tag".encode("utf-8") in lists[0][2]
+    # a character that shares its capital with another one: two such spellings would be one candidate to the reference
+    arena, toffs = pack_lines(["1girl", "µm", "smile"])
+    r = sim.run_scored(arena, toffs, np.array([0, 3], dtype=np.uint64), np.array([0.9, 0.8, 0.7]), np.zeros(3, np.uint8))
+    assert r.verdicts["flags"][0] & 0x20

@@ -238,18 +238,17 @@ def test_review_rows(name):
         assert any(b"male_subject_token" in x for x in got.review_jsonl)
 
 
-def test_audit_mode_takes_known_non_ascii_tags():
-    """Audit mode (thread-per-file kernel) takes what the wave kernels take of tags with characters outside ASCII, and the JSON line
-    escapes them the way System.Text.Json does."""
+def test_audit_mode_takes_text_outside_ascii():
+    """Audit mode (thread-per-file kernel) on lines with characters outside ASCII; the JSON line escapes them the way
+    System.Text.Json does."""
     from helpers import NON_ASCII_LINES
     cfg = non_ascii_config()
     p, o = pipe_for(cfg), Oracle(cfg)
-    texts = [t for t, _ in NON_ASCII_LINES]
+    texts = list(NON_ASCII_LINES)
     audit = _review_args(len(texts))
     audit["image_paths"] = ["/data/\u9752 %d.png" % i for i in range(len(texts))]
     got, want = p.run_texts(texts, audit=audit), o.run_texts(texts, detail=True, audit=audit)
-    for i, (text, taken) in enumerate(NON_ASCII_LINES):
-        assert bool(got.verdicts["flags"][i] & 0x20) == (not taken), text
+    assert not (got.verdicts["flags"] & 0x20).any()
     _check_audit(got, want)
     _check_review(got, want)
     assert any(b"\\u9752" in x for x in got.review_jsonl)
@@ -349,11 +348,13 @@ def test_empty_and_ragged_batches():
         assert_same_results(got, want, p.histogram_dict(got.histogram), "ragged")
 
 
-def test_non_ascii_is_reported_not_guessed():
-    p = pipe_for(shipped_config())
-    r = p.run_texts(["1girl, smile, dress", "1girl, café, dress", "1girl, 青い髪"])
-    assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
-    assert r.caption(1) == b"" and r.caption(2) == b"" and r.counters["unsupported"] == 2
+def test_text_outside_ascii_with_the_shipped_tables():
+    cfg = shipped_config()
+    lines = ["1girl, smile, dress", "1girl, caf\u00e9, dress", "1girl, \u9752\u3044\u9aea"]
+    p = pipe_for(cfg)
+    got, want = p.run_texts(lines), Oracle(cfg).run_texts(lines)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "shipped tables")
 
 
 def test_long_files():
@@ -395,9 +396,16 @@ def test_multi_line_texts():
     assert_same_results(got, want, p.histogram_dict(got.histogram), "carriage returns")
 
 
-def test_known_non_ascii_tags_pass_through_the_wave_kernel():
-    cfg = non_ascii_config()
-    check_non_ascii(pipe_for(cfg).run_texts, Oracle(cfg))
+@pytest.mark.parametrize("strict", [True, False])
+def test_text_outside_ascii(strict):
+    """The Unicode half of NormalizeTag (Trim and \\s over Unicode white space, the ideographic stops, ToLowerInvariant;
+    Program.cs:1150-1154) on the device: no such line is unsupported, and all equal the oracle's."""
+    cfg = non_ascii_config() if strict else non_ascii_config(strict_known=False, strict_known_explicit=True)
+    p = pipe_for(cfg)
+    check_non_ascii(p.run_lines, Oracle(cfg), p.histogram_dict)
+    if strict:
+        from helpers import check_case_twins
+        check_case_twins(pipe_for)
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
@@ -576,3 +584,20 @@ def test_unusual_finite_scores():
     p = pipe_for(cfg)
     got, want = p.run_scored(*args), Oracle(cfg).run_scored(*args)
     assert_same_results(got, want, p.histogram_dict(got.histogram), "finite scores")
+
+
+def test_tagger_reply_tags_outside_ascii():
+    """Scored ingest keeps unknown tags with characters outside ASCII as candidates; the dropped list spells them as NormalizeTag
+    leaves them (Program.cs:1150-1154, 630-631)."""
+    from test_audit_cpu import unicode_reply_tags
+    cfg = non_ascii_config()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    arena, toffs, begin, scores, src = unicode_reply_tags()
+    audit = _review_args(len(begin) - 1)
+    got = p.run_scored(arena, toffs, begin, scores, src, audit=audit)
+    want = o.run_scored(arena, toffs, begin, scores, src, detail=True, audit=audit)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "reply tags outside ASCII")
+    _check_audit(got, want)
+    _check_review(got, want)
+    assert "caf\u00e9_au_lait:invalid_tag".encode("utf-8") in got.audit_lists[0][2]

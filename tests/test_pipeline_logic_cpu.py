@@ -10,7 +10,7 @@ import random
 import numpy as np
 import pytest
 
-from helpers import DATA, EDGE_LINES, Config, HostSim, Oracle, assert_same_results, check_non_ascii, non_ascii_config, shipped_config
+from helpers import DATA, EDGE_LINES, NON_ASCII_LINES, Config, HostSim, Oracle, assert_same_results, check_non_ascii, non_ascii_config, shipped_config
 from imagecaptioner_amd.corpus import make_corpus
 
 CONFIGS = {
@@ -121,13 +121,21 @@ def test_scored_ingest(name):
     assert_same_results(got, want, s.histogram_dict(got.histogram), name + " scored")
 
 
-def test_non_ascii_is_reported_not_guessed():
-    cfg = shipped_config()
+@pytest.mark.parametrize("strict", [True, False])
+def test_text_outside_ascii(strict):
+    """The Unicode half of NormalizeTag (Program.cs:1150-1154) in the thread-per-file pipeline."""
+    cfg = non_ascii_config() if strict else non_ascii_config(strict_known=False, strict_known_explicit=True)
     s = HostSim(cfg)
-    r = s.run_texts(["1girl, smile, dress", "1girl, café, dress", "1girl, 青い髪"])
-    assert list(r.verdicts["flags"] & 0x20) == [0, 0x20, 0x20]
-    assert r.caption(1) == b"" and r.caption(2) == b""
-    assert r.counters["unsupported"] == 2
+    check_non_ascii(s.run_lines, Oracle(cfg), s.histogram_dict)
+    cfg = shipped_config()
+    lines = ["1girl, smile, dress", "1girl, café, dress", "1girl, 青い髪"]
+    s = HostSim(cfg)
+    got, want = s.run_texts(lines), Oracle(cfg).run_texts(lines)
+    assert got.counters["unsupported"] == 0
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "shipped tables")
+    if strict:
+        from helpers import check_case_twins
+        check_case_twins(HostSim)
 
 
 def long_lines(seed, count):
@@ -161,9 +169,15 @@ def test_long_files_take_the_long_wave_stage(name):
         assert got.n_general < len(lines) // 2      # most of them fit the long-file stage
 
 
-def test_known_non_ascii_tags_pass_through_the_wave_kernel():
+def test_text_outside_ascii_through_the_wave_stages():
+    """A token with bytes outside ASCII that is a known string as it stands stays in the wave kernels; every other such file is
+    handed to the thread-per-file pipeline, none is reported as unsupported."""
     cfg = non_ascii_config()
-    check_non_ascii(HostSim(cfg).run_texts_fast, Oracle(cfg))
+    s = HostSim(cfg)
+    check_non_ascii(s.run_lines_fast, Oracle(cfg), s.histogram_dict)
+    check_non_ascii(s.run_lines_lean, Oracle(cfg), s.histogram_dict)
+    got = s.run_texts_fast(NON_ASCII_LINES[:3])
+    assert got.n_general == 0
 
 
 # ---- the wave-per-file kernel body (tp_fast.h) on an emulated wavefront ---------------------------------------------
