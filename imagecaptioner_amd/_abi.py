@@ -144,6 +144,15 @@ class tp_timing(C.Structure):
                 ("other_ms", C.c_float), ("general_files", C.c_uint64), ("lean_front_ms", C.c_float), ("lean_back_ms", C.c_float)]
 
 
+class tp_replies(C.Structure):
+    _fields_ = [("n_files", C.c_uint64), ("n_tags", C.c_uint64), ("arena", C.POINTER(C.c_uint8)), ("tag_offsets", C.POINTER(C.c_uint64)),
+                ("tag_begin", C.POINTER(C.c_uint64)), ("secondary_begin", C.POINTER(C.c_uint64)), ("scores", C.POINTER(C.c_double)),
+                ("sources", C.POINTER(C.c_uint8)), ("status", C.POINTER(C.c_uint8)), ("has_score", C.POINTER(C.c_uint8)), ("opaque", C.c_void_p)]
+
+
+TP_REPLY_OK, TP_REPLY_NO_TAGS, TP_REPLY_ORDER, TP_REPLY_FAILED = 0, 1, 2, 3
+
+
 class Config:
     """Keyword-style builder for tp_config that keeps the backing buffers alive.
 

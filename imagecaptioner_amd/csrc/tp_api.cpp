@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tagpipe.h"
@@ -96,6 +97,7 @@ struct tp_ctx {
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
     DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets, out_review_bits;
+    std::unordered_map<std::string, uint32_t> string_ids;   // text of every interned string -> id (made on first use by tp_decode_joytag_replies)
     bool audit = false;              // tp_set_audit: the host-pointer runs also return the audit row's tag lists
     std::vector<hipEvent_t> events;
     tp_timing timing{};
@@ -736,6 +738,64 @@ int tp_run_scored(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets
     }
     if (tag_offsets[n_tags] && !arena) return fail(TP_E_INVALID_ARG, "null argument");
     return guarded([&]() { return run_host(ctx, arena, tag_offsets[n_tags], tag_offsets, n_tags + 1, tag_begin, scores, sources, n_tags, n_files, out); });
+}
+
+namespace {
+struct HostReplies {
+    DecodedReplies d;
+    std::vector<uint64_t> tag_begin, secondary_begin;
+    std::vector<uint8_t> sources, status, has_score;
+};
+}  // namespace
+
+int tp_decode_joytag_replies(tp_ctx* ctx, const uint8_t* primary, const uint64_t* primary_offsets, const uint8_t* secondary,
+                             const uint64_t* secondary_offsets, uint64_t n_files, tp_replies* out) {
+    if (!ctx || !out || !primary_offsets || (secondary_offsets && !secondary && n_files && secondary_offsets[n_files]) ||
+        (n_files && primary_offsets[n_files] && !primary))
+        return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_files; ++i)
+        if (primary_offsets[i + 1] < primary_offsets[i] || (secondary_offsets && secondary_offsets[i + 1] < secondary_offsets[i]))
+            return fail(TP_E_INVALID_ARG, "offsets must be non-decreasing");
+    return guarded([&]() {
+        if (ctx->string_ids.empty()) ctx->string_ids = index_strings(ctx->ht);
+        std::unique_ptr<HostReplies> r(new HostReplies());
+        r->tag_begin.assign(1, 0);
+        r->status.assign(n_files, 0);
+        r->has_score.assign(n_files, 0);
+        for (uint64_t i = 0; i < n_files; ++i) {
+            uint8_t st = 0, hs = 0;
+            decode_joytag_reply(ctx->ht, ctx->string_ids, primary + primary_offsets[i], (size_t)(primary_offsets[i + 1] - primary_offsets[i]), r->d, st, hs);
+            r->sources.resize(r->d.scores.size(), (uint8_t)TP_SRC_PRIMARY_JOY);
+            r->status[i] = st;
+            r->has_score[i] = hs;
+            if (secondary_offsets) {
+                r->secondary_begin.push_back(r->d.scores.size());
+                decode_joytag_reply(ctx->ht, ctx->string_ids, secondary + secondary_offsets[i], (size_t)(secondary_offsets[i + 1] - secondary_offsets[i]), r->d, st, hs);
+                r->sources.resize(r->d.scores.size(), (uint8_t)TP_SRC_SECONDARY_JOY);
+                r->status[i] = std::max(r->status[i], st);
+                r->has_score[i] |= (uint8_t)(hs << 1);
+            }
+            r->tag_begin.push_back(r->d.scores.size());
+        }
+        if (r->d.arena.empty()) r->d.arena.push_back(0);          // never a null pointer, also without tags
+        if (r->d.scores.empty()) { r->d.scores.push_back(0.0); r->sources.push_back(0); }
+        out->n_files = n_files;
+        out->n_tags = r->tag_begin.back();
+        out->arena = r->d.arena.data();
+        out->tag_offsets = r->d.tag_offsets.data();
+        out->tag_begin = r->tag_begin.data();
+        out->secondary_begin = secondary_offsets ? (r->secondary_begin.empty() ? r->tag_begin.data() : r->secondary_begin.data()) : nullptr;
+        out->scores = r->d.scores.data();
+        out->sources = r->sources.data();
+        out->status = r->status.data();
+        out->has_score = r->has_score.data();
+        out->opaque = r.release();
+        return TP_OK;
+    });
+}
+
+void tp_release_replies(tp_replies* replies) {
+    if (replies && replies->opaque) { delete (HostReplies*)replies->opaque; std::memset(replies, 0, sizeof *replies); }
 }
 
 void tp_release(tp_ctx* ctx, tp_result* res) {

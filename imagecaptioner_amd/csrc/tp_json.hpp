@@ -25,7 +25,7 @@ struct JNode {
     int32_t first = -1;   // first child (Array: item, Object: member)
     int32_t next = -1;    // next sibling
     int32_t name = -1;    // index into JDoc::text of the member name (Object children only)
-    int32_t value = -1;   // index into JDoc::text for String
+    int32_t value = -1;   // index into JDoc::text for String, and for Number (its characters as written)
 };
 
 class JDoc {
@@ -89,7 +89,7 @@ private:
             case 't': c.expect_word("true"); return add(JKind::Bool);
             case 'f': c.expect_word("false"); return add(JKind::Bool);
             case 'n': c.expect_word("null"); return add(JKind::Null);
-            default: number(c); return add(JKind::Number);
+            default: { const size_t from = c.pos; number(c); int32_t n = add(JKind::Number); std::u16string lit; for (size_t k = from; k < c.pos; ++k) lit.push_back((char16_t)c.p[k]); int32_t tix = add_text(std::move(lit)); nodes[n].value = tix; return n; }
         }
     }
     int32_t object(Cursor& c, int depth) {

@@ -1339,6 +1339,70 @@ std::string top_tags_text(const HostTables& h, const uint64_t* histogram) {
     return text;
 }
 
+std::unordered_map<std::string, uint32_t> index_strings(const HostTables& ht) {
+    std::unordered_map<std::string, uint32_t> m;
+    m.reserve(ht.strings.size() * 2);
+    for (uint32_t i = 0; i < (uint32_t)ht.strings.size(); ++i) m.emplace(ht.strings[i], i);
+    return m;
+}
+
+void decode_joytag_reply(const HostTables& ht, const std::unordered_map<std::string, uint32_t>& string_ids, const uint8_t* json, size_t len,
+                         DecodedReplies& out, uint8_t& status, uint8_t& has_score) {
+    status = TP_REPLY_OK;
+    has_score = 0;
+    struct Item { W tag; double score; };
+    std::vector<Item> items;
+    try {
+        JDoc d = JDoc::parse(json, len);
+        const int32_t tags = d.member(d.root, u"tags");                       // TryGetProperty throws unless the root is an object
+        if (tags < 0 || d.kind(tags) != JKind::Array) { status = TP_REPLY_NO_TAGS; return; }
+        // NormalizeTag(tag) is blank?  Only tags that are not blank take an Order (Program.cs:470, 484), and a string element's
+        // score falls with that Order.
+        auto blank = [&](const W& raw) {
+            const W nb = normalize_basic(raw);
+            auto it = string_ids.find(to_utf8(nb));
+            if (it == string_ids.end()) return nb.empty();                     // in no table: no alias applies, and white space has become '_'
+            return (ht.flags[ht.alias1[it->second]] & FL_BLANK) != 0;
+        };
+        auto number = [&](int32_t n, double& v) {                              // JsonElement.TryGetDouble: throws unless the element is a number
+            if (d.kind(n) != JKind::Number) throw JsonFail("a JSON number was expected");
+            v = std::strtod(to_utf8(d.str(n)).c_str(), nullptr);
+            return true;
+        };
+        int order = 0;
+        for (int32_t e = d.nodes[tags].first; e >= 0; e = d.nodes[e].next) {
+            if (d.kind(e) == JKind::String) {
+                const W& raw = d.str(e);
+                if (!blank(raw)) { items.push_back(Item{raw, std::max(0.01, 1.0 - order * 0.001)}); ++order; }
+                continue;
+            }
+            if (d.kind(e) != JKind::Object) continue;
+            W tag;
+            int32_t m = d.member(e, u"tag");
+            if (m >= 0 && d.kind(m) == JKind::String) tag = d.str(m);
+            else if ((m = d.member(e, u"name")) >= 0 && d.kind(m) == JKind::String) tag = d.str(m);
+            double score = 0.5;
+            if ((m = d.member(e, u"score")) >= 0 && number(m, score)) has_score = 1;
+            else if ((m = d.member(e, u"confidence")) >= 0 && number(m, score)) has_score = 1;
+            if (!blank(tag)) { items.push_back(Item{tag, score}); ++order; }
+        }
+    } catch (const JsonFail&) {
+        status = TP_REPLY_FAILED;
+        has_score = 0;
+        return;
+    }
+    // With HasScore the list is sorted by (score descending, order) (Program.cs:487), which is what the scored ingest does with any
+    // list.  Without it the list stays as it is: that is the same thing only when the scores do not rise along it.
+    if (!has_score)
+        for (size_t k = 1; k < items.size(); ++k) if (items[k].score > items[k - 1].score) { status = TP_REPLY_ORDER; return; }
+    for (const Item& it : items) {
+        const std::string b = to_utf8(it.tag);
+        out.arena.insert(out.arena.end(), b.begin(), b.end());
+        out.tag_offsets.push_back(out.arena.size());
+        out.scores.push_back(it.score);
+    }
+}
+
 DevTables bind_host_pointers(const HostTables& ht) {
     DevTables t = ht.scalars;
     t.str_bytes = ht.str_bytes.data();

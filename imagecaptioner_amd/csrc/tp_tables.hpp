@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tagpipe.h"
@@ -63,6 +64,18 @@ bool less_ordinal_ignore_case(const std::string& a, const std::string& b);
 // The corpus-wide tag table as a file LoadKnownTagDictionary reads (one tag per line, Program.cs:1021-1028): tags with a
 // non-zero count, by count descending, then by the tag's bytes ascending.  `histogram` has one count per interned string.
 std::string top_tags_text(const HostTables& ht, const uint64_t* histogram);
+
+// Cached tagger replies (the JSON bodies of JoyTag's /tag endpoint) as the arrays tp_run_scored / tp_run_merged take:
+// the "tags" lookup of CallJoyTagAsync and ParseJoyTags (Program.cs:463-489, 500-505).  One call appends one reply.
+struct DecodedReplies {
+    std::vector<uint8_t> arena;             // the tags' texts as the reply spells them, back to back
+    std::vector<uint64_t> tag_offsets{0};   // into arena, one more than tags
+    std::vector<double> scores;
+};
+// status (TP_REPLY_*), has_score: ParseJoyTags' HasScore.  A reply that fails or whose order cannot be kept appends nothing.
+void decode_joytag_reply(const HostTables& ht, const std::unordered_map<std::string, uint32_t>& string_ids, const uint8_t* json, size_t len,
+                         DecodedReplies& out, uint8_t& status, uint8_t& has_score);
+std::unordered_map<std::string, uint32_t> index_strings(const HostTables& ht);
 
 // A DevTables whose pointers address the HostTables vectors themselves (host-side logic checks).
 DevTables bind_host_pointers(const HostTables& ht);

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from ._abi import (TP_E_CAPACITY, TP_OK, VERDICT_DTYPE, Config, tp_audit, tp_config, tp_counters, tp_device_io, tp_result, tp_table_info,
+from ._abi import (tp_replies, TP_E_CAPACITY, TP_OK, VERDICT_DTYPE, Config, tp_audit, tp_config, tp_counters, tp_device_io, tp_result, tp_table_info,
                    tp_timing)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,7 +20,7 @@ EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_run_lines_device_noalloc", "tp_format_top_tags", "tp_get_last_timing",
     "tp_triage_lines", "tp_run_merged", "tp_format_fired_rules", "tp_needtag_text", "tp_format_side_files",
-    "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows", "tp_review_csv_header", "tp_format_review_rows",
+    "tp_decode_joytag_replies", "tp_release_replies", "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows", "tp_review_csv_header", "tp_format_review_rows",
 )
 
 
@@ -61,6 +61,9 @@ def load_library():
     L.tp_run_lines_device_noalloc.argtypes = [C.c_void_p, C.POINTER(tp_device_io), C.POINTER(C.c_uint64)]
     L.tp_format_top_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tp_get_last_timing.argtypes = [C.c_void_p, C.POINTER(tp_timing)]
+    L.tp_decode_joytag_replies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(tp_replies)]
+    L.tp_release_replies.argtypes = [C.POINTER(tp_replies)]
+    L.tp_release_replies.restype = None
     L.tp_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(tp_result)]
     L.tp_format_fired_rules.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     L.tp_needtag_text.restype = C.c_char_p
@@ -377,6 +380,36 @@ class TagPipe:
         finally:
             self._L.tp_set_audit(self._h, 0)
         return self._collect(res, audit)
+
+    # ---- cached tagger replies ---------------------------------------------------------------------
+    def decode_joytag_replies(self, primary, secondary=None):
+        """tp_decode_joytag_replies: lists of JSON reply bodies (bytes) -> dict of the arrays run_scored / run_merged take
+        (arena, tag_offsets, tag_begin, secondary_begin or None, scores, sources) plus status and has_score per file."""
+        def pack(blobs):
+            offs = np.zeros(len(blobs) + 1, dtype=np.uint64)
+            if blobs:
+                offs[1:] = np.cumsum([len(b) for b in blobs])
+            data = np.frombuffer(b"".join(blobs), dtype=np.uint8).copy() if offs[-1] else np.zeros(1, np.uint8)
+            return data, offs
+        n = len(primary)
+        pa, po = pack(list(primary))
+        sa, so = pack(list(secondary)) if secondary is not None else (None, None)
+        if secondary is not None and len(secondary) != n:
+            raise ValueError("one secondary reply per primary reply")
+        r = tp_replies()
+        self._check(self._L.tp_decode_joytag_replies(self._h, pa.ctypes.data, po.ctypes.data, sa.ctypes.data if sa is not None else None,
+                                                     so.ctypes.data if so is not None else None, n, C.byref(r)))
+        try:
+            nt = int(r.n_tags)
+            grab = lambda ptr, count, dt: np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True) if count else np.zeros(0, dt)
+            offs = grab(r.tag_offsets, nt + 1, np.uint64)
+            out = {"arena": grab(r.arena, int(offs[-1]), np.uint8), "tag_offsets": offs, "tag_begin": grab(r.tag_begin, n + 1, np.uint64),
+                   "secondary_begin": grab(r.secondary_begin, n, np.uint64) if secondary is not None else None,
+                   "scores": grab(r.scores, nt, np.float64), "sources": grab(r.sources, nt, np.uint8),
+                   "status": grab(r.status, n, np.uint8), "has_score": grab(r.has_score, n, np.uint8)}
+        finally:
+            self._L.tp_release_replies(C.byref(r))
+        return out
 
     # ---- device-resident run ---------------------------------------------------------------------
     def run_lines_device(self, io: tp_device_io, noalloc=False):

@@ -229,6 +229,39 @@ int tp_run_merged(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets
 void tp_release(tp_ctx* ctx, tp_result* res);
 
 /*
+ * Cached tagger replies into the arrays tp_run_scored / tp_run_merged take: the JSON bodies JoyTag's /tag endpoint
+ * returned for every file (CallJoyTagAsync's "tags" lookup and ParseJoyTags, Program.cs:463-489, 500-505).  File i's
+ * primary reply is primary[primary_offsets[i] .. primary_offsets[i + 1]) (UTF-8 JSON); secondary / secondary_offsets hold
+ * the second call's replies (Program.cs:219) or are NULL.  Out: the tags' texts as the replies spell them (the run normalises
+ * them), tag_offsets, tag_begin and - with secondary replies - secondary_begin in tp_run_merged's layout, scores (a string
+ * element's score is max(0.01, 1.0 - order * 0.001), an object's its "score", else "confidence", else 0.5; "tag" else "name"),
+ * sources (TP_SRC_PRIMARY_JOY / TP_SRC_SECONDARY_JOY by reply).  Tags that NormalizeTag makes blank are left out, as
+ * ParseJoyTags leaves them out (they take no Order).  status[i] is the worse of the file's replies:
+ */
+#define TP_REPLY_OK       0
+#define TP_REPLY_NO_TAGS  1  /* well-formed JSON without a "tags" array: an empty list, as in the reference (Program.cs:502-503) */
+#define TP_REPLY_ORDER    2  /* no element carries a score, and the default scores rise somewhere along the list (string and score-less
+                                object elements mixed): ParseJoyTags keeps such a list unsorted (Program.cs:487), the scored ingest would
+                                sort it; the reply is returned empty and is the caller's to handle */
+#define TP_REPLY_FAILED   3  /* the reference throws on it (JSON that does not parse, a root that is not an object, a "score" or
+                                "confidence" that is not a number): the image fails there; returned empty */
+typedef struct tp_replies {
+    uint64_t n_files, n_tags;
+    const uint8_t*  arena;
+    const uint64_t* tag_offsets;      /* n_tags + 1 */
+    const uint64_t* tag_begin;        /* n_files + 1 */
+    const uint64_t* secondary_begin;  /* n_files, NULL without secondary replies */
+    const double*   scores;           /* n_tags */
+    const uint8_t*  sources;          /* n_tags */
+    const uint8_t*  status;           /* n_files, TP_REPLY_* */
+    const uint8_t*  has_score;        /* n_files: bit 0 the primary reply's HasScore, bit 1 the secondary's (Program.cs:463) */
+    void* opaque;
+} tp_replies;
+int tp_decode_joytag_replies(tp_ctx* ctx, const uint8_t* primary, const uint64_t* primary_offsets, const uint8_t* secondary,
+                             const uint64_t* secondary_offsets, uint64_t n_files, tp_replies* out);
+void tp_release_replies(tp_replies* replies);
+
+/*
  * Device-resident variant of tp_run_lines for callers that already hold the
  * corpus in HBM (and for benchmarking the kernels without PCIe): every pointer
  * is a device pointer on the context's device; the caller provides the output

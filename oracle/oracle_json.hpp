@@ -121,7 +121,7 @@ private:
         if (c == 't') { if (!lit("true")) fail("bad literal"); v.kind = JV::True; return v; }
         if (c == 'f') { if (!lit("false")) fail("bad literal"); v.kind = JV::False; return v; }
         if (c == 'n') { if (!lit("null")) fail("bad literal"); v.kind = JV::Null; return v; }
-        if (c == '-' || (c >= '0' && c <= '9')) { parse_number(); v.kind = JV::Number; return v; }
+        if (c == '-' || (c >= '0' && c <= '9')) { const size_t from = i_; parse_number(); v.kind = JV::Number; for (size_t k = from; k < i_; ++k) v.str.push_back((char16_t)p_[k]); return v; }
         fail("unexpected character");
     }
     void parse_number() {

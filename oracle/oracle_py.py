@@ -258,6 +258,26 @@ class Oracle:
             raise OracleError(self._L.orc_last_error().decode("utf-8", "replace"))
         return self._collect(res, n, detail, audit)
 
+    def run_replies(self, primary, secondary=None, secondary_cap=15, threads=1, detail=False, audit=None):
+        """Cached tagger reply bodies (lists of bytes), one or two per file: CallJoyTagAsync from the body on, ParseJoyTags, the
+        merge of Program.cs:214-221 when there are two, then the pipeline.  The result also carries .reply_status per file:
+        0 parsed, 1 no "tags" array, 3 the reference throws on the reply."""
+        pa, po = pack_lines(primary)
+        n = len(po) - 1
+        sa, so = pack_lines(secondary) if secondary is not None else (None, None)
+        status = np.zeros(max(n, 1), dtype=np.uint8)
+        res = orc_result()
+        self._L.orc_run_replies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
+                                            C.POINTER(orc_result)]
+        rc = self._L.orc_run_replies(self._h, pa.ctypes.data if pa.size else None, po.ctypes.data, sa.ctypes.data if sa is not None and sa.size else None,
+                                     so.ctypes.data if so is not None else None, int(secondary_cap), n, threads, int(detail or audit is not None),
+                                     status.ctypes.data, C.byref(res))
+        if rc != 0:
+            raise OracleError(self._L.orc_last_error().decode("utf-8", "replace"))
+        out = self._collect(res, n, detail, audit)
+        out.reply_status = status[:n]
+        return out
+
     def run_texts(self, texts, **kw):
         arena, offsets = pack_lines(texts)
         return self.run_lines(arena, offsets, **kw)

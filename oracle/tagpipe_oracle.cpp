@@ -1285,7 +1285,10 @@ static thread_local std::string g_err;
 // secondaryBegin != nullptr: tags [tagBegin[i], secondaryBegin[i]) are the primary tagger reply, [secondaryBegin[i], tagBegin[i+1]) the
 // secondary one, merged as Program.cs:214-221 does (sources is not read then).
 struct ScoredInput { const uint8_t* arena; const uint64_t* tagOffsets; const uint64_t* tagBegin; const double* scores; const uint8_t* sources;
-                     const uint64_t* secondaryBegin; int secondaryCap; };
+                     const uint64_t* secondaryBegin; int secondaryCap;
+                     // or the tagger's reply bodies themselves: replyOffsets != nullptr (secondary ones when secondaryReplyOffsets != nullptr)
+                     const uint8_t* replies = nullptr; const uint64_t* replyOffsets = nullptr;
+                     const uint8_t* secondaryReplies = nullptr; const uint64_t* secondaryReplyOffsets = nullptr; uint8_t* replyStatus = nullptr; };
 
 static void run_batch(const Ctx& cx, const uint8_t* arena, const uint64_t* offsets, const ScoredInput* scored, uint64_t n, bool wantDetail, int threads,
                       Batch& b, tp_counters& ctr) {
@@ -1304,6 +1307,58 @@ static void run_batch(const Ctx& cx, const uint8_t* arena, const uint64_t* offse
             if (!scored) {
                 S raw = utf8_to_16(arena + offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
                 cands = e.ParseTagCandidatesFromLine(raw, nullptr, e.lineWeight, e.lineSource, &rejected);
+            } else if (scored->replyOffsets) {
+                // CallJoyTagAsync from the reply body on (Program.cs:500-505) and ParseJoyTags (Program.cs:463-489).
+                // status: 0 parsed, 1 no "tags" array (empty list), 3 the reference throws (the image fails; an empty list here)
+                uint8_t status = 0;
+                auto reply = [&](const uint8_t* p, size_t len, int source) {
+                    std::vector<Candidate> list;
+                    try {
+                        JsonParser jp(p, len);
+                        JV doc = jp.parse_document();
+                        const JV* tagsEl = doc.get("tags");
+                        if (!tagsEl || tagsEl->kind != JV::Array) { status = std::max<uint8_t>(status, 1); return list; }
+                        bool hasScore = false;
+                        int order = 0;
+                        auto number = [](const JV& v) {                 // TryGetDouble: InvalidOperationException unless a number
+                            if (v.kind != JV::Number) throw JsonError("TryGetDouble on an element that is not a number");
+                            return std::strtod(to8(v.str).c_str(), nullptr);
+                        };
+                        for (const JV& t : tagsEl->arr) {
+                            if (t.kind == JV::String) {
+                                S sn = e.NormalizeTag(t.str);
+                                if (!is_blank(sn)) { list.push_back(Candidate{sn, std::max(0.01, 1.0 - order * 0.001), order, source}); ++order; }
+                                continue;
+                            }
+                            if (t.kind != JV::Object) continue;
+                            S tag;
+                            const JV* el;
+                            if ((el = t.get("tag")) && el->kind == JV::String) tag = el->str;
+                            else if ((el = t.get("name")) && el->kind == JV::String) tag = el->str;
+                            double score = 0.5;
+                            if ((el = t.get("score"))) { score = number(*el); hasScore = true; }
+                            else if ((el = t.get("confidence"))) { score = number(*el); hasScore = true; }
+                            S nn = e.NormalizeTag(tag);
+                            if (!is_blank(nn)) { list.push_back(Candidate{nn, score, order, source}); ++order; }
+                        }
+                        if (hasScore)
+                            std::stable_sort(list.begin(), list.end(), [](const Candidate& a, const Candidate& c) { return a.score != c.score ? a.score > c.score : a.order < c.order; });
+                    } catch (const JsonError&) {
+                        status = 3;
+                        list.clear();
+                    }
+                    return list;
+                };
+                std::vector<Candidate> primary = reply(scored->replies + scored->replyOffsets[i], (size_t)(scored->replyOffsets[i + 1] - scored->replyOffsets[i]),
+                                                       TP_SRC_PRIMARY_JOY);
+                if (!scored->secondaryReplyOffsets) cands = primary;
+                else {
+                    std::vector<Candidate> secondary = reply(scored->secondaryReplies + scored->secondaryReplyOffsets[i],
+                                                             (size_t)(scored->secondaryReplyOffsets[i + 1] - scored->secondaryReplyOffsets[i]), TP_SRC_SECONDARY_JOY);
+                    cands = Engine::MergeCandidateTags(primary, Engine::LimitSecondaryTags(primary, secondary, scored->secondaryCap));
+                }
+                if (status == 3) cands.clear();
+                if (scored->replyStatus) scored->replyStatus[i] = status;
             } else {
                 // ParseJoyTags, object-shaped entries (Program.cs:473-487)
                 auto parse = [&](uint64_t lo, uint64_t hi, int fixedSource) {
@@ -1469,6 +1524,21 @@ int orc_run_merged(void* ctx, const uint8_t* arena, const uint64_t* tag_offsets,
         std::unique_ptr<Batch> b(new Batch());
         tp_counters ctr;
         ScoredInput si{arena, tag_offsets, tag_begin, scores, nullptr, secondary_begin, secondary_cap};
+        run_batch(*cx, nullptr, nullptr, &si, n, detail != 0, threads, *b, ctr);
+        return finish(b.release(), n, ctr, out);
+    } catch (const std::exception& ex) { g_err = ex.what(); return TP_E_INVALID_ARG; }
+}
+
+// Cached tagger replies (JSON bodies), one or two per file: status receives 0 / 1 / 3 per file (see run_batch).
+int orc_run_replies(void* ctx, const uint8_t* primary, const uint64_t* primary_offsets, const uint8_t* secondary, const uint64_t* secondary_offsets,
+                    int secondary_cap, uint64_t n, int threads, int detail, uint8_t* status, orc_result* out) {
+    try {
+        Ctx* cx = (Ctx*)ctx;
+        if (!cx || !out || !primary_offsets) { g_err = "invalid argument"; return TP_E_INVALID_ARG; }
+        std::unique_ptr<Batch> b(new Batch());
+        tp_counters ctr;
+        ScoredInput si{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, secondary_cap};
+        si.replies = primary; si.replyOffsets = primary_offsets; si.secondaryReplies = secondary; si.secondaryReplyOffsets = secondary_offsets; si.replyStatus = status;
         run_batch(*cx, nullptr, nullptr, &si, n, detail != 0, threads, *b, ctr);
         return finish(b.release(), n, ctr, out);
     } catch (const std::exception& ex) { g_err = ex.what(); return TP_E_INVALID_ARG; }

@@ -96,6 +96,39 @@ class HostSim:
         nz = np.nonzero(np.asarray(histogram)[:len(s)])[0]
         return {s[int(i)]: int(histogram[int(i)]) for i in nz}
 
+    def decode_joytag_replies(self, primary, secondary=None):
+        """The library's reply decoder on the host build, in TagPipe.decode_joytag_replies' output form."""
+        self._L.sim_decode_reply.restype = C.c_int64
+        self._L.sim_decode_reply.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        n = len(primary)
+        arena, offs, scores, sources, begin, mid = [], [0], [], [], [0], []
+        status, has = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+
+        def one(blob, source):
+            blob = bytes(blob)
+            cap = len(blob) + 16
+            a, o, sc = np.zeros(cap, np.uint8), np.zeros(cap + 1, np.uint64), np.zeros(cap, np.float64)
+            st, hs = C.c_uint8(), C.c_uint8()
+            k = self._L.sim_decode_reply(self._h, blob, len(blob), a.ctypes.data, cap, o.ctypes.data, sc.ctypes.data, cap, C.byref(st), C.byref(hs))
+            assert k >= 0
+            base = offs[-1]
+            arena.append(a[:int(o[k])].copy())
+            offs.extend(int(x) + base for x in o[1:k + 1])
+            scores.extend(sc[:k])
+            sources.extend([source] * k)
+            return st.value, hs.value
+        for i in range(n):
+            status[i], has[i] = one(primary[i], 0)
+            if secondary is not None:
+                mid.append(len(scores))
+                st, hs = one(secondary[i], 1)
+                status[i] = max(status[i], st)
+                has[i] |= hs << 1
+            begin.append(len(scores))
+        return {"arena": np.concatenate(arena) if arena else np.zeros(0, np.uint8), "tag_offsets": np.array(offs, dtype=np.uint64),
+                "tag_begin": np.array(begin, dtype=np.uint64), "secondary_begin": np.array(mid, dtype=np.uint64) if secondary is not None else None,
+                "scores": np.array(scores, dtype=np.float64), "sources": np.array(sources, dtype=np.uint8), "status": status, "has_score": has}
+
     def format_top_tags(self, histogram):
         hist = np.ascontiguousarray(histogram, dtype=np.uint64)
         assert len(hist) >= self.info.n_strings
@@ -504,3 +537,81 @@ def check_top_tags_file(make_engine):
     got, want = eng2.run_lines(c.arena, c.offsets), o.run_lines(c.arena, c.offsets)
     assert_same_results(got, want, eng2.histogram_dict(got.histogram), "written top_tags as vocabulary")
     assert set(eng2.histogram_dict(got.histogram)) <= set(lines)               # strict vocabulary: nothing new appears
+
+
+# ---- cached tagger replies (the JSON bodies of JoyTag's /tag endpoint) -----------------------------------------------------
+def joytag_replies(seed, n):
+    """(primary, secondary) reply bodies in the shapes ParseJoyTags takes (Program.cs:463-489): objects with tag / name and
+    score / confidence, bare strings, elements of other kinds, blank and aliased tags, escapes, and bodies without a tags array."""
+    import json
+    import random
+    rng = random.Random(seed)
+    vocab = [l.strip() for l in open(os.path.join(DATA, "top_tags.txt"), encoding="utf-8") if l.strip()][:500]
+    extra = ["foot", "fingers", "Pedal Stimulation", "zz_unknown", "x'.", "", " ", "a", "Long Hair", "BLUE EYES", "caf\u00e9", "\u9752\u3044\u9aea", "licking", "soles"]
+
+    def body(kind):
+        k = rng.choice([0, 1, 3, 8, 25, 60])
+        tags = [rng.choice(vocab + extra) for _ in range(k)]
+        if kind == "objects":
+            els = []
+            for t in tags:
+                e = {}
+                e[rng.choice(["tag", "tag", "name"])] = t
+                r = rng.random()
+                if r < 0.7: e["score"] = round(rng.random(), 3)
+                elif r < 0.9: e["confidence"] = rng.choice([0.28, 0.6, 0.5, 0.53, 1, 0, 1e-3, 12.5, -0.25])
+                if rng.random() < 0.1: e["tag"] = rng.choice([None, 5, ["x"]]); e["name"] = t
+                if rng.random() < 0.05: e["score"], e["confidence"] = round(rng.random(), 2), 0.99
+                els.append(e)
+            return {"tags": els}
+        if kind == "strings":
+            return {"tags": tags, "model": "joytag"}
+        if kind == "objects_no_score":
+            return {"tags": [{"tag": t} for t in tags]}
+        if kind == "mixed_kinds":
+            els = [{"tag": t, "score": round(rng.random(), 2)} for t in tags]
+            for junk in (None, 5, True, [1, 2], {}, {"score": 0.9}, {"name": "smile", "confidence": 0.75}):
+                els.insert(rng.randint(0, len(els)), junk)
+            return {"tags": els}
+        if kind == "many_strings":
+            return {"tags": [rng.choice(vocab) for _ in range(1100)]}          # past order 990 the score stays 0.01
+        if kind == "no_tags":
+            return rng.choice([{}, {"tags": None}, {"tags": "smile"}, {"result": ["smile"]}, {"tags": {"tag": "smile"}}])
+        raise ValueError(kind)
+    kinds = ["objects"] * 6 + ["strings"] * 3 + ["objects_no_score", "mixed_kinds", "no_tags"]
+    prim, sec = [], []
+    for i in range(n):
+        prim.append(json.dumps(body("many_strings" if i == 5 else rng.choice(kinds)), ensure_ascii=rng.random() < 0.5).encode("utf-8"))
+        sec.append(json.dumps(body(rng.choice(kinds)), ensure_ascii=rng.random() < 0.5).encode("utf-8"))
+    prim[0] = b'\xef\xbb\xbf {"tags": [ {"tag": "smile", "score": 9e-1}, {"name": "Long\\u0020Hair", "confidence": 1E0}, "dress" ] } '
+    return prim, sec
+
+
+# bodies the reference throws on, and one whose order the scored ingest cannot keep
+BAD_REPLIES = [(b"", 3), (b"not json", 3), (b'["smile"]', 3), (b'{"tags": [{"tag": "smile", "score": "0.9"}]}', 3), (b'{"tags": [{"tag": "smile", "score": null}]}', 3),
+               (b'{"tags": [{"tag": "smile", "confidence": [1]}]}', 3), (b'{"tags": ["smile",]}', 3), (b'{"tags": ["smile"]} x', 3),
+               (b'{"tags": ["smile", {"tag": "dress"}, "long_hair"]}', 2), (b'{"tags": [{"tag": "dress"}, "smile"]}', 2),
+               (b'{"tags": ["smile", {"tag": "dress"}]}', 0), (b'{"tags": [{"tag": "dress", "score": 0.5, "score": "x"}]}', 3)]
+
+
+def check_joytag_replies(engine, oracle):
+    """engine.decode_joytag_replies + run_scored / run_merged against the oracle's own reading of the same bodies."""
+    prim, sec = joytag_replies(17, 120)
+    d = engine.decode_joytag_replies(prim)
+    want = oracle.run_replies(prim)
+    assert list(d["status"]) == list(want.reply_status) and set(d["status"]) == {0, 1}
+    assert d["secondary_begin"] is None and (d["sources"] == 0).all()
+    got = engine.run_scored(d["arena"], d["tag_offsets"], d["tag_begin"], d["scores"], d["sources"])
+    assert_same_results(got, want, engine.histogram_dict(got.histogram), "decoded replies")
+    assert d["has_score"][0] == 1 and bytes(d["arena"][:int(d["tag_offsets"][3])]) == b"smileLong Hairdress" and list(d["scores"][:3]) == [0.9, 1.0, 0.998]
+    for cap in (15, 2, 0):
+        d = engine.decode_joytag_replies(prim, sec)
+        want = oracle.run_replies(prim, sec, secondary_cap=cap)
+        assert list(d["status"]) == list(want.reply_status)
+        got = engine.run_merged(d["arena"], d["tag_offsets"], d["tag_begin"], d["secondary_begin"], d["scores"], cap)
+        assert_same_results(got, want, engine.histogram_dict(got.histogram), "decoded replies, merged, cap %d" % cap)
+    d = engine.decode_joytag_replies([b for b, _ in BAD_REPLIES])
+    assert list(d["status"]) == [st for _, st in BAD_REPLIES]
+    want = oracle.run_replies([b for b, _ in BAD_REPLIES])
+    assert [int(x) for x in want.reply_status] == [st if st != 2 else 0 for _, st in BAD_REPLIES]
+    assert all(d["tag_begin"][i + 1] == d["tag_begin"][i] for i, (_, st) in enumerate(BAD_REPLIES) if st)

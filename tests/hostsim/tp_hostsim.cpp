@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tagpipe.h"
@@ -143,6 +144,23 @@ uint64_t sim_format_top_tags(void* h, const uint64_t* histogram, uint8_t* out, u
     const std::string text = top_tags_text(((Sim*)h)->ht, histogram);
     if (out && capacity) std::memcpy(out, text.data(), std::min<uint64_t>(capacity, text.size()));
     return text.size();
+}
+
+// One tagger reply through the library's decoder (decode_joytag_reply).  Returns the number of tags, or -1 when a buffer is too
+// small; arena / offsets (tags + 1) / scores are the caller's.
+int64_t sim_decode_reply(void* h, const uint8_t* json, uint64_t len, uint8_t* arena, uint64_t arena_cap, uint64_t* offsets, double* scores, uint64_t tag_cap,
+                         uint8_t* status, uint8_t* has_score) {
+    Sim& s = *(Sim*)h;
+    static thread_local const Sim* indexed = nullptr;
+    static thread_local std::unordered_map<std::string, uint32_t> ids;
+    if (indexed != &s) { ids = index_strings(s.ht); indexed = &s; }
+    DecodedReplies d;
+    decode_joytag_reply(s.ht, ids, json, (size_t)len, d, *status, *has_score);
+    if (d.arena.size() > arena_cap || d.scores.size() > tag_cap) return -1;
+    if (!d.arena.empty()) std::memcpy(arena, d.arena.data(), d.arena.size());
+    std::memcpy(offsets, d.tag_offsets.data(), d.tag_offsets.size() * 8);
+    if (!d.scores.empty()) std::memcpy(scores, d.scores.data(), d.scores.size() * 8);
+    return (int64_t)d.scores.size();
 }
 
 const char* sim_string(void* h, uint32_t id) { return ((Sim*)h)->ht.strings[id].c_str(); }

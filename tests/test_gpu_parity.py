@@ -601,3 +601,11 @@ def test_tagger_reply_tags_outside_ascii():
     _check_audit(got, want)
     _check_review(got, want)
     assert "caf\u00e9_au_lait:invalid_tag".encode("utf-8") in got.audit_lists[0][2]
+
+
+def test_cached_tagger_replies_decode_like_parse_joy_tags():
+    """tp_decode_joytag_replies through the C ABI, its arrays through tp_run_scored / tp_run_merged, against the oracle reading
+    the same JSON bodies (CallJoyTagAsync from the body on and ParseJoyTags, Program.cs:463-489, 500-505)."""
+    from helpers import check_joytag_replies
+    cfg = shipped_config()
+    check_joytag_replies(pipe_for(cfg), Oracle(cfg))

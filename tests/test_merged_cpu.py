@@ -202,3 +202,10 @@ def test_wave_kernel_counts_tags_in_no_table():
         want, got = o.run_merged(arena, offs, begin, mid, scores, cap), s.run_scored_fast(arena, offs, begin, scores, None, mid, cap)
         assert_same_results(got, want, s.histogram_dict(got.histogram), "tags in no table, merged cap %d" % cap)
         assert got.n_general < 30, got.n_general
+
+
+def test_cached_tagger_replies_decode_like_parse_joy_tags():
+    """tp_decode_joytag_replies' decoder (host build) and the scored / merged runs against the oracle reading the same JSON bodies."""
+    from helpers import HostSim, Oracle, check_joytag_replies, shipped_config
+    for cfg in (shipped_config(), shipped_config(strict_known=False, strict_known_explicit=True, lexicon=b'{"aliases": {"": "smile", "zz_unknown": " "}}')):
+        check_joytag_replies(HostSim(cfg), Oracle(cfg))
