@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, cpu count)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--cpu-single-sample", type=int, default=20_000, help="files timed on ONE host thread; 0 = skip")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (RCCL) is the measured configuration; gloo (sums on the host) is for rehearsals")
+    ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (RCCL refuses two ranks on one GPU: use --backend gloo)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -58,11 +60,16 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py rank %d of %d needs a GPU: the tag pipeline has no CPU path" % (rank, world))
+    if args.one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from imagecaptioner_amd import Config, TagPipe
     from imagecaptioner_amd._abi import tp_device_io
@@ -98,9 +105,14 @@ def main():
         hist.zero_()
         counters.zero_()
         nbytes = pipe.run_lines_device(io)
-        if world > 1:
+        if world > 1 and args.backend == "nccl":
             dist.all_reduce(hist)        # RCCL sum over xGMI: the corpus-wide tag histogram
             dist.all_reduce(counters)
+        elif world > 1:                  # rehearsal: the same sums through host memory
+            for t in (hist, counters):
+                h = t.cpu()
+                dist.all_reduce(h)
+                t.copy_(h)
         return nbytes
 
     for _ in range(args.warmup):
@@ -122,9 +134,15 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank counted its own files into the summed histogram: the sum over ranks of the files' tag counts
+        tags = torch.tensor([int(np.frombuffer(verdicts.cpu().numpy().tobytes(), dtype=np.uint16)[1::8].astype(np.int64).sum())], dtype=torch.int64,
+                            device=t.device)
+        dist.all_reduce(tags)
+        if int(hist.sum().item()) != int(tags.item()):
+            raise SystemExit("bench.py: the all-reduced histogram does not add up to the ranks' tag counts")
 
     # ---- correctness spot check outside the timed region: device result == oracle on a prefix ----
     check_n = min(n, 2000)
@@ -185,7 +203,7 @@ def main():
                    "files_per_gpu": n, "input_bytes_per_file": in_bytes / n, "caption_bytes_per_file": cap_bytes / n,
                    "kernel_ms": kernel_ms,
                    "files_in_general_kernel": int(gen_files),
-                   "parallelism": "files sharded by rank; histogram all-reduce (RCCL)" if world > 1 else "single GPU",
+                   "parallelism": ("files sharded by rank; histogram all-reduce (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal")) if world > 1 else "single GPU",
                    "corpus_gen_s": gen_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": step_ms,

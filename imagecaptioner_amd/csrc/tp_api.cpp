@@ -606,6 +606,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.slots = upload(c->table_mem, h.slots);
         d.lslots = h.lslots.empty() ? nullptr : upload(c->table_mem, h.lslots);
         d.attr2 = upload(c->table_mem, h.attr2);
+        d.emit_rec = upload(c->table_mem, h.emit_rec);
         d.case_map = upload(c->table_mem, h.case_map);
         d.crec = upload(c->table_mem, h.crec);
         d.step_off = upload(c->table_mem, h.step_off);

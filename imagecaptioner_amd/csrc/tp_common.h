@@ -321,6 +321,8 @@ struct DevTables {
     uint32_t n_case_map;         //   ASCII that it changes; then n_case_twin lower-case characters, sorted, that share their capital with another
     uint32_t n_case_twin;        //   lower-case character (ordinal-ignore-case comparison takes the two for one, byte comparison does not)
     uint32_t tables_hold_twins;  // some table string holds such a character
+    const uint32_t* emit_rec;    // per id, four words, for the caption writer: a string of up to 15 bytes itself (zero-padded) with its length in byte 15;
+                                 //   a longer one as {offset into str_bytes, byte length, 0, 0xFF << 24}
     const uint32_t* attr2;       // per id: flags, byte length (two words)
     const uint32_t* crec;        // per id, eight words: flags, byte length, Rec::lit, min(step count, 3), step0, step1, s0_info, s1_info
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
     EmitCounts cnt;
 
     struct Meta { uint32_t nfin, total, slot, fl; uint64_t out0; uint32_t id[2]; };
-    struct Strs { uint32_t off[2], len[2]; };
+    struct Strs { uint4 rec[2]; };                                     // DevTables::emit_rec of the lane's two tags
     auto load_meta = [&](uint64_t f, Meta& m) {
         m.nfin = 0; m.total = 0; m.slot = 0; m.fl = 0; m.out0 = 0; m.id[0] = m.id[1] = 0;
         if (f >= a.file_end) return;
@@ -640,12 +640,11 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         m.id[1] = i1 < t.n_strings ? i1 : 0;
     };
     auto load_strs = [&](const Meta& m, Strs& q) {
-        for (int blk = 0; blk < 2; ++blk) {                         // str_off[id], str_off[id + 1] in one 8-byte load
-            uint32_t oo[2];
-            __builtin_memcpy(oo, t.str_off + m.id[blk], 8);
-            q.off[blk] = oo[0];
-            q.len[blk] = oo[1] - oo[0];
-        }
+#ifdef EMIT_X_NOGATHER
+        for (int blk = 0; blk < 2; ++blk) q.rec[blk] = make_uint4(m.id[blk], m.id[blk], 7, 12u << 24);
+#else
+        for (int blk = 0; blk < 2; ++blk) q.rec[blk] = *(const uint4*)(t.emit_rec + 4 * (size_t)m.id[blk]);   // most strings whole, in one 16-byte load
+#endif
     };
     Meta m0, m1, m2;
     Strs q0, q1;
@@ -666,7 +665,7 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         for (int blk = 0; blk < 2; ++blk) {
             const uint32_t k = (uint32_t)blk * 64 + lane;
             const bool live = k < nfin;
-            len[blk] = live ? q0.len[blk] : 0;
+            len[blk] = live ? ((q0.rec[blk].w >> 24) == 0xFFu ? q0.rec[blk].y : q0.rec[blk].w >> 24) : 0;
             seg[blk] = len[blk] + ((live && k + 1 < nfin) ? 2u : 0u);
             incl[blk] = (blk == 0 || nfin > 64) ? wave_scan_incl(seg[blk]) : 0;
         }
@@ -674,12 +673,17 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         for (int blk = 0; blk < 2; ++blk) {
             if (blk == 1 && nfin <= 64) break;
             uint8_t* dst = stage + head + (blk ? tot0 : 0) + incl[blk] - seg[blk];
-            const uint8_t* sp = t.str_bytes + q0.off[blk];
+            const uint4 er = q0.rec[blk];
+            const bool in_rec = (er.w >> 24) != 0xFFu;                // up to 15 bytes: the record holds them
+            const uint8_t* sp = t.str_bytes + (in_rec ? 0u : er.x);
             const uint32_t n = len[blk];
-            // the first 32 bytes are fetched at once (the string arena has slack behind its end), stored exactly
+            // a longer string's first 32 bytes are fetched at once (the string arena has slack behind its end); stored exactly
             uint64_t v[4];
-            __builtin_memcpy(&v[0], sp, 16);
-            __builtin_memcpy(&v[2], sp + 16, 16);
+            v[0] = er.x | (uint64_t)er.y << 32; v[1] = er.z | (uint64_t)(er.w & 0xFFFFFFu) << 32; v[2] = 0; v[3] = 0;
+            if (!in_rec && n) {
+                __builtin_memcpy(&v[0], sp, 16);
+                __builtin_memcpy(&v[2], sp + 16, 16);
+            }
             const uint32_t n32 = n < 32 ? n : 32, nfull = n32 >> 3;
             for (uint32_t k = 0; k < 4; ++k)
                 if (k < nfull) __builtin_memcpy(dst + 8 * k, &v[k], 8);
@@ -699,6 +703,9 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint8_t* gbase = a.captions + out0 - head;                    // 16-byte aligned
         const uint32_t end = head + total, nchunks = (end + 15) >> 4;
+#ifdef EMIT_X_NOSTORE
+        if (total == 0xFFFFFFFFu)
+#endif
         for (uint32_t c = lane; c < nchunks; c += 64) {
             if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
         }

@@ -1151,6 +1151,17 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         for (const W& w : in.text) for (wc c : w) if (c >= 0x80 && std::binary_search(twins.begin(), twins.end(), (uint32_t)c)) sc.tables_hold_twins = 1;
     }
     // ---- the lean stage's lookup table: two-choice placement (cuckoo insertion), at most 40 % full ----
+    out.emit_rec.assign(4 * (size_t)N + 4, 0);
+    for (uint32_t i = 0; i < N; ++i) {
+        const std::string& str = out.strings[i];
+        uint32_t* r = &out.emit_rec[4 * (size_t)i];
+        if (str.size() <= 15) {
+            uint8_t b[16] = {0};
+            std::memcpy(b, str.data(), str.size());
+            b[15] = (uint8_t)str.size();
+            std::memcpy(r, b, 16);
+        } else { r[0] = out.str_off[i]; r[1] = (uint32_t)str.size(); r[2] = 0; r[3] = 0xFFu << 24; }
+    }
     out.attr2.assign(2 * (size_t)N, 0);
     for (uint32_t i = 0; i < N; ++i) { out.attr2[2 * i] = out.flags[i]; out.attr2[2 * i + 1] = out.str_off[i + 1] - out.str_off[i]; }
     out.crec.assign(8 * (size_t)N, 0);
@@ -1429,6 +1440,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.slots = ht.slots.data();
     t.lslots = ht.lslots.empty() ? nullptr : ht.lslots.data();
     t.attr2 = ht.attr2.data();
+    t.emit_rec = ht.emit_rec.data();
     t.case_map = ht.case_map.data();
     t.crec = ht.crec.data();
     t.step_off = ht.step_off.data();

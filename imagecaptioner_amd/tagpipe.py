@@ -41,6 +41,13 @@ def load_library():
     path = os.environ.get("TAGPIPE_LIBRARY") or LIB_PATH     # the override is for diagnostic builds of the same library
     if not os.path.exists(path):
         raise TagPipeError(-3, "HIP extension not built: %s is missing (run `python -m imagecaptioner_amd.build`)" % path)
+    try:
+        # PyTorch ships its own copy of the HIP runtime.  A process that also uses torch on the GPU must end up with one runtime,
+        # not two: with torch's libraries loaded first, this library binds to the same ones.  (Loaded the other way round, torch
+        # later reports that no GPU is available.)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     L.tp_config_init.argtypes = [C.POINTER(tp_config)]
     L.tp_config_init.restype = None

@@ -609,3 +609,17 @@ def test_cached_tagger_replies_decode_like_parse_joy_tags():
     from helpers import check_joytag_replies
     cfg = shipped_config()
     check_joytag_replies(pipe_for(cfg), Oracle(cfg))
+
+
+def test_bench_two_ranks_share_this_gpu():
+    """`bench.py --gpus 2` as its own launcher, both ranks on the one GPU of this box, sums through gloo (RCCL refuses two ranks on
+    one GPU): the ranks' shards go through tp_run_lines_device, the summed histogram adds up, and rank 0 prints the line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-gpu", "--files", "30000", "--steps", "2",
+                        "--warmup", "1", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["files_per_gpu"] == 30000 and line["value"] > 0 and line["scaling"] == "weak"
