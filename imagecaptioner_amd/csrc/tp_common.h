@@ -232,15 +232,15 @@ struct HtInfo { uint32_t val, woff, slen, pad; };   // woff: first 8-byte word o
 
 // One slot of the lean stage's lookup table (tp_lean.h), one cache line: a string of at most 32 bytes that the normalisation
 // before the alias lookup leaves alone (key) -> what the stage needs of the string NormalizeTag makes of it (val).  Every key
-// sits in one of the two slots its hash names (lean_slots()), so a lookup is one round of two independent loads.
+// sits in one of the two slots its hash names (lean_slots()), so a lookup is two independent 16-byte loads, then the payload
+// of the slot whose first half matched (and the second half of a long key).
 struct alignas(64) LeanSlot {
-    uint32_t key[8];     // the key's bytes, zero padded
+    uint32_t key_lo[4];  // the key's first 16 bytes, zero padded: most keys whole, so most lookups compare these alone
     uint32_t head;       // val | key length << 20 (0 in an unused slot) | min(step count, 3) << 26 | (NormalizeTag changes val) << 28
     uint32_t flags;      // of val
-    uint32_t len;        // byte length of val
-    uint32_t lit;        // evidence-bitset index of val, NO_ID when no rule names it
-    uint32_t step0, step1;       // Rec::step0 / step1 of val (NO_ID when absent)
-    uint32_t s0_info, s1_info;   // Rec::s0_info / s1_info of val
+    uint32_t pad0[2];
+    uint32_t key_hi[4];  // bytes 16 .. 31 of the key, zero padded (read only for keys longer than 16 bytes)
+    uint32_t pad1[4];
 };
 constexpr uint32_t LEAN_KEY_MAX = 32;
 constexpr uint32_t LEAN_HEAD_ID_MASK = 0xFFFFFu;

@@ -392,7 +392,7 @@ TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, c
         if (w.ballot(tok && decline) != 0) return LEAN_NO(4);
         bool hop = false;
         if (tok && n > 0) {
-            // the token's bytes as eight zero-padded words, its two slots, both keys at once; the payload of the slot that holds it
+            // the token's bytes as eight zero-padded words and its two slots
             const uint64_t* mk = S.tail_mask[n];
             const uint64_t w0 = ld64u(s + i2) & mk[0], w1 = ld64u(s + i2 + 8) & mk[1], w2 = ld64u(s + i2 + 16) & mk[2], w3 = ld64u(s + i2 + 24) & mk[3];
             const uint32_t kw[8] = {(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32), (uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32)};
@@ -400,21 +400,35 @@ TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, c
             lean_slots(kw, n, t.lslot_mask, s1, s2);
             const LeanSlot* A = t.lslots + s1;
             const LeanSlot* B = t.lslots + s2;
-            uint64_t ka[4], kb[4];
-            __builtin_memcpy(ka, A->key, 32);
-            __builtin_memcpy(kb, B->key, 32);
-            const bool in_a = ((ka[0] ^ w0) | (ka[1] ^ w1) | (ka[2] ^ w2) | (ka[3] ^ w3)) == 0, in_b = ((kb[0] ^ w0) | (kb[1] ^ w1) | (kb[2] ^ w2) | (kb[3] ^ w3)) == 0;
+            // the table builder fills a key's first slot when it can, so most keys are found there: the second slot is read
+            // only by the lanes whose first slot holds something else
+            uint64_t la[2];
+            __builtin_memcpy(la, A->key_lo, 16);
+            const bool lo_a = ((la[0] ^ w0) | (la[1] ^ w1)) == 0;
+            auto first_half_in_b = [&]() {
+                uint64_t lb[2];
+                __builtin_memcpy(lb, B->key_lo, 16);
+                return ((lb[0] ^ w0) | (lb[1] ^ w1)) == 0;
+            };
+            const bool lo_b = !lo_a && first_half_in_b();
             miss = true;
-            if (in_a || in_b) {
-                const LeanSlot* P = in_a ? A : B;
+            // the slot whose first half matches holds the token when the lengths agree and, for a token longer than 16 bytes,
+            // the second half matches too (two long keys with one first half may sit in both slots: then the other is tried)
+            auto try_slot = [&](const LeanSlot* P) {
                 uint32_t pay[2];
                 __builtin_memcpy(pay, &P->head, 8);
-                if (((pay[0] >> 20) & 63u) == n) {                  // the same length as well: the very string
-                    miss = false;
-                    id = pay[0] & LEAN_HEAD_ID_MASK; f = pay[1];
-                    hop = ((pay[0] >> 28) & 1u) != 0;
+                if (((pay[0] >> 20) & 63u) != n) return;
+                if (n > 16) {
+                    uint64_t kh[2];
+                    __builtin_memcpy(kh, P->key_hi, 16);
+                    if (((kh[0] ^ w2) | (kh[1] ^ w3)) != 0) return;
                 }
-            }
+                miss = false;
+                id = pay[0] & LEAN_HEAD_ID_MASK; f = pay[1];
+                hop = ((pay[0] >> 28) & 1u) != 0;
+            };
+            if (lo_a || lo_b) try_slot(lo_a ? A : B);
+            if (miss && lo_a && first_half_in_b()) try_slot(B);        // the first slot held another key with this first half
         }
         if (w.ballot(miss) != 0) {
             // in no table as it stands: dropped under strict vocabulary, provided it is plain (then normalisation leaves it

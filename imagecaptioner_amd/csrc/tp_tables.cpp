@@ -1211,12 +1211,13 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
                 const uint32_t id = owner[sidx];
                 if (id == NO_ID) continue;
                 LeanSlot& ls = out.lslots[sidx];
-                key_words(id, ls.key);
+                uint32_t kw[8];
+                key_words(id, kw);
+                for (int k = 0; k < 4; ++k) { ls.key_lo[k] = kw[k]; ls.key_hi[k] = kw[4 + k]; }
                 const uint32_t val = out.alias1[id];
                 const Rec& rv = out.rec[val];
                 ls.head = val | ((uint32_t)out.strings[id].size() << 20) | (std::min<uint32_t>(rv.step_cnt, 3) << 26) | ((out.next[val] != val ? 1u : 0u) << 28);
-                ls.flags = rv.flags; ls.len = rv.len; ls.lit = rv.lit;
-                ls.step0 = rv.step0; ls.step1 = rv.step1; ls.s0_info = rv.s0_info; ls.s1_info = rv.s1_info;
+                ls.flags = rv.flags;
             }
             sc.lslot_mask = lsl - 1;
         }
