@@ -605,6 +605,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.rc = upload(c->table_mem, h.rule_cache);
         d.slots = upload(c->table_mem, h.slots);
         d.lslots = h.lslots.empty() ? nullptr : upload(c->table_mem, h.lslots);
+        d.lkey_hi = upload(c->table_mem, h.lkey_hi);
         d.attr2 = upload(c->table_mem, h.attr2);
         d.emit_rec = upload(c->table_mem, h.emit_rec);
         d.case_map = upload(c->table_mem, h.case_map);

@@ -230,30 +230,35 @@ constexpr uint32_t SLOT_KEY_BASIC = 1u;   // the key is what NormalizeTag's step
 // Hash-table payload: what the alias lookup makes of the string in this slot, and where its bytes are (to verify a probe).
 struct HtInfo { uint32_t val, woff, slen, pad; };   // woff: first 8-byte word of the string in DevTables::str_words
 
-// One slot of the lean stage's lookup table (tp_lean.h), one cache line: a string of at most 32 bytes that the normalisation
+// One slot of the lean stage's lookup table (tp_lean.h), half a cache line: a string of at most 32 bytes that the normalisation
 // before the alias lookup leaves alone (key) -> what the stage needs of the string NormalizeTag makes of it (val).  Every key
-// sits in one of the two slots its hash names (lean_slots()), so a lookup is two independent 16-byte loads, then the payload
-// of the slot whose first half matched (and the second half of a long key).
-struct alignas(64) LeanSlot {
+// sits in one of the two slots its hash names (lean_slots()), so a lookup is one or two independent 16-byte loads, then the
+// payload of the slot whose first half matched (and, from DevTables::lkey_hi, the second half of a long key).  The table is kept
+// small (at most half full, 32 bytes a slot) so that it stays in the L2 cache of every XCD.
+struct alignas(32) LeanSlot {
     uint32_t key_lo[4];  // the key's first 16 bytes, zero padded: most keys whole, so most lookups compare these alone
     uint32_t head;       // val | key length << 20 (0 in an unused slot) | min(step count, 3) << 26 | (NormalizeTag changes val) << 28
     uint32_t flags;      // of val
-    uint32_t pad0[2];
-    uint32_t key_hi[4];  // bytes 16 .. 31 of the key, zero padded (read only for keys longer than 16 bytes)
-    uint32_t pad1[4];
+    uint32_t hi;         // keys longer than 16 bytes: which four words of DevTables::lkey_hi hold bytes 16 .. 31 (zero padded)
+    uint32_t pad;
 };
 constexpr uint32_t LEAN_KEY_MAX = 32;
 constexpr uint32_t LEAN_HEAD_ID_MASK = 0xFFFFFu;
 TP_HD uint32_t rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); }   // 0 < r < 32
-// The two slots of a key given as eight zero-padded little-endian words; mask = slots - 1.  Two accumulators with
-// different rotations, so that keys whose words merely trade places do not share both slots.
-TP_HD void lean_slots(const uint32_t k[8], uint32_t n, uint32_t mask, uint32_t& s1, uint32_t& s2) {
-    const uint32_t x = k[0] ^ rotl32(k[1], 5) ^ rotl32(k[2], 10) ^ rotl32(k[3], 15) ^ rotl32(k[4], 20) ^ rotl32(k[5], 25) ^ rotl32(k[6], 30) ^ rotl32(k[7], 3) ^ (n << 26);
-    const uint32_t y = k[0] ^ rotl32(k[1], 11) ^ rotl32(k[2], 22) ^ rotl32(k[3], 1) ^ rotl32(k[4], 12) ^ rotl32(k[5], 23) ^ rotl32(k[6], 2) ^ rotl32(k[7], 13) ^ n;
-    const uint32_t a = (x ^ (x >> 15)) * 2654435761u, b = (y ^ (y >> 13)) * 0x85EBCA77u;
-    s1 = (a >> 8) & mask;
-    s2 = (b >> 8) & mask;
-    if (s2 == s1) s2 = (s1 + 1) & mask;
+// The two slots of a key given as eight zero-padded little-endian words; the table has 1 << (32 - shift) slots.  Two
+// accumulators with different rotations, so that keys whose words merely trade places do not share both slots; two multiply
+// rounds each, and the slot from the top bits of the product (the low bits of a product see only the low bits of its
+// factors: tag names that differ in a digit or two would crowd into few slots).
+// `seed` is the table's (DevTables::lslot_seed): the builder takes the first one under which every key finds a place.
+TP_HD void lean_slots(const uint32_t k[8], uint32_t n, uint32_t shift, uint32_t seed, uint32_t& s1, uint32_t& s2) {
+    const uint32_t x = seed ^ k[0] ^ rotl32(k[1], 5) ^ rotl32(k[2], 10) ^ rotl32(k[3], 15) ^ rotl32(k[4], 20) ^ rotl32(k[5], 25) ^ rotl32(k[6], 30) ^ rotl32(k[7], 3) ^ (n << 26);
+    const uint32_t y = rotl32(seed, 16) ^ k[0] ^ rotl32(k[1], 11) ^ rotl32(k[2], 22) ^ rotl32(k[3], 1) ^ rotl32(k[4], 12) ^ rotl32(k[5], 23) ^ rotl32(k[6], 2) ^ rotl32(k[7], 13) ^ n;
+    uint32_t a = (x ^ (x >> 15)) * 2654435761u, b = (y ^ (y >> 13)) * 0x85EBCA77u;
+    a = (a ^ (a >> 13)) * 0xC2B2AE35u;
+    b = (b ^ (b >> 16)) * 0x27D4EB2Fu;
+    s1 = a >> shift;
+    s2 = b >> shift;
+    if (s2 == s1) s2 = (s1 + 1) & (0xFFFFFFFFu >> shift);
 }
 
 constexpr uint32_t NO_ID = 0xFFFFFFFFu;
@@ -315,8 +320,9 @@ struct DevTables {
     const Slot* slots;           // ht_mask + 1
     const HtInfo* ht_info;       // per hash slot
     const uint64_t* str_words;   // every string again as zero-padded little-endian 8-byte words, for word-wise probe verification
-    const LeanSlot* lslots;      // the lean stage's lookup table, lslot_mask + 1 slots (null when it could not be built)
-    uint32_t lslot_mask;
+    const LeanSlot* lslots;      // the lean stage's lookup table (null when it could not be built)
+    uint32_t lslot_shift, lslot_seed;   // 1 << (32 - lslot_shift) slots
+    const uint32_t* lkey_hi;     // second halves of the lean table's long keys, four words each (LeanSlot::hi)
     const uint32_t* case_map;    // n_case_map entries sorted by character: character << 16 | what ToLowerInvariant makes of it, for every character outside
     uint32_t n_case_map;         //   ASCII that it changes; then n_case_twin lower-case characters, sorted, that share their capital with another
     uint32_t n_case_twin;        //   lower-case character (ordinal-ignore-case comparison takes the two for one, byte comparison does not)

@@ -397,7 +397,7 @@ TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, c
             const uint64_t w0 = ld64u(s + i2) & mk[0], w1 = ld64u(s + i2 + 8) & mk[1], w2 = ld64u(s + i2 + 16) & mk[2], w3 = ld64u(s + i2 + 24) & mk[3];
             const uint32_t kw[8] = {(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32), (uint32_t)w2, (uint32_t)(w2 >> 32), (uint32_t)w3, (uint32_t)(w3 >> 32)};
             uint32_t s1, s2;
-            lean_slots(kw, n, t.lslot_mask, s1, s2);
+            lean_slots(kw, n, t.lslot_shift, t.lslot_seed, s1, s2);
             const LeanSlot* A = t.lslots + s1;
             const LeanSlot* B = t.lslots + s2;
             // the table builder fills a key's first slot when it can, so most keys are found there: the second slot is read
@@ -415,12 +415,12 @@ TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, c
             // the slot whose first half matches holds the token when the lengths agree and, for a token longer than 16 bytes,
             // the second half matches too (two long keys with one first half may sit in both slots: then the other is tried)
             auto try_slot = [&](const LeanSlot* P) {
-                uint32_t pay[2];
-                __builtin_memcpy(pay, &P->head, 8);
+                uint32_t pay[4];
+                __builtin_memcpy(pay, &P->head, 16);
                 if (((pay[0] >> 20) & 63u) != n) return;
                 if (n > 16) {
                     uint64_t kh[2];
-                    __builtin_memcpy(kh, P->key_hi, 16);
+                    __builtin_memcpy(kh, t.lkey_hi + 4 * (size_t)pay[2], 16);
                     if (((kh[0] ^ w2) | (kh[1] ^ w3)) != 0) return;
                 }
                 miss = false;

@@ -1171,7 +1171,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         cr[0] = rv.flags; cr[1] = rv.len; cr[2] = rv.lit; cr[3] = std::min<uint32_t>(rv.step_cnt, 3); cr[4] = rv.step0; cr[5] = rv.step1; cr[6] = rv.s0_info; cr[7] = rv.s1_info;
     }
     out.lslots.clear();
-    sc.lslot_mask = 0;
+    sc.lslot_shift = 31;
     if (N <= LEAN_HEAD_ID_MASK) {
         std::vector<uint32_t> keys;
         for (uint32_t i = 0; i < N; ++i) {
@@ -1184,17 +1184,20 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             for (size_t b = 0; b < str.size(); ++b) kw[b >> 2] |= (uint32_t)(unsigned char)str[b] << (8 * (b & 3));
         };
         uint32_t lsl = 16;
-        while ((uint64_t)lsl * 2 < (uint64_t)keys.size() * 5 + 16) lsl <<= 1;
-        for (int attempt = 0; attempt < 3 && out.lslots.empty(); ++attempt, lsl <<= 1) {
+        while ((uint64_t)lsl < (uint64_t)keys.size() * 2 + 8) lsl <<= 1;     // at most half full
+        out.lkey_hi.assign(4, 0);
+        for (int attempt = 0; attempt < 24 && out.lslots.empty(); ++attempt) {
+            if (attempt && attempt % 8 == 0) lsl <<= 1;                     // eight seeds per size, then twice the slots
+            const uint32_t seed = (uint32_t)attempt * 0x9E3779B9u;
             std::vector<uint32_t> owner(lsl, NO_ID);               // slot -> string id
             bool ok = true;
             for (uint32_t id0 : keys) {
                 uint32_t id = id0, avoid = NO_ID;
                 bool placed = false;
-                for (int kick = 0; kick < 2000 && !placed; ++kick) {
+                for (int kick = 0; kick < 4000 && !placed; ++kick) {
                     uint32_t kw[8], s1, s2;
                     key_words(id, kw);
-                    lean_slots(kw, (uint32_t)out.strings[id].size(), lsl - 1, s1, s2);
+                    lean_slots(kw, (uint32_t)out.strings[id].size(), 32u - (uint32_t)__builtin_ctz(lsl), seed, s1, s2);
                     if (owner[s1] == NO_ID) { owner[s1] = id; placed = true; }
                     else if (owner[s2] == NO_ID) { owner[s2] = id; placed = true; }
                     else {                                          // evict: the slot it was not just thrown out of
@@ -1203,7 +1206,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
                         avoid = victim_slot;
                     }
                 }
-                if (!placed) { ok = false; break; }
+                if (!placed) { ok = false; if (std::getenv("TAGPIPE_DEBUG_TABLES")) std::fprintf(stderr, "tagpipe tables: lean slots attempt %d at %u slots: no place for \"%s\"\n", attempt, lsl, out.strings[id0].c_str()); break; }
             }
             if (!ok) continue;
             out.lslots.assign(lsl, LeanSlot{});
@@ -1213,13 +1216,18 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
                 LeanSlot& ls = out.lslots[sidx];
                 uint32_t kw[8];
                 key_words(id, kw);
-                for (int k = 0; k < 4; ++k) { ls.key_lo[k] = kw[k]; ls.key_hi[k] = kw[4 + k]; }
+                for (int k = 0; k < 4; ++k) ls.key_lo[k] = kw[k];
+                if (out.strings[id].size() > 16) {
+                    ls.hi = (uint32_t)out.lkey_hi.size() / 4;
+                    out.lkey_hi.insert(out.lkey_hi.end(), kw + 4, kw + 8);
+                }
                 const uint32_t val = out.alias1[id];
                 const Rec& rv = out.rec[val];
                 ls.head = val | ((uint32_t)out.strings[id].size() << 20) | (std::min<uint32_t>(rv.step_cnt, 3) << 26) | ((out.next[val] != val ? 1u : 0u) << 28);
                 ls.flags = rv.flags;
             }
-            sc.lslot_mask = lsl - 1;
+            sc.lslot_shift = 32u - (uint32_t)__builtin_ctz(lsl);
+            sc.lslot_seed = seed;
         }
         if (std::getenv("TAGPIPE_DEBUG_TABLES")) std::fprintf(stderr, "tagpipe tables: lean slots %zu keys in %zu slots\n", keys.size(), out.lslots.size());
     }
@@ -1440,6 +1448,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.rc = ht.rule_cache.data();
     t.slots = ht.slots.data();
     t.lslots = ht.lslots.empty() ? nullptr : ht.lslots.data();
+    t.lkey_hi = ht.lkey_hi.data();
     t.attr2 = ht.attr2.data();
     t.emit_rec = ht.emit_rec.data();
     t.case_map = ht.case_map.data();
