@@ -14,7 +14,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 
 SOURCES = ["tp_kernels.hip", "tp_api.cpp", "tp_tables.cpp"]
-HEADERS = ["tp_common.h", "tp_pipeline.h", "tp_fast.h", "tp_launch.h", "tp_tables.hpp", "tp_json.hpp", "tp_case_tables.inc",
+HEADERS = ["tp_common.h", "tp_pipeline.h", "tp_fast.h", "tp_lean.h", "tp_launch.h", "tp_tables.hpp", "tp_json.hpp", "tp_case_tables.inc",
            os.path.join("..", "..", "include", "tagpipe.h")]
 # -ffp-contract=off: the score arithmetic (1.0 - i * 0.01) must round like the reference's, with no fused multiply-add.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -610,6 +610,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.emit_rec = upload(c->table_mem, h.emit_rec);
         d.case_map = upload(c->table_mem, h.case_map);
         d.crec = upload(c->table_mem, h.crec);
+        d.fw_tix = upload(c->table_mem, h.fw_tix);
         d.step_off = upload(c->table_mem, h.step_off);
         d.step_ids = upload(c->table_mem, h.step_ids);
         d.reach_off = upload(c->table_mem, h.reach_off);

@@ -244,6 +244,27 @@ struct alignas(32) LeanSlot {
 };
 constexpr uint32_t LEAN_KEY_MAX = 32;
 constexpr uint32_t LEAN_HEAD_ID_MASK = 0xFFFFFu;
+constexpr uint32_t CREC_LIT_NONE = 0xFFFu;         // no literal, in DevTables::crec
+constexpr uint32_t CREC_TOO_LONG = 1u << 31;       // in a record's third word: a length that a final-list word has no room for
+// What a tag adds to the sums and tests over a file's final and selected lists, as one word per string (DevTables::fw_tix),
+// so that a wavefront accumulates them with an OR and an add per list element instead of testing the flags one by one.
+enum : uint32_t {
+    FW_LEN_MASK = 0x3FFu,      // byte length (below 1023; the record carries CREC_TOO_LONG otherwise)
+    FW_FACE = 1u << 10,        // ClassifyTag == "face"   (MissingCoreBuckets, Program.cs:1097-1101)
+    FW_OUTFIT = 1u << 11,      // ClassifyTag == "outfit" (the same, and EvaluateCoverage, Program.cs:1056-1095)
+    FW_SAFE = 1u << 12,        // SafeModeRejectTags member (Program.cs:942-945), its index in bits 13..17
+    FW_SAFE_IDX_SHIFT = 13,
+    FW_FOOTJOB = 1u << 18,     // the string NormalizeTag makes of "footjob" (Program.cs:309-311)
+    FW_UNKNOWN = 1u << 19,     // not in KnownTags (GetUnknownTags, Program.cs:817-824)
+    FW_TRIGGER = 1u << 20,     // the trigger tag          (EvaluateCoverage's identity test)
+    FW_GIRL = 1u << 21,        // "1girl" as normalised
+    FW_HAIR = 1u << 22, FW_EYES = 1u << 23, FW_POSE = 1u << 24, FW_BACKGROUND = 1u << 25,
+    FW_BLANK = 1u << 26,       // FL_BLANK
+    FW_FIX = 1u << 27,         // FL_FIX
+    FW_EDGE = 1u << 28,        // FL_EDGE
+};
+constexpr uint32_t LEAN_TIX_MAX = 512;             // target indices the lean stage's direct first-occurrence table has room for
+constexpr uint32_t TIX_NONE = 0xFFFu;
 TP_HD uint32_t rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); }   // 0 < r < 32
 // The two slots of a key given as eight zero-padded little-endian words; the table has 1 << (32 - shift) slots.  Two
 // accumulators with different rotations, so that keys whose words merely trade places do not share both slots; two multiply
@@ -268,8 +289,8 @@ constexpr int N_BANNED = 9;               // BannedFinalTags, Program.cs:33-35
 constexpr int TOP_TAGS = 20;              // TopJoyTags of a review record, Program.cs:860
 constexpr int MAX_ALWAYS_ADD = 64;
 constexpr int MAX_FALLBACK = MAX_TOTAL_TAGS;
-constexpr uint32_t RC_REC_WORDS = 10;
-constexpr uint32_t RC_FACET_WORDS = 6;
+constexpr uint32_t RC_REC_WORDS = 12;
+constexpr uint32_t RC_FACET_WORDS = 8;
 constexpr uint32_t FAST_RC_MAX_WORDS = 8192;   // 32 KB of LDS per block at most
 constexpr uint32_t FAST_FRULES_MAX = 512;      // facet rules the wave-per-file kernel keeps one hit bit each for
 
@@ -330,7 +351,14 @@ struct DevTables {
     const uint32_t* emit_rec;    // per id, four words, for the caption writer: a string of up to 15 bytes itself (zero-padded) with its length in byte 15;
                                  //   a longer one as {offset into str_bytes, byte length, 0, 0xFF << 24}
     const uint32_t* attr2;       // per id: flags, byte length (two words)
-    const uint32_t* crec;        // per id, eight words: flags, byte length, Rec::lit, min(step count, 3), step0, step1, s0_info, s1_info
+    const uint32_t* crec;        // per id, eight words, for the lean stage's back half: flags; its final-list word (FW_*); Rec::lit (12 bits,
+                                 // CREC_LIT_NONE = none) | its target index << 12 (12 bits, TIX_NONE = none) | min(step count, 3) << 24 | CREC_TOO_LONG;
+                                 // Rec::s0_info | s1_info << 16, each as literal index (12 bits), feet-ness << 12, penis-ness << 13; step0 and step1,
+                                 // each as id | target index << 20, or NO_ID; the final-list words of step0 and step1 (0 when absent)
+                                 // (steps: the first two entries of the string's ExpandImpliedTags step list; absent without FL_EDGE)
+    const uint32_t* fw_tix;      // per id, two words: the final-list word (FW_*), the target index or TIX_NONE
+    uint32_t n_tix;              // target indices in use: one per string that is a step of some string or a facet's default or rule tag
+                                 // (what can occur twice in a file's final list); above LEAN_TIX_MAX none are given out
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:
     const uint32_t* step_ids;    //   NormalizeTag(it), then the implied tags of that (Program.cs:1164-1175); empty when nothing can change
     const uint32_t* reach_off;   // n_strings + 1: every other string the closure of {it} holds, as pairs
@@ -346,8 +374,9 @@ struct DevTables {
     // RC_REC_WORDS-word records {tag id, first subtype (rules), all_cnt | any_cnt << 8 | forbidden_cnt << 16,
     // literal list offset in the cache (15 bits) | 0x8000 when NormalizeTag does not leave the tag alone | subtype count << 16,
     // four literals inline (all, any, forbidden in this order; the offset is used when there are more), the tag's flags, its
-    // byte length}, then facets as RC_FACET_WORDS-word records {default id, first facet rule, rule count, the default's flags,
-    // its byte length, 1 when NormalizeTag does not leave the default alone}, then the longer literal lists.
+    // byte length, its final-list word, its target index}, then facets as RC_FACET_WORDS-word records {default id, first facet
+    // rule, rule count, the default's flags, its byte length, 1 when NormalizeTag does not leave the default alone, its final-list
+    // word, its target index}, then the longer literal lists.
     const uint32_t* rc;
     uint32_t rc_words, rc_subs, rc_frules, rc_facets, n_frules;
     // Literal masks in the cache (lit_words words each): the literals action rules (facet rules) test positively.  A file whose

@@ -45,6 +45,24 @@ __device__ inline uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
+// The OR over the 64 lanes, the same way; the result is in lane 63.
+__device__ inline uint32_t wave_or_to_last(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// The number of this wavefront in its block and in the grid.  (Handing these to the compiler as wave-uniform values - through
+// readfirstlane - turns the per-file loads of sizes and offsets into scalar loads; measured, that is no gain in the lean
+// kernels and a loss of 7 % in k_emit: scalar loads return out of order and share a counter with LDS, so every wait
+// for one of them also waits for all LDS traffic.)
+__device__ __forceinline__ uint32_t wave_in_block() { return threadIdx.x >> 6; }
+__device__ __forceinline__ uint64_t wave_index() { return ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
+
 struct DevWave {
 #ifdef TP_PROF
     uint64_t last = 0, acc[32] = {0};
@@ -71,6 +89,8 @@ struct DevWave {
     __device__ uint32_t shift_up(uint32_t v, uint32_t fill) const { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
     // the sum over all lanes, in every lane
     __device__ uint32_t sum(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63); }
+    // the OR over all lanes, in every lane
+    __device__ uint32_t or_all(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readlane((int)wave_or_to_last(v), 63); }
     __device__ uint32_t shfl(uint32_t v, uint32_t src) const { return (uint32_t)__shfl((int)v, (int)(src & 63u), 64); }
     // Orders the wave's own LDS traffic (each wavefront owns its LDS state): LDS instructions of one wave execute in
     // order, so wavefront scope is enough and, unlike a wider scope, does not wait for outstanding global loads and stores.
@@ -129,9 +149,9 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
     __syncthreads();
     __shared__ DeclineBuf dbuf[FAST_WAVES_PER_BLOCK];
     uint32_t n_declined = 0;
-    FastLds& L = lds[threadIdx.x >> 6];
+    FastLds& L = lds[wave_in_block()];
     DevWave w;
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_items = a.item_list ? (uint64_t)*a.item_count : a.file_end - a.file0;
     for (uint64_t i = wave_global; i < n_items; i += n_waves) {
@@ -152,11 +172,11 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
                 a.slot_of[f] = SLOT_FAST;
             }
         } else {
-            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)(f - a.file0), a.slow_list, a.slow_count);
+            decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)(f - a.file0), a.slow_list, a.slow_count);
         }
         w.sync();
     }
-    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
+    decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
 #ifdef TP_PROF
     w.flush();
 #endif
@@ -181,7 +201,7 @@ constexpr int LEAN_WAVES_PER_BLOCK = 4;
 #define TP_LEAN_A_WAVES_PER_SIMD 8
 #endif
 #ifndef TP_LEAN_B_WAVES_PER_SIMD
-#define TP_LEAN_B_WAVES_PER_SIMD 6
+#define TP_LEAN_B_WAVES_PER_SIMD 5
 #endif
 typedef const __attribute__((address_space(4))) DevTables ConstTables;
 __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_A_WAVES_PER_SIMD))) void k_lean_a(FastArgs a) {
@@ -192,9 +212,9 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     lean_shared_init(t, shared, threadIdx.x, blockDim.x);
     __syncthreads();
     uint32_t n_declined = 0;
-    LeanFrontLds& L = lds[threadIdx.x >> 6];
+    LeanFrontLds& L = lds[wave_in_block()];
     DevWave w;
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_items = a.file_end - a.file0;
     // Two files ahead the wave reads a file's offsets, one file ahead its piece of the line, so that neither load is
@@ -222,11 +242,11 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
         if (done) {
             if (w.lane() == 0) { a.n_final[f] = n_cand; a.slot_of[f] = SLOT_LEAN; }
         } else {
-            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
+            decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
         }
         w.sync();
     }
-    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
+    decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
 #ifdef TP_PROF
     w.flush();
 #endif
@@ -241,12 +261,14 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     lean_shared_init(t, shared, threadIdx.x, blockDim.x);
     __syncthreads();
     uint32_t n_declined = 0;
-    LeanLds& L = lds[threadIdx.x >> 6];
+    LeanLds& L = lds[wave_in_block()];
     DevWave w;
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_items = a.file_end - a.file0;
-    // one file ahead: whether the front half passed the file, its candidate count and ids
+    // Two files ahead the wave reads whether the front half passed a file, its candidate count and ids; one file ahead it
+    // has the candidates' records (DevTables::crec, 32 bytes each) loaded straight into L.cr, as soon as the file before
+    // has read its own out of there; so neither the ids nor the records are waited for when a file's turn comes.
     auto peek = [&](uint64_t i, uint32_t& n_cand, uint32_t& id) {
         n_cand = 0xFFFFFFFFu; id = NO_ID;
         if (i < n_items && a.slot_of[a.file0 + i] == SLOT_LEAN) {
@@ -254,15 +276,31 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
             id = a.fin32[i * FAST_FIN_MAX + w.lane()];           // entries behind the count are never used
         }
     };
-    uint32_t n0, id0, n1, id1;
+    auto fetch_records = [&](uint32_t n_cand, uint32_t id) {       // n_cand is the same in every lane
+        if (n_cand != 0xFFFFFFFFu && w.lane() < n_cand) {
+            const uint32_t* src = t.crec + 8 * (size_t)id;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)&L.cr[0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4), (__attribute__((address_space(3))) void*)&L.cr[1][0], 16, 0, 0);
+        }
+    };
+    uint32_t n0, id0, n1, id1, n2, id2;
     peek(wave_global, n0, id0);
+    peek(wave_global + n_waves, n1, id1);
+    fetch_records(n0, id0);
     for (uint64_t i = wave_global; i < n_items; i += n_waves) {
         const uint64_t f = a.file0 + i;
-        peek(i + n_waves, n1, id1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this file's records are in L.cr (and the next file's ids in registers)
+        peek(i + 2 * n_waves, n2, id2);
+        bool fetched = false;
+        auto records_free = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // what this file read out of L.cr has arrived
+            fetch_records(n1, id1);
+            fetched = true;
+        };
         if (n0 != 0xFFFFFFFFu) {
             FastOut out;
             const bool done = lean_back(w, t, L, shared, rc_lds, w.lane() < n0 ? id0 : NO_ID, n0, out, a.fin32 + i * FAST_FIN_MAX,
-                                        a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr);
+                                        a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, records_free);
             if (done) {
                 if (w.lane() == 0) {
                     a.verdicts[f] = out.verdict;
@@ -271,13 +309,14 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                     a.slot_of[f] = SLOT_FAST;
                 }
             } else {
-                decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
+                decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
             }
             w.sync();
         }
-        n0 = n1; id0 = id1;
+        if (!fetched) records_free();
+        n0 = n1; id0 = id1; n1 = n2; id1 = id2;
     }
-    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
+    decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
 #ifdef TP_PROF
     w.flush();
 #endif
@@ -293,9 +332,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
     __syncthreads();
     __shared__ DeclineBuf dbuf[FAST_WAVES_PER_BLOCK];
     uint32_t n_declined = 0;
-    FastLds& L = lds[threadIdx.x >> 6];
+    FastLds& L = lds[wave_in_block()];
     DevWave w;
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_items = a.file_end - a.file0;
     for (uint64_t i = wave_global; i < n_items; i += n_waves) {
@@ -315,11 +354,11 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
                 a.slot_of[f] = SLOT_FAST;
             }
         } else {
-            decline_push(dbuf[threadIdx.x >> 6], n_declined, (uint32_t)(f - a.file0), a.slow_list, a.slow_count);
+            decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)(f - a.file0), a.slow_list, a.slow_count);
         }
         w.sync();
     }
-    decline_flush(dbuf[threadIdx.x >> 6], n_declined, a.slow_list, a.slow_count);
+    decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
 }
 
 // Third stage: the files the second declined, up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes; one wavefront per block.
@@ -529,9 +568,9 @@ __device__ inline void put_bytes(uint8_t* dst, const uint8_t* src, uint32_t len)
 // record's lists are separated by "\n" (the host sorts and joins them); the unknown-tag column keeps only entries that qualify.
 __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][AUDIT_STAGE];
-    uint8_t* stage = stage_all[threadIdx.x >> 6];
+    uint8_t* stage = stage_all[wave_in_block()];
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t i = wave_global; i < a.n_items; i += n_waves) {
         const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
@@ -616,8 +655,8 @@ struct EmitCounts {
 __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu(TP_EMIT_WAVES_PER_SIMD))) void k_emit(DevTables t, EmitArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[EMIT_WAVES][EMIT_STAGE + 32];
     const uint32_t lane = threadIdx.x & 63;
-    uint8_t* stage = stage_all[threadIdx.x >> 6];
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint8_t* stage = stage_all[wave_in_block()];
+    const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     EmitCounts cnt;
 
@@ -767,9 +806,9 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
 // bytes.  A group of tags too long for the area is stored lane by lane.
 __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][GEN_STAGE];
-    uint8_t* stage = stage_all[threadIdx.x >> 6];
+    uint8_t* stage = stage_all[wave_in_block()];
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave_global = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     EmitCounts cnt;
     uint64_t c_other = 0;

@@ -62,17 +62,14 @@ constexpr uint32_t LEAN_DEAD = 0xFFFFFFFFu;   // no element
 constexpr uint32_t LEAN_ROUNDS = 5;
 constexpr uint32_t LEAN_FACETS_MAX = 64;      // one facet per lane
 constexpr uint32_t LEAN_LIT_WORDS = 64;       // evidence bitset words (2048 rule literals)
-constexpr uint32_t LEAN_CAND_WORDS = 8;       // words of a candidate's record in LDS
 
-// What the rest of the pipeline needs to know about a candidate, kept in LDS from the token lookup to the point where the
-// selected tags are put on the lanes by position (so that it does not occupy registers in between).
-struct LeanCand {
-    uint32_t id, flags, len, step_cnt;
-    uint32_t step0, step1, pad0, pad1;       // the first two steps of one ExpandImpliedTags visit (Rec::step0 / step1), NO_ID when absent
-};
-static_assert(sizeof(LeanCand) == 4 * LEAN_CAND_WORDS, "two 16-byte pieces");
+// What the back half needs to know about a candidate is its string's record in DevTables::crec (eight words).  The records of
+// a file's candidates are in LDS as two planes of 16 bytes per lane (LeanLds::cr), put there by whoever calls lean_back -
+// the GPU kernel by loads that write LDS directly, one file ahead - and stay there until the selected tags are on the
+// lanes by position.
+struct LeanCr { uint32_t w[4]; };
 // Tags one level further down (steps of a selected tag's steps), per position: two per lane.
-struct LeanDeep { uint32_t val, flags, len, pad; };
+struct LeanDeep { uint32_t val, fw, pad0, pad1; };
 
 // The front half's LDS state per wavefront (line scan, token lookup, Distinct) ...
 struct alignas(16) LeanFrontLds {
@@ -84,21 +81,22 @@ struct alignas(16) LeanFrontLds {
 // ... and the back half's (everything from the candidates on).
 struct alignas(16) LeanLds {
     union {
-        LeanCand cand[64];                    // the candidates' records, until the selected tags are on the lanes by position
+        LeanCr cr[2][64];                     // cr[h][l]: words 4h .. 4h + 3 of candidate l's record, until the selected tags are on the lanes by position
         LeanDeep deep[2][64];                 // after that
     };
+    uint32_t ids[64];                         // the candidates' ids
     static constexpr uint32_t TAB_BITS = LEAN_BACK_TAB_BITS, TAB = 1u << TAB_BITS;   // slots per min-order table
     uint32_t tab[2 * TAB];                    // two min-order tables
     uint32_t ebits[LEAN_LIT_WORDS];           // evidence bitset over the rule literals
     uint32_t fhit[FAST_FRULES_MAX / 32];      // bit p: facet rule p matches the evidence
     uint32_t inv[64];                         // selected position -> candidate lane
-    uint32_t act[64][4];                      // the tags the action rules offer, in rule order: val, flags, length
+    uint32_t act[64][4];                      // the tags the action rules offer, in rule order: val, final-list word
     uint32_t scratch[4];
 };
 // Per block: masks that cut a 32-byte read down to a token's length; the tags SelectTags adds before the candidates.
 struct alignas(16) LeanShared {
     uint64_t tail_mask[33][4];
-    uint32_t prefix_ids[MAX_TOTAL_TAGS], prefix_flags[MAX_TOTAL_TAGS], prefix_len[MAX_TOTAL_TAGS];
+    uint32_t prefix_ids[MAX_TOTAL_TAGS], prefix_flags[MAX_TOTAL_TAGS], prefix_fw[MAX_TOTAL_TAGS], prefix_tix[MAX_TOTAL_TAGS];
 };
 template <class TT>
 TP_HD void lean_shared_init(const TT& t, LeanShared& S, uint32_t tid, uint32_t nthreads) {
@@ -106,11 +104,13 @@ TP_HD void lean_shared_init(const TT& t, LeanShared& S, uint32_t tid, uint32_t n
     for (uint32_t k = tid; k < (uint32_t)MAX_TOTAL_TAGS; k += nthreads) {
         S.prefix_ids[k] = k < t.n_prefix ? t.prefix_ids[k] : NO_ID;
         S.prefix_flags[k] = k < t.n_prefix ? t.prefix_flags[k] : 0;
-        S.prefix_len[k] = k < t.n_prefix ? t.prefix_len[k] : 0;
+        S.prefix_fw[k] = k < t.n_prefix ? t.fw_tix[2 * (size_t)t.prefix_ids[k]] : 0;
+        S.prefix_tix[k] = k < t.n_prefix ? t.fw_tix[2 * (size_t)t.prefix_ids[k] + 1] : TIX_NONE;
     }
 }
 // The tables fit this stage at all (checked once on the host).
 inline bool lean_tables_ok(const DevTables& t) {
+    for (uint32_t k = 0; k < t.n_prefix && k < (uint32_t)MAX_TOTAL_TAGS; ++k) if (t.prefix_len[k] >= FW_LEN_MASK) return false;   // no room in a final-list word
     return t.fast_ok && t.prefix_simple && t.lslots != nullptr && t.n_strings <= LEAN_ID_MASK && t.n_facets <= LEAN_FACETS_MAX && t.n_prefix <= 8 && !t.rules_vacuous &&
            t.lit_words <= LEAN_LIT_WORDS;
 }
@@ -198,20 +198,17 @@ TP_HD bool lean_rc_match(const uint32_t* ebits, const uint32_t* rc, uint32_t rec
 #define TP_NOINLINE
 #endif
 
-// What the final list's elements add up to: caption bytes, tags outside the vocabulary, the first safe-mode hit, bucket bits.
-struct LeanAcc { uint32_t bytes, unknown, safe_key, bits; };
-constexpr uint32_t LA_FACE = 1, LA_OUTFIT = 2, LA_SAFE = 4, LA_FOOT = 8;
-template <class TT>
-TP_HD void lean_emit(LeanAcc& a, const TT& t, uint32_t* fin32, bool first, uint32_t val, uint32_t fl, uint32_t ln, uint32_t at) {
+// What the final list's elements add up to: the OR of their final-list words (FW_*: bucket bits of MissingCoreBuckets,
+// Program.cs:1097-1101, safe-mode and footjob membership), caption bytes (low 20 bits of sum) and tags outside the
+// vocabulary (from bit 20), the first safe-mode hit.
+struct LeanAcc { uint32_t sum, safe_key, bits; };
+constexpr uint32_t LA_UNKNOWN_SHIFT = 20;
+TP_HD void lean_emit(LeanAcc& a, uint32_t* fin32, bool first, uint32_t val, uint32_t fw, uint32_t at) {
     if (first) {
-        const uint32_t bk = fl_bucket(fl), eid = val & LEAN_ID_MASK;
-        if (bk == B_FACE) a.bits |= LA_FACE;                        // MissingCoreBuckets, Program.cs:1097-1101
-        if (bk == B_OUTFIT) a.bits |= LA_OUTFIT;
-        if (fl & FL_SAFE) { a.bits |= LA_SAFE; const uint32_t key = (at << 8) | ((fl >> FL_SAFE_IDX_SHIFT) & 31u); a.safe_key = key < a.safe_key ? key : a.safe_key; }
-        if (eid == t.footjob_n) a.bits |= LA_FOOT;
-        a.bytes += ln;
-        a.unknown += (fl & FL_KNOWN) ? 0u : 1u;
-        fin32[at] = eid;
+        a.bits |= fw;
+        a.sum += (fw & FW_LEN_MASK) | ((fw / FW_UNKNOWN) & 1u) << LA_UNKNOWN_SHIFT;
+        if (fw & FW_SAFE) { const uint32_t key = (at << 8) | ((fw >> FW_SAFE_IDX_SHIFT) & 31u); a.safe_key = key < a.safe_key ? key : a.safe_key; }
+        fin32[at] = val & LEAN_ID_MASK;
     }
 }
 
@@ -236,9 +233,9 @@ TP_HD TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uin
             const uint32_t* rr = rc + (r0 + ctz64(m)) * RC_REC_WORDS;
             m &= m - 1;
             const uint32_t sub_off = rr[1], sub_cnt = rr[3] >> 16;
-            if (rr[3] & 0x8000u) changes = true;                   // a tag NormalizeTag changes
+            if ((rr[3] & 0x8000u) || (rr[10] & FW_LEN_MASK) == FW_LEN_MASK) changes = true;   // a tag NormalizeTag changes, or too long for its final-list word
             if (n_act >= 64) return LEAN_DEAD;
-            if (lane == 0) { L.act[n_act][0] = lean_val(640 + n_act, rr[0], true); L.act[n_act][1] = rr[8]; L.act[n_act][2] = rr[9]; }
+            if (lane == 0) { L.act[n_act][0] = lean_val(640 + n_act, rr[0], true); L.act[n_act][1] = rr[10]; }
             ++n_act;
             for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
                 const uint32_t si = s0 + lane;
@@ -250,9 +247,9 @@ TP_HD TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uin
                     const uint32_t bit = t.n_rules + sub_off + si;                           // "subtype:{parent}:{tag}" (Program.cs:748)
                     w.lds_or(&firedw[bit >> 5], 1u << (bit & 31));
                     const uint32_t* sr = rc + srec;
-                    if (sr[3] & 0x8000u) changes = true;
+                    if ((sr[3] & 0x8000u) || (sr[10] & FW_LEN_MASK) == FW_LEN_MASK) changes = true;
                     const uint32_t q = n_act + w.rank(ms);
-                    L.act[q][0] = lean_val(640 + q, sr[0], true); L.act[q][1] = sr[8]; L.act[q][2] = sr[9];
+                    L.act[q][0] = lean_val(640 + q, sr[0], true); L.act[q][1] = sr[10];
                 }
                 n_act += popc64(ms);
             }
@@ -269,7 +266,7 @@ TP_HD TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uin
 // appends in the next round of ExpandImpliedTags (Program.cs:1160-1179); at most two steps, at most two of those tags per
 // selected tag, and nothing beyond them, or the file is not for this stage (returns true).  The tags go to L.deep.
 template <class W, class TT>
-TP_HD TP_NOINLINE bool lean_deep(W& w, const TT& t, LeanLds& L, bool deep, uint32_t k_cnt, uint32_t kv0, uint32_t kv1, uint32_t kf0, uint32_t kf1) {
+TP_HD TP_NOINLINE bool lean_deep(W& w, const TT& t, LeanLds& L, bool deep, uint32_t k_cnt, uint32_t kv0, uint32_t kv1, uint32_t kw0, uint32_t kw1) {
     const uint32_t lane = w.lane();
     w.sync();                                                       // the candidates' records have been read: their place is taken by the deeper tags
     bool bad_deep = deep && k_cnt > 2;
@@ -277,16 +274,18 @@ TP_HD TP_NOINLINE bool lean_deep(W& w, const TT& t, LeanLds& L, bool deep, uint3
     if (deep && !bad_deep) {
         uint32_t ng = 0;
         for (uint32_t c = 0; c < 2; ++c) {
-            const uint32_t kv = c ? kv1 : kv0, kf = c ? kf1 : kf0;
+            const uint32_t kv = c ? kv1 : kv0, kw = c ? kw1 : kw0;
             if (kv == LEAN_DEAD) continue;
-            if (!(kf & FL_FIX)) { bad_deep = true; continue; }     // a step NormalizeTag changes
-            if (!(kf & FL_EDGE)) continue;
+            if (!(kw & FW_FIX)) { bad_deep = true; continue; }     // a step NormalizeTag changes
+            if (!(kw & FW_EDGE)) continue;
             const Rec rk = t.rec[kv & LEAN_ID_MASK];
             if (!(rk.flags & FL_LEAF2) || ng + rk.step_cnt > 2) { bad_deep = true; continue; }
             for (uint32_t j = 0; j < rk.step_cnt; ++j) {
                 LeanDeep g;
-                g.val = lean_val(320 + 4 * lane + 2 * c + j, j == 0 ? rk.step0 : rk.step1, true);
-                g.flags = j == 0 ? rk.s0_flags : rk.s1_flags; g.len = j == 0 ? rk.s0_len : rk.s1_len; g.pad = 0;
+                const uint32_t gid = j == 0 ? rk.step0 : rk.step1;
+                g.val = lean_val(320 + 4 * lane + 2 * c + j, gid, true);
+                g.fw = t.fw_tix[2 * (size_t)gid]; g.pad0 = g.pad1 = 0;
+                if ((g.fw & FW_LEN_MASK) == FW_LEN_MASK) bad_deep = true;   // a length the word has no room for
                 if (ng == 0) g0 = g; else g1 = g;
                 ++ng;
             }
@@ -313,15 +312,15 @@ TP_HD TP_NOINLINE LeanWide lean_first_wide(W& w, LeanLds& L, uint32_t v0, uint32
 template <class W, class TT>
 TP_HD TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uint32_t* fin32, uint32_t fb, uint32_t base_g, uint32_t base_a, bool any_deep, uint32_t n_act) {
     const uint32_t lane = w.lane();
-    LeanAcc a = {0, 0, 0xFFFFFFFFu, 0};
+    LeanAcc a = {0, 0xFFFFFFFFu, 0};
     const uint64_t mg0 = w.ballot(fb & 16u), mg1 = w.ballot(fb & 32u), ma = w.ballot(fb & 64u);
     if (any_deep) {
         const LeanDeep g0 = L.deep[0][lane], g1 = L.deep[1][lane];
         const uint32_t pos_g0 = base_g + w.rank(mg0) + w.rank(mg1);
-        lean_emit(a, t, fin32, (fb & 16u) != 0, g0.val, g0.flags, g0.len, pos_g0);
-        lean_emit(a, t, fin32, (fb & 32u) != 0, g1.val, g1.flags, g1.len, pos_g0 + ((fb >> 4) & 1u));
+        lean_emit(a, fin32, (fb & 16u) != 0, g0.val, g0.fw, pos_g0);
+        lean_emit(a, fin32, (fb & 32u) != 0, g1.val, g1.fw, pos_g0 + ((fb >> 4) & 1u));
     }
-    if (lane < n_act) lean_emit(a, t, fin32, (fb & 64u) != 0, L.act[lane][0], L.act[lane][1], L.act[lane][2], base_a + w.rank(ma));
+    if (lane < n_act) lean_emit(a, fin32, (fb & 64u) != 0, L.act[lane][0], L.act[lane][1], base_a + w.rank(ma));
     return a;
 }
 
@@ -455,33 +454,34 @@ TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, c
 }
 
 // The back half for one file: everything from the candidates on (Program.cs:223-229, 292-329).  id: candidate number `lane`
-// of the file (lane < n_cand; NO_ID otherwise), as lean_front left it.  rc: the rule cache; fin32: the caption's tag ids
-// (FAST_FIN_MAX entries); fired (fired_words words) and facet_choice may be null; with fired the evidence set is counted
-// (tp_verdict::n_evidence).  false = declined.
-template <class W, class TT>
+// of the file (lane < n_cand; NO_ID otherwise), as lean_front left it; L.cr[0][l], L.cr[1][l]: the record of candidate l's
+// string (DevTables::crec), for every l < n_cand, put there by the caller.  records_free() is called at most once, at the
+// point from which L.cr is no longer read (a caller that fills it for the next file ahead of time may start then; it is
+// not called on every path).  rc: the rule cache; fin32: the caption's tag ids (FAST_FIN_MAX entries); fired (fired_words
+// words) and facet_choice may be null; with fired the evidence set is counted (tp_verdict::n_evidence).  false = declined.
+template <class W, class TT, class RF>
 TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const uint32_t* rc, uint32_t id, uint32_t n_cand, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice) {
+                     uint32_t* fired, uint16_t* facet_choice, RF&& records_free) {
     const uint32_t lane = w.lane();
     const bool act = lane < n_cand;
     const uint32_t ci = lane;
     // the candidate's record: what NormalizeTag, ClassifyTag, the rules and ExpandImpliedTags need to know of the string
-    uint32_t f = FL_BLANK, lit = NO_ID, s0_info = 0xFFFFFFu, s1_info = 0xFFFFFFu, ev_step[2] = {NO_ID, NO_ID};
+    uint32_t f = FL_BLANK, lit = CREC_LIT_NONE, s_info = CREC_LIT_NONE | CREC_LIT_NONE << 16, ev_step[2] = {NO_ID, NO_ID};
     {
-        LeanCand c;
-        c.id = NO_ID; c.flags = FL_BLANK; c.len = 0; c.step_cnt = 0; c.step0 = c.step1 = NO_ID; c.pad0 = c.pad1 = 0;
+        bool too_long = false;
         if (act) {
-            uint32_t cr[8];
-            __builtin_memcpy(cr, t.crec + 8 * (size_t)id, 32);
-            f = cr[0]; lit = cr[2]; s0_info = cr[6]; s1_info = cr[7];
-            const bool edge = (f & FL_EDGE) != 0;
-            c.id = id; c.flags = f; c.len = cr[1]; c.step_cnt = edge ? cr[3] : 0;
-            c.step0 = edge ? cr[4] : NO_ID; c.step1 = edge ? cr[5] : NO_ID;
-            ev_step[0] = c.step0; ev_step[1] = c.step1;
+            uint32_t c0[4], c1[4];
+            w.load16((const uint8_t*)&L.cr[0][lane], c0);
+            w.load16((const uint8_t*)&L.cr[1][lane], c1);
+            f = c0[0]; lit = c0[2] & CREC_LIT_NONE; s_info = c0[3];
+            too_long = (c0[2] & CREC_TOO_LONG) != 0;
+            ev_step[0] = c1[0] == NO_ID ? NO_ID : c1[0] & LEAN_ID_MASK; ev_step[1] = c1[1] == NO_ID ? NO_ID : c1[1] & LEAN_ID_MASK;
+            L.ids[lane] = id;
         }
-        w.store16((uint8_t*)&L.cand[lane], (const uint32_t(&)[4])c.id);
-        w.store16((uint8_t*)&L.cand[lane] + 16, (const uint32_t(&)[4])c.step0);
+        if (w.ballot(too_long) != 0) return LEAN_NO(8);           // a length the record has no room for
     }
     w.tick(20);
+    LEAN_STOP(1, f ^ lit ^ s_info ^ ev_step[0] ^ ev_step[1])
 
     // ---- candidates (Program.cs:625-655): scores fall with the candidate index, so sorted order is candidate order ----------
     const bool nonblank = act && !(f & FL_BLANK);
@@ -502,7 +502,7 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
         bool ev_far = false;
         uint32_t ev_id[3] = {id, NO_ID, NO_ID};
         if (seed) {
-            if (lit != NO_ID) w.lds_or(&L.ebits[lit >> 5], 1u << (lit & 31));
+            if (lit != CREC_LIT_NONE) w.lds_or(&L.ebits[lit >> 5], 1u << (lit & 31));
             ev_feet = (f & FL_NFEET) != 0; ev_penis = (f & FL_NPENIS) != 0;
             if ((f & FL_EDGE) && !(f & FL_REACH2)) {
                 const uint32_t m0 = t.reach_off[id], m1 = t.reach_off[id + 1];
@@ -515,11 +515,11 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
                     if (m - m0 < 2) ev_id[1 + (m - m0)] = t.reach_ent[2 * m];
                 }
             } else if (f & FL_EDGE) {
-                const uint32_t i0 = ev_step[0] != NO_ID ? s0_info : 0xFFFFFFu, i1 = ev_step[1] != NO_ID ? s1_info : 0xFFFFFFu;
-                if ((i0 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i0 & 0xFFFFFFu) >> 5], 1u << (i0 & 31));
-                if ((i1 & 0xFFFFFFu) != 0xFFFFFFu) w.lds_or(&L.ebits[(i1 & 0xFFFFFFu) >> 5], 1u << (i1 & 31));
-                ev_feet |= (((i0 | i1) >> 24) & 1u) != 0;
-                ev_penis |= (((i0 | i1) >> 25) & 1u) != 0;
+                const uint32_t l0 = s_info & CREC_LIT_NONE, l1 = (s_info >> 16) & CREC_LIT_NONE;   // absent steps have no literal and no bits
+                if (l0 != CREC_LIT_NONE) w.lds_or(&L.ebits[l0 >> 5], 1u << (l0 & 31));
+                if (l1 != CREC_LIT_NONE) w.lds_or(&L.ebits[l1 >> 5], 1u << (l1 & 31));
+                ev_feet |= (s_info & 0x10001000u) != 0;
+                ev_penis |= (s_info & 0x20002000u) != 0;
                 ev_id[1] = ev_step[0]; ev_id[2] = ev_step[1];
             }
         }
@@ -536,6 +536,7 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
     }
     w.sync();
     w.tick(21);
+    LEAN_STOP(2, n_dropped + style_n + (uint32_t)seed + (uint32_t)ev_feet + (uint32_t)ev_penis + L.ebits[lane] + n_evidence)
 
     // ---- InferActionTags / EnsureRequiredFacets (Program.cs:731-775): both read the evidence only -------------------------
     bool frules_possible;
@@ -554,7 +555,7 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
             if (n_act == LEAN_DEAD) return LEAN_NO(11);
         } else if (fired && lane < t.fired_words) fired[lane] = 0;
     }
-    uint32_t f_val = LEAN_DEAD, f_fl = 0, f_len = 0;               // lane q: the tag facet q asks for
+    uint32_t f_val = LEAN_DEAD, f_fw = 0, f_tix = TIX_NONE;        // lane q: the tag facet q asks for
     {
         if (frules_possible) {
             for (uint32_t p0 = 0; p0 < t.n_frules; p0 += 64) {
@@ -568,7 +569,7 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
         if (lane < t.n_facets) {
             const uint32_t* fr = rc + t.rc_facets + RC_FACET_WORDS * lane;
             uint32_t fsel = fr[0];
-            f_fl = fr[3]; f_len = fr[4]; changes = fr[5] != 0;
+            f_fw = fr[6]; f_tix = fr[7]; changes = fr[5] != 0;
             uint16_t choice = 0xFFFF;
             if (frules_possible) {
                 const uint32_t rule_off = fr[1], rule_cnt = fr[2];
@@ -576,18 +577,20 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
                     const uint32_t p = rule_off + q;
                     if ((L.fhit[p >> 5] >> (p & 31)) & 1u) {
                         const uint32_t* pr = rc + t.rc_frules + p * RC_REC_WORDS;
-                        fsel = pr[0]; f_fl = pr[8]; f_len = pr[9]; changes = (pr[3] & 0x8000u) != 0;
+                        fsel = pr[0]; f_fw = pr[10]; f_tix = pr[11]; changes = (pr[3] & 0x8000u) != 0;
                         choice = (uint16_t)q;
                         break;
                     }
                 }
             }
             f_val = lean_val(1024 + lane, fsel, true);
+            if ((f_fw & FW_LEN_MASK) == FW_LEN_MASK) changes = true;   // a length the word has no room for
             if (facet_choice) facet_choice[lane] = choice;
         }
         if (w.ballot(changes) != 0) return LEAN_NO(12);             // a facet tag NormalizeTag changes
     }
     w.tick(22);
+    LEAN_STOP(3, f_val ^ f_fw ^ f_tix ^ n_act ^ n_dropped ^ style_n ^ (uint32_t)ev_feet)
 
     // ---- SelectTags' bucket fills (Program.cs:661-699) ------------------------------------------------------------------------
     uint32_t nr = t.n_prefix;
@@ -614,38 +617,40 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
     }
     w.sync();
     w.tick(20);
+    LEAN_STOP(4, f_val ^ f_fw ^ f_tix ^ n_act ^ n_dropped ^ nr ^ L.inv[lane])
 
     // ---- the selected tags by position; EvaluateCoverage (Program.cs:1056-1095) --------------------------------------------
     // position p < n_prefix: a prefix tag; else the candidate of lane inv[p]
     const bool in_sel = lane < nr;
-    uint32_t p_val = LEAN_DEAD, p_fl = FL_BLANK, p_len = 0;
-    uint32_t k_val[2] = {LEAN_DEAD, LEAN_DEAD}, k_fl[2] = {0, 0}, k_len[2] = {0, 0};
+    uint32_t p_val = LEAN_DEAD, p_fl = FL_BLANK, p_fw = FW_BLANK, p_tix = TIX_NONE;
+    uint32_t k_val[2] = {LEAN_DEAD, LEAN_DEAD}, k_fw[2] = {0, 0}, k_tix[2] = {TIX_NONE, TIX_NONE};
     uint32_t k_cnt = 0;
     if (in_sel) {
         if (lane >= t.n_prefix) {
-            const LeanCand& c = L.cand[L.inv[lane]];
-            p_val = lean_val(lane, c.id, true); p_fl = c.flags; p_len = c.len; k_cnt = c.step_cnt;
-            k_val[0] = lean_val(64 + 2 * lane, c.step0, c.step0 != NO_ID); k_val[1] = lean_val(65 + 2 * lane, c.step1, c.step1 != NO_ID);
-            // the steps' flags and lengths: asked for here, used after the first-occurrence pass
-            if (c.step0 != NO_ID) { k_fl[0] = t.attr2[2 * c.step0]; k_len[0] = t.attr2[2 * c.step0 + 1]; }
-            if (c.step1 != NO_ID) { k_fl[1] = t.attr2[2 * c.step1]; k_len[1] = t.attr2[2 * c.step1 + 1]; }
+            const uint32_t cl = L.inv[lane];
+            uint32_t c0[4], c1[4];
+            w.load16((const uint8_t*)&L.cr[0][cl], c0);
+            w.load16((const uint8_t*)&L.cr[1][cl], c1);
+            p_val = lean_val(lane, L.ids[cl], true); p_fl = c0[0]; p_fw = c0[1]; p_tix = (c0[2] >> 12) & TIX_NONE; k_cnt = (c0[2] >> 24) & 3u;
+            k_val[0] = lean_val(64 + 2 * lane, c1[0] & LEAN_ID_MASK, c1[0] != NO_ID); k_val[1] = lean_val(65 + 2 * lane, c1[1] & LEAN_ID_MASK, c1[1] != NO_ID);
+            k_tix[0] = c1[0] >> LEAN_ID_BITS; k_tix[1] = c1[1] >> LEAN_ID_BITS;
+            k_fw[0] = c1[2]; k_fw[1] = c1[3];                      // the steps' final-list words (zero for an absent step)
         } else {
-            p_val = lean_val(lane, S.prefix_ids[lane], true); p_fl = S.prefix_flags[lane]; p_len = S.prefix_len[lane];
+            p_val = lean_val(lane, S.prefix_ids[lane], true); p_fl = S.prefix_flags[lane]; p_fw = S.prefix_fw[lane]; p_tix = S.prefix_tix[lane];
         }
     }
     uint32_t coverage;
     {
-        const bool nb = in_sel && !(p_fl & FL_BLANK);
-        const uint32_t p_id = p_val & LEAN_ID_MASK;
-        const bool has_trigger = w.ballot(nb && p_id == t.trigger_id) != 0, has_girl = w.ballot(nb && p_id == t.girl_lit_id) != 0;
-        coverage = ((has_trigger && has_girl) ? TP_COV_IDENTITY : 0) | (w.ballot(nb && (p_fl & FL_HAIR)) ? TP_COV_HAIR : 0) |
-                   (w.ballot(nb && (p_fl & FL_EYES)) ? TP_COV_EYES : 0) | (w.ballot(nb && fl_bucket(p_fl) == B_OUTFIT) ? TP_COV_OUTFIT : 0) |
-                   (w.ballot(nb && fl_bucket(p_fl) == B_POSE) ? TP_COV_POSE_ACTION : 0) | (w.ballot(nb && fl_bucket(p_fl) == B_BACKGROUND) ? TP_COV_BACKGROUND : 0);
+        const uint32_t cv = w.or_all((in_sel && !(p_fw & FW_BLANK)) ? p_fw : 0u);
+        coverage = ((cv & FW_TRIGGER) && (cv & FW_GIRL) ? TP_COV_IDENTITY : 0) | ((cv & FW_HAIR) ? TP_COV_HAIR : 0) | ((cv & FW_EYES) ? TP_COV_EYES : 0) |
+                   ((cv & FW_OUTFIT) ? TP_COV_OUTFIT : 0) | ((cv & FW_POSE) ? TP_COV_POSE_ACTION : 0) | ((cv & FW_BACKGROUND) ? TP_COV_BACKGROUND : 0);
     }
     // a selected tag with FL_LEAF2 has steps NormalizeTag leaves alone and that lead nowhere further; the others' steps are followed one level down
     const bool deep = in_sel && (p_fl & FL_EDGE) && !(p_fl & FL_LEAF2);
     const bool any_deep = w.ballot(deep) != 0;
-    if (any_deep && lean_deep(w, t, L, deep, k_cnt, k_val[0], k_val[1], k_fl[0], k_fl[1])) return LEAN_NO(15);
+    if (!any_deep) { w.sync(); records_free(); }                    // (the deeper tags take the records' place)
+    if (any_deep && lean_deep(w, t, L, deep, k_cnt, k_val[0], k_val[1], k_fw[0], k_fw[1])) return LEAN_NO(15);
+    LEAN_STOP(5, f_val ^ f_fw ^ f_tix ^ n_act ^ n_dropped ^ nr ^ p_val ^ p_fl ^ p_fw ^ p_tix ^ k_val[0] ^ k_val[1] ^ k_fw[0] ^ k_fw[1] ^ k_tix[0] ^ k_tix[1] ^ coverage)
 
     // ---- the final set in the reference's insertion order (Program.cs:303-307): the selected tags, their implied tags by
     // position (and those one level further, by their parents' positions), the action tags by rule, the facet tags by
@@ -656,6 +661,21 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
     if (wide) {
         const LeanWide r = lean_first_wide(w, L, p_val, k_val[0], k_val[1], f_val, any_deep, n_act);
         fb = r.fb; grown2 = r.grown2; nact = r.nact;
+    } else if (t.n_tix <= LEAN_TIX_MAX) {
+        // Only a step or a facet tag can be in the list twice, and each of those strings has a target index: the lowest
+        // order per index, in a table indexed by it, says which element is the first of its string.  The selected tags are
+        // distinct and come first, so each of them is the first of its string; it enters the table only to be seen there.
+        static_assert(LEAN_TIX_MAX <= 2 * LeanLds::TAB && LEAN_TIX_MAX % 256 == 0, "the table area holds one word per target index");
+        TP_UNROLL for (uint32_t k = 0; k < LEAN_TIX_MAX / 256; ++k) w.fill16(&L.tab[256 * k + 4 * lane], 0xFFFFFFFFu);
+        w.sync();
+        const bool lk0 = k_val[0] != LEAN_DEAD, lk1 = k_val[1] != LEAN_DEAD, lf = f_val != LEAN_DEAD;
+        if (p_tix != TIX_NONE) w.lds_min(&L.tab[p_tix], p_val);
+        if (lk0) w.lds_min(&L.tab[k_tix[0]], k_val[0]);
+        if (lk1) w.lds_min(&L.tab[k_tix[1]], k_val[1]);
+        if (lf) w.lds_min(&L.tab[f_tix], f_val);
+        w.sync();
+        fb = (uint32_t)in_sel | (uint32_t)(lk0 && L.tab[lk0 ? k_tix[0] : 0] == k_val[0]) << 1 | (uint32_t)(lk1 && L.tab[lk1 ? k_tix[1] : 0] == k_val[1]) << 2 |
+             (uint32_t)(lf && L.tab[lf ? f_tix : 0] == f_val) << 3;
     } else {
         const uint32_t v4[4] = {p_val, k_val[0], k_val[1], f_val};
         fb = lean_first<4>(w, L, v4);
@@ -667,33 +687,33 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
     const uint32_t nf = nr + grown1 + grown2 + nact + nfac;
     if (nf > FAST_FIN_MAX) return LEAN_NO(14);
     w.tick(23);
+    LEAN_STOP(6, fb ^ nf ^ pos_k0 ^ rank_f ^ f_fw ^ n_dropped ^ p_fl ^ p_fw ^ k_fw[0] ^ k_fw[1] ^ coverage)
 
-    LeanAcc acc = {0, 0, 0xFFFFFFFFu, 0};
-    lean_emit(acc, t, fin32, (fb & 1u) != 0, p_val, p_fl, p_len, lane);
-    lean_emit(acc, t, fin32, (fb & 2u) != 0, k_val[0], k_fl[0], k_len[0], pos_k0);
-    lean_emit(acc, t, fin32, (fb & 4u) != 0, k_val[1], k_fl[1], k_len[1], pos_k0 + ((fb >> 1) & 1u));
-    lean_emit(acc, t, fin32, (fb & 8u) != 0, f_val, f_fl, f_len, nr + grown1 + grown2 + nact + rank_f);
+    LeanAcc acc = {0, 0xFFFFFFFFu, 0};
+    lean_emit(acc, fin32, (fb & 1u) != 0, p_val, p_fw, lane);
+    lean_emit(acc, fin32, (fb & 2u) != 0, k_val[0], k_fw[0], pos_k0);
+    lean_emit(acc, fin32, (fb & 4u) != 0, k_val[1], k_fw[1], pos_k0 + ((fb >> 1) & 1u));
+    lean_emit(acc, fin32, (fb & 8u) != 0, f_val, f_fw, nr + grown1 + grown2 + nact + rank_f);
     if (wide) {
         const LeanAcc wa = lean_emit_wide(w, t, L, fin32, fb, nr + grown1, nr + grown1 + grown2, any_deep, n_act);
-        acc.bytes += wa.bytes; acc.unknown += wa.unknown; acc.bits |= wa.bits; acc.safe_key = wa.safe_key < acc.safe_key ? wa.safe_key : acc.safe_key;
+        acc.sum += wa.sum; acc.bits |= wa.bits; acc.safe_key = wa.safe_key < acc.safe_key ? wa.safe_key : acc.safe_key;
     }
-    const bool face = (acc.bits & LA_FACE) != 0, outfit = (acc.bits & LA_OUTFIT) != 0, safe = (acc.bits & LA_SAFE) != 0, foot = (acc.bits & LA_FOOT) != 0;
-    uint32_t bytes = acc.bytes, unknown = acc.unknown;
-    const uint32_t safe_key = acc.safe_key;
+    const uint32_t all_bits = w.or_all(acc.bits);
+    const bool safe = (acc.bits & FW_SAFE) != 0;
     uint32_t flags = 0;
-    if (!(w.ballot(face) && w.ballot(outfit))) flags |= TP_F_LOW;
+    if (!((all_bits & FW_FACE) && (all_bits & FW_OUTFIT))) flags |= TP_F_LOW;
     int safe_hit = -1;
-    if (t.safe_mode && w.ballot(safe) != 0) {                       // first final tag in SafeModeRejectTags (Program.cs:942-945)
+    if (t.safe_mode && (all_bits & FW_SAFE)) {                      // first final tag in SafeModeRejectTags (Program.cs:942-945)
         if (lane == 0) L.scratch[0] = 0xFFFFFFFFu;
         w.sync();
-        if (safe) w.lds_min(&L.scratch[0], safe_key);
+        if (safe) w.lds_min(&L.scratch[0], acc.safe_key);
         w.sync();
         safe_hit = (int)(L.scratch[0] & 255u);
         flags |= TP_F_SAFE_REJECT;
     }
-    bytes = w.sum(bytes);
-    unknown = t.known_active ? w.sum(unknown) : 0u;
-    if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (w.ballot(foot) != 0) flags |= TP_F_FOOTJOB; }
+    const uint32_t sums = w.sum(acc.sum);
+    const uint32_t bytes = sums & ((1u << LA_UNKNOWN_SHIFT) - 1u), unknown = t.known_active ? sums >> LA_UNKNOWN_SHIFT : 0u;
+    if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (all_bits & FW_FOOTJOB) flags |= TP_F_FOOTJOB; }
     tp_verdict& v = out.verdict;
     v.coverage = (uint8_t)coverage;
     v.flags = (uint8_t)flags;
@@ -718,8 +738,15 @@ TP_HD bool lean_file(W& w, const TT& t, LeanFrontLds& LF, LeanLds& L, const Lean
     if (!lean_front(w, t, LF, S, text, len, x, row, n_cand)) return false;
     w.sync();
     const uint32_t id = w.lane() < n_cand ? row[w.lane()] : NO_ID;
+    if (w.lane() < n_cand) {
+        uint32_t c0[4], c1[4];
+        w.load16((const uint8_t*)(t.crec + 8 * (size_t)id), c0);
+        w.load16((const uint8_t*)(t.crec + 8 * (size_t)id + 4), c1);
+        w.store16((uint8_t*)&L.cr[0][w.lane()], c0);
+        w.store16((uint8_t*)&L.cr[1][w.lane()], c1);
+    }
     w.sync();
-    return lean_back(w, t, L, S, rc, id, n_cand, out, fin32, fired, facet_choice);
+    return lean_back(w, t, L, S, rc, id, n_cand, out, fin32, fired, facet_choice, []() {});
 }
 
 }  // namespace tp

@@ -1164,11 +1164,60 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     }
     out.attr2.assign(2 * (size_t)N, 0);
     for (uint32_t i = 0; i < N; ++i) { out.attr2[2 * i] = out.flags[i]; out.attr2[2 * i + 1] = out.str_off[i + 1] - out.str_off[i]; }
+    // final-list words and target indices (what can occur twice in a file's final list: steps, facet tags)
+    out.fw_tix.assign(2 * (size_t)N, 0);
+    {
+        std::vector<uint8_t> target(N, 0);
+        for (uint32_t x : out.step_ids) if (x < N) target[x] = 1;
+        for (size_t f = 0; f < ld.facets.size(); ++f) {
+            target[out.facets[f].def_id] = 1;
+            for (uint32_t k = 0; k < out.facets[f].rule_cnt; ++k) target[out.facet_rules[out.facets[f].rule_off + k].tag_id] = 1;
+        }
+        uint32_t n_tix = 0;
+        for (uint32_t i = 0; i < N; ++i) n_tix += target[i];
+        sc.n_tix = n_tix;
+        uint32_t next_tix = 0;
+        for (uint32_t i = 0; i < N; ++i) {
+            const uint32_t fl = out.flags[i], len = out.str_off[i + 1] - out.str_off[i], bk = fl_bucket(fl);
+            uint32_t fw = std::min<uint32_t>(len, FW_LEN_MASK);
+            if (bk == B_FACE) fw |= FW_FACE;
+            if (bk == B_OUTFIT) fw |= FW_OUTFIT;
+            if (bk == B_POSE) fw |= FW_POSE;
+            if (bk == B_BACKGROUND) fw |= FW_BACKGROUND;
+            if (fl & FL_SAFE) fw |= FW_SAFE | ((fl >> FL_SAFE_IDX_SHIFT) & 31u) << FW_SAFE_IDX_SHIFT;
+            if (i == sc.footjob_n) fw |= FW_FOOTJOB;
+            if (!(fl & FL_KNOWN)) fw |= FW_UNKNOWN;
+            if (i == sc.trigger_id) fw |= FW_TRIGGER;
+            if (i == sc.girl_lit_id) fw |= FW_GIRL;
+            if (fl & FL_HAIR) fw |= FW_HAIR;
+            if (fl & FL_EYES) fw |= FW_EYES;
+            if (fl & FL_BLANK) fw |= FW_BLANK;
+            if (fl & FL_FIX) fw |= FW_FIX;
+            if (fl & FL_EDGE) fw |= FW_EDGE;
+            out.fw_tix[2 * (size_t)i] = fw;
+            out.fw_tix[2 * (size_t)i + 1] = (target[i] && n_tix <= LEAN_TIX_MAX) ? next_tix++ : TIX_NONE;
+        }
+    }
     out.crec.assign(8 * (size_t)N, 0);
     for (uint32_t i = 0; i < N; ++i) {
         const Rec& rv = out.rec[i];
         uint32_t* cr = &out.crec[8 * (size_t)i];
-        cr[0] = rv.flags; cr[1] = rv.len; cr[2] = rv.lit; cr[3] = std::min<uint32_t>(rv.step_cnt, 3); cr[4] = rv.step0; cr[5] = rv.step1; cr[6] = rv.s0_info; cr[7] = rv.s1_info;
+        const bool edge = (rv.flags & FL_EDGE) != 0;
+        const uint32_t step0 = edge ? rv.step0 : NO_ID, step1 = edge ? rv.step1 : NO_ID;
+        auto len_of = [&](uint32_t id) { return id != NO_ID ? out.str_off[id + 1] - out.str_off[id] : 0u; };
+        auto info16 = [](uint32_t info) {                           // Rec::s0_info in 16 bits: literal index (CREC_LIT_NONE = none), feet-ness, penis-ness
+            const uint32_t li = info & 0xFFFFFFu;
+            return (li == 0xFFFFFFu || li >= CREC_LIT_NONE ? CREC_LIT_NONE : li) | ((info >> 24) & 3u) << 12;
+        };
+        auto step_word = [&](uint32_t id) { return id == NO_ID || id > LEAN_HEAD_ID_MASK ? NO_ID : id | out.fw_tix[2 * (size_t)id + 1] << 20; };
+        const bool too_long = rv.len >= FW_LEN_MASK || len_of(step0) >= FW_LEN_MASK || len_of(step1) >= FW_LEN_MASK;
+        cr[0] = rv.flags;
+        cr[1] = out.fw_tix[2 * (size_t)i];
+        cr[2] = (rv.lit == NO_ID || rv.lit >= CREC_LIT_NONE ? CREC_LIT_NONE : rv.lit) | out.fw_tix[2 * (size_t)i + 1] << 12 |
+                (edge ? std::min<uint32_t>(rv.step_cnt, 3) : 0u) << 24 | (too_long ? CREC_TOO_LONG : 0u);
+        cr[3] = info16(step0 != NO_ID ? rv.s0_info : 0xFFFFFFu) | info16(step1 != NO_ID ? rv.s1_info : 0xFFFFFFu) << 16;
+        cr[4] = step_word(step0); cr[5] = step_word(step1);
+        cr[6] = step0 != NO_ID ? out.fw_tix[2 * (size_t)step0] : 0; cr[7] = step1 != NO_ID ? out.fw_tix[2 * (size_t)step1] : 0;
     }
     out.lslots.clear();
     sc.lslot_shift = 31;
@@ -1250,6 +1299,8 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             rc[base + 3] = sub_cnt << 16;
             rc[base + 8] = out.flags[tag];
             rc[base + 9] = out.str_off[tag + 1] - out.str_off[tag];
+            rc[base + 10] = out.fw_tix[2 * (size_t)tag];
+            rc[base + 11] = out.fw_tix[2 * (size_t)tag + 1];
             if (out.next[tag] != tag || (out.flags[tag] & FL_BLANK)) rc[base + 3] |= 0x8000u;   // NormalizeTag does not leave this tag alone
             std::vector<uint32_t> lits;
             for (uint32_t k = 0; k < all_cnt; ++k) lits.push_back(out.pool[all_off + k]);
@@ -1286,6 +1337,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             rc.push_back(d); rc.push_back(out.facets[f].rule_off); rc.push_back(out.facets[f].rule_cnt);
             rc.push_back(out.flags[d]); rc.push_back(out.str_off[d + 1] - out.str_off[d]);
             rc.push_back((out.next[d] != d || (out.flags[d] & FL_BLANK)) ? 1u : 0u);
+            rc.push_back(out.fw_tix[2 * (size_t)d]); rc.push_back(out.fw_tix[2 * (size_t)d + 1]);
         }
         {   // positive-literal masks
             std::vector<uint32_t> rmask(sc.lit_words, 0), fmask(sc.lit_words, 0);
@@ -1453,6 +1505,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.emit_rec = ht.emit_rec.data();
     t.case_map = ht.case_map.data();
     t.crec = ht.crec.data();
+    t.fw_tix = ht.fw_tix.data();
     t.step_off = ht.step_off.data();
     t.step_ids = ht.step_ids.data();
     t.reach_off = ht.reach_off.data();

@@ -32,7 +32,7 @@ struct HostTables {
     std::vector<Rec> rec;
     std::vector<Slot> slots;
     std::vector<LeanSlot> lslots;           // empty when the two-choice placement failed
-    std::vector<uint32_t> attr2, crec;
+    std::vector<uint32_t> attr2, crec, fw_tix;
     std::vector<uint32_t> case_map;         // DevTables::case_map
     std::vector<uint32_t> emit_rec;         // DevTables::emit_rec
     std::vector<uint32_t> lkey_hi;          // DevTables::lkey_hi

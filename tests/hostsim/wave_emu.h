@@ -114,6 +114,7 @@ struct Wave {
     uint32_t shift_up(uint32_t v, uint32_t fill) { uint32_t r = shfl(v, lane() == 0 ? 0 : lane() - 1); return lane() == 0 ? fill : r; }
     uint32_t scan_incl(uint32_t v) { for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t o = shfl(v, lane() >= d ? lane() - d : lane()); if (lane() >= d) v += o; } return v; }
     uint32_t sum(uint32_t v) { for (uint32_t d = 32; d >= 1; d >>= 1) v += shfl(v, lane() ^ d); return v; }
+    uint32_t or_all(uint32_t v) { for (uint32_t d = 32; d >= 1; d >>= 1) v |= shfl(v, lane() ^ d); return v; }
     uint32_t rank(uint64_t m) { return (uint32_t)__builtin_popcountll(m & (lane() == 0 ? 0ull : (~0ull >> (64 - lane())))); }
 };
 
