@@ -357,8 +357,8 @@ struct DevTables {
                                  // each as id | target index << 20, or NO_ID; the final-list words of step0 and step1 (0 when absent)
                                  // (steps: the first two entries of the string's ExpandImpliedTags step list; absent without FL_EDGE)
     const uint32_t* fw_tix;      // per id, two words: the final-list word (FW_*), the target index or TIX_NONE
-    uint32_t n_tix;              // target indices in use: one per string that is a step of some string or a facet's default or rule tag
-                                 // (what can occur twice in a file's final list); above LEAN_TIX_MAX none are given out
+    uint32_t n_tix;              // target indices in use: one per string that is a step of a string NormalizeTag leaves alone, or a facet's default
+                                 // or rule tag (what can occur twice in the final list of a file of the lean stage); above LEAN_TIX_MAX none are given out
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:
     const uint32_t* step_ids;    //   NormalizeTag(it), then the implied tags of that (Program.cs:1164-1175); empty when nothing can change
     const uint32_t* reach_off;   // n_strings + 1: every other string the closure of {it} holds, as pairs

@@ -669,6 +669,7 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
         TP_UNROLL for (uint32_t k = 0; k < LEAN_TIX_MAX / 256; ++k) w.fill16(&L.tab[256 * k + 4 * lane], 0xFFFFFFFFu);
         w.sync();
         const bool lk0 = k_val[0] != LEAN_DEAD, lk1 = k_val[1] != LEAN_DEAD, lf = f_val != LEAN_DEAD;
+        if (w.ballot((lk0 && k_tix[0] >= LEAN_TIX_MAX) || (lk1 && k_tix[1] >= LEAN_TIX_MAX) || (lf && f_tix >= LEAN_TIX_MAX)) != 0) return LEAN_NO(13);   // (no such element exists)
         if (p_tix != TIX_NONE) w.lds_min(&L.tab[p_tix], p_val);
         if (lk0) w.lds_min(&L.tab[k_tix[0]], k_val[0]);
         if (lk1) w.lds_min(&L.tab[k_tix[1]], k_val[1]);

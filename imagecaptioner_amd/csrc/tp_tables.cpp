@@ -1168,7 +1168,9 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     out.fw_tix.assign(2 * (size_t)N, 0);
     {
         std::vector<uint8_t> target(N, 0);
-        for (uint32_t x : out.step_ids) if (x < N) target[x] = 1;
+        // (the lean stage's candidates are strings NormalizeTag leaves alone: only their steps can be among its list elements)
+        for (uint32_t i = 0; i < N; ++i)
+            if (out.flags[i] & FL_FIX) for (uint32_t m = out.step_off[i]; m < out.step_off[i + 1]; ++m) if (out.step_ids[m] < N) target[out.step_ids[m]] = 1;
         for (size_t f = 0; f < ld.facets.size(); ++f) {
             target[out.facets[f].def_id] = 1;
             for (uint32_t k = 0; k < out.facets[f].rule_cnt; ++k) target[out.facet_rules[out.facets[f].rule_off + k].tag_id] = 1;
@@ -1176,6 +1178,7 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         uint32_t n_tix = 0;
         for (uint32_t i = 0; i < N; ++i) n_tix += target[i];
         sc.n_tix = n_tix;
+        if (std::getenv("TAGPIPE_DEBUG_TABLES")) std::fprintf(stderr, "tagpipe tables: %u target indices (direct first-occurrence table up to %u)\n", n_tix, LEAN_TIX_MAX);
         uint32_t next_tix = 0;
         for (uint32_t i = 0; i < N; ++i) {
             const uint32_t fl = out.flags[i], len = out.str_off[i + 1] - out.str_off[i], bk = fl_bucket(fl);
@@ -1343,10 +1346,18 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             std::vector<uint32_t> rmask(sc.lit_words, 0), fmask(sc.lit_words, 0);
             sc.rules_vacuous = sc.frules_vacuous = 0;
             auto mark = [&](std::vector<uint32_t>& m, uint32_t off, uint32_t cnt) { for (uint32_t k = 0; k < cnt; ++k) { uint32_t li = out.pool[off + k]; m[li >> 5] |= 1u << (li & 31); } };
+            // An action rule with required literals fires only when all of them are in the evidence: one of them per rule is
+            // enough for the mask, and the one most rules share keeps the mask small (the built-in rules all require "penis").
+            std::unordered_map<uint32_t, uint32_t> all_uses;
+            for (uint32_t r = 0; r < n_rules; ++r) for (uint32_t k = 0; k < out.rules[r].all_cnt; ++k) ++all_uses[out.pool[out.rules[r].all_off + k]];
             for (uint32_t r = 0; r < n_rules; ++r) {
                 const DRule& d = out.rules[r];
                 if (d.all_cnt + d.any_cnt == 0) sc.rules_vacuous = 1;
-                mark(rmask, d.all_off, d.all_cnt); mark(rmask, d.any_off, d.any_cnt);
+                if (d.all_cnt) {
+                    uint32_t best = out.pool[d.all_off];
+                    for (uint32_t k = 1; k < d.all_cnt; ++k) { const uint32_t li = out.pool[d.all_off + k]; if (all_uses[li] > all_uses[best]) best = li; }
+                    rmask[best >> 5] |= 1u << (best & 31);
+                } else mark(rmask, d.any_off, d.any_cnt);
             }
             for (uint32_t k = 0; k < n_frules; ++k) {
                 const DSub& d = out.facet_rules[k];
