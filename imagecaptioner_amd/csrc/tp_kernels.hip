@@ -632,6 +632,19 @@ struct EmitCounts {
         low += (fl & TP_F_LOW) != 0; elig += (fl & TP_F_ELIGIBLE) != 0; foot += (fl & TP_F_FOOTJOB) != 0; fb += (fl & TP_F_FALLBACK) != 0;
         rej += (fl & TP_F_LINE_REJECTED) != 0; uns += (fl & TP_F_UNSUPPORTED) != 0; safe += (fl & TP_F_SAFE_REJECT) != 0;
     }
+    // The block's wavefronts add their counts up in LDS and one thread hands the sums on: every thread of the block must
+    // call this (it holds a block barrier).  One global atomic per wavefront and counter - thousands of wavefronts ending at
+    // about the same time, all on the same eight addresses - used to cost k_emit a fifth of its time.
+    __device__ void flush_block(tp_counters* out, unsigned long long* blk8) const {
+        if (threadIdx.x < 8) blk8[threadIdx.x] = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 0) {
+            const uint64_t v[8] = {files, low, elig, foot, fb, rej, uns, safe};
+            for (int k = 0; k < 8; ++k) if (v[k]) atomicAdd(&blk8[k], (unsigned long long)v[k]);
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && blk8[threadIdx.x]) atomicAdd((unsigned long long*)out + threadIdx.x, blk8[threadIdx.x]);
+    }
     __device__ void flush(tp_counters* out) const {
         unsigned long long* c = (unsigned long long*)out;
         if (files) atomicAdd(&c[0], (unsigned long long)files);
@@ -756,12 +769,13 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         }
         __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next file's are written
     }
-    if (a.counters && lane == 0) cnt.flush(a.counters);
+    __shared__ unsigned long long blk_cnt[8];
+    if (a.counters) cnt.flush_block(a.counters, blk_cnt);
 }
 
 // Tag histogram of the wave-kernel files: ids id0 .. id0 + HIST_IDS are counted in LDS (a tag occurs at most once per file,
 // so a block's 16-bit counters cannot overflow before HIST_FILES_PER_FLUSH files), then added to the global histogram.
-// Wider id ranges take further launches.  One wavefront per file, two files per step so that their loads overlap.
+// Wider id ranges take further launches.  One wavefront per file.
 // general != 0: the files of the general kernel whose ids its emit kernel left in the same rows are counted too.
 __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t id0, int general) {
     __shared__ uint32_t bins[HIST_IDS / 2];
@@ -774,21 +788,29 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
         const uint64_t c1 = c0 + HIST_FILES_PER_FLUSH < b1 ? c0 + HIST_FILES_PER_FLUSH : b1;
         for (uint32_t i = threadIdx.x; i < HIST_IDS / 2; i += blockDim.x) bins[i] = 0;
         __syncthreads();
-        for (uint64_t f = c0 + wave; f < c1; f += 2 * waves) {
-            const uint64_t g = f + waves;
-            const bool two = g < c1;
-            const uint32_t nf0 = a.n_final[f], nf1 = two ? a.n_final[g] : 0;
-            const bool fast0 = a.slot_of[f] == SLOT_FAST || (general && nf0 <= FAST_FIN_MAX);
-            const bool fast1 = two && (a.slot_of[g] == SLOT_FAST || (general && nf1 <= FAST_FIN_MAX));
-            const uint32_t* i0 = a.fin32 + (f - a.file0) * FAST_FIN_MAX;
-            const uint32_t* i1 = a.fin32 + ((two ? g : f) - a.file0) * FAST_FIN_MAX;
-            const uint32_t x0 = i0[lane], x1 = i0[lane + 64], y0 = i1[lane], y1 = i1[lane + 64];
+        // four files per step, so that their loads overlap; a lane takes two neighbouring ids of each (only the part of a
+        // row that holds ids is fetched)
+        constexpr int NF = 4;
+        for (uint64_t f = c0 + wave; f < c1; f += NF * waves) {
+            uint32_t nf[NF];
+            TP_UNROLL for (int k = 0; k < NF; ++k) {
+                const uint64_t g = f + (uint64_t)k * waves;
+                nf[k] = 0;
+                if (g < c1) {
+                    const uint32_t n = a.n_final[g];
+                    if (a.slot_of[g] == SLOT_FAST || (general && n <= FAST_FIN_MAX)) nf[k] = n;
+                }
+            }
+            uint2 x[NF];
+            TP_UNROLL for (int k = 0; k < NF; ++k) {
+                x[k] = make_uint2(0, 0);
+                if (2 * lane < nf[k]) x[k] = *(const uint2*)(a.fin32 + (f + (uint64_t)k * waves - a.file0) * FAST_FIN_MAX + 2 * lane);
+            }
             auto count = [&](uint32_t id, bool live) {
                 const uint32_t k = id - id0;
                 if (live && k < span) atomicAdd(&bins[k >> 1], 1u << (16 * (k & 1)));
             };
-            count(x0, fast0 && lane < nf0); count(x1, fast0 && lane + 64 < nf0);
-            count(y0, fast1 && lane < nf1); count(y1, fast1 && lane + 64 < nf1);
+            TP_UNROLL for (int k = 0; k < NF; ++k) { count(x[k].x, 2 * lane < nf[k]); count(x[k].y, 2 * lane + 1 < nf[k]); }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < (span + 1) / 2; i += blockDim.x) {
