@@ -255,8 +255,9 @@ enum : uint32_t {
     FW_SAFE = 1u << 12,        // SafeModeRejectTags member (Program.cs:942-945), its index in bits 13..17
     FW_SAFE_IDX_SHIFT = 13,
     FW_FOOTJOB = 1u << 18,     // the string NormalizeTag makes of "footjob" (Program.cs:309-311)
-    FW_UNKNOWN = 1u << 19,     // not in KnownTags (GetUnknownTags, Program.cs:817-824)
-    FW_TRIGGER = 1u << 20,     // the trigger tag          (EvaluateCoverage's identity test)
+    FW_TRIGGER = 1u << 19,     // the trigger tag          (EvaluateCoverage's identity test)
+    FW_UNKNOWN = 1u << 20,     // not in KnownTags (GetUnknownTags, Program.cs:817-824); the sum of a list's words under FW_SUM_MASK holds
+    FW_SUM_MASK = FW_LEN_MASK | FW_UNKNOWN,   //   its caption bytes in bits 0..19 and its unknown tags from bit 20 (at most 128 tags below 1023 bytes)
     FW_GIRL = 1u << 21,        // "1girl" as normalised
     FW_HAIR = 1u << 22, FW_EYES = 1u << 23, FW_POSE = 1u << 24, FW_BACKGROUND = 1u << 25,
     FW_BLANK = 1u << 26,       // FL_BLANK

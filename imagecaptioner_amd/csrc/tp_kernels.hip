@@ -726,7 +726,11 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
             if (blk == 1 && nfin <= 64) break;
             uint8_t* dst = stage + head + (blk ? tot0 : 0) + incl[blk] - seg[blk];
             const uint4 er = q0.rec[blk];
+#ifdef EMIT_X_NOLONG
+            const bool in_rec = true;
+#else
             const bool in_rec = (er.w >> 24) != 0xFFu;                // up to 15 bytes: the record holds them
+#endif
             const uint8_t* sp = t.str_bytes + (in_rec ? 0u : er.x);
             const uint32_t n = len[blk];
             // a longer string's first 32 bytes are fetched at once (the string arena has slack behind its end); stored exactly

@@ -200,17 +200,21 @@ TP_HD bool lean_rc_match(const uint32_t* ebits, const uint32_t* rc, uint32_t rec
 
 // What the final list's elements add up to: the OR of their final-list words (FW_*: bucket bits of MissingCoreBuckets,
 // Program.cs:1097-1101, safe-mode and footjob membership), caption bytes (low 20 bits of sum) and tags outside the
-// vocabulary (from bit 20), the first safe-mode hit.
-struct LeanAcc { uint32_t sum, safe_key, bits; };
+// vocabulary (from bit 20).
+struct LeanAcc { uint32_t sum, bits; };
 constexpr uint32_t LA_UNKNOWN_SHIFT = 20;
+static_assert(FW_UNKNOWN == 1u << LA_UNKNOWN_SHIFT, "a word's unknown bit sits where the sum counts unknown tags");
 TP_HD void lean_emit(LeanAcc& a, uint32_t* fin32, bool first, uint32_t val, uint32_t fw, uint32_t at) {
     if (first) {
         a.bits |= fw;
-        a.sum += (fw & FW_LEN_MASK) | ((fw / FW_UNKNOWN) & 1u) << LA_UNKNOWN_SHIFT;
-        if (fw & FW_SAFE) { const uint32_t key = (at << 8) | ((fw >> FW_SAFE_IDX_SHIFT) & 31u); a.safe_key = key < a.safe_key ? key : a.safe_key; }
+        a.sum += fw & FW_SUM_MASK;
         fin32[at] = val & LEAN_ID_MASK;
     }
 }
+// The first safe-mode hit of the final list (Program.cs:942-945) as position << 8 | index in SafeModeRejectTags; looked for
+// only in a file whose list holds such a tag at all.
+TP_HD uint32_t lean_safe_key(bool first, uint32_t fw, uint32_t at) { return first && (fw & FW_SAFE) ? (at << 8) | ((fw >> FW_SAFE_IDX_SHIFT) & 31u) : 0xFFFFFFFFu; }
+TP_HD uint32_t min32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // InferActionTags (Program.cs:731-753) for a file whose evidence holds a literal some rule tests positively: the tags of
 // the rules and subtypes that match go to L.act in rule order, their bits to `fired` (when asked for).  Returns how many
@@ -310,17 +314,23 @@ TP_HD TP_NOINLINE LeanWide lean_first_wide(W& w, LeanLds& L, uint32_t v0, uint32
 }
 // ... and what its deeper tags (from position base_g on) and action tags (from base_a on) add to the final list.
 template <class W, class TT>
-TP_HD TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uint32_t* fin32, uint32_t fb, uint32_t base_g, uint32_t base_a, bool any_deep, uint32_t n_act) {
+TP_HD TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uint32_t* fin32, uint32_t fb, uint32_t base_g, uint32_t base_a, bool any_deep, uint32_t n_act,
+                                         uint32_t& safe_key) {
     const uint32_t lane = w.lane();
-    LeanAcc a = {0, 0xFFFFFFFFu, 0};
+    LeanAcc a = {0, 0};
+    safe_key = 0xFFFFFFFFu;
     const uint64_t mg0 = w.ballot(fb & 16u), mg1 = w.ballot(fb & 32u), ma = w.ballot(fb & 64u);
     if (any_deep) {
         const LeanDeep g0 = L.deep[0][lane], g1 = L.deep[1][lane];
         const uint32_t pos_g0 = base_g + w.rank(mg0) + w.rank(mg1);
         lean_emit(a, fin32, (fb & 16u) != 0, g0.val, g0.fw, pos_g0);
         lean_emit(a, fin32, (fb & 32u) != 0, g1.val, g1.fw, pos_g0 + ((fb >> 4) & 1u));
+        safe_key = min32(lean_safe_key((fb & 16u) != 0, g0.fw, pos_g0), lean_safe_key((fb & 32u) != 0, g1.fw, pos_g0 + ((fb >> 4) & 1u)));
     }
-    if (lane < n_act) lean_emit(a, fin32, (fb & 64u) != 0, L.act[lane][0], L.act[lane][1], base_a + w.rank(ma));
+    if (lane < n_act) {
+        lean_emit(a, fin32, (fb & 64u) != 0, L.act[lane][0], L.act[lane][1], base_a + w.rank(ma));
+        safe_key = min32(safe_key, lean_safe_key((fb & 64u) != 0, L.act[lane][1], base_a + w.rank(ma)));
+    }
     return a;
 }
 
@@ -597,19 +607,33 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
     {
         const uint32_t style_cap = style_n < 2 ? 2u : (style_n > 4 ? 4u : style_n);
         const bool ok = nonblank && !bad && !(f & FL_PREFIX);       // AddOne's tests; prefix tags are already in
-        const uint32_t bk_own = fl_bucket(f);
-        bool taken = false;
-        uint32_t pos = 0;
-        TP_UNROLL for (uint32_t bk = 0; bk <= 6; ++bk) {           // FillBucket for the six capped buckets, then the final sweep (Program.cs:670-680)
-            const bool el = ok && !taken && (bk == 6 || bk_own == bk);
-            const uint64_t m = w.ballot(el);
+        // FillBucket for the six capped buckets (Program.cs:670-678): a candidate belongs to one of them at most, so each lane
+        // keeps its rank among its own bucket's candidates and that bucket's place and share (place << 8 | share); what a
+        // bucket takes depends on the room the buckets before it left, which is counted in scalar registers
+        const uint32_t key = ok ? fl_bucket(f) : 7u;
+        uint32_t rk = 0, share = 0;
+        TP_UNROLL for (uint32_t bk = 0; bk < 6; ++bk) {
+            const bool mine = key == bk;
+            const uint64_t m = w.ballot(mine);
             const uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0u;
-            const uint32_t cap = bk == 0 ? 3u : bk == 1 ? 10u : bk == 2 ? 8u : bk == 3 ? 6u : bk == 4 ? 4u : bk == 5 ? style_cap : 64u;
+            const uint32_t cap = bk == 0 ? 3u : bk == 1 ? 10u : bk == 2 ? 8u : bk == 3 ? 6u : bk == 4 ? 4u : style_cap;
             uint32_t take = popc64(m);
             take = take < cap ? take : cap;
             take = take < room ? take : room;
-            const uint32_t rk = w.rank(m);
-            if (el && rk < take) { taken = true; pos = nr + rk; }
+            rk = mine ? w.rank(m) : rk;
+            share = mine ? (nr << 8 | take) : share;
+            nr += take;
+        }
+        bool taken = key < 6u && rk < (share & 255u);
+        uint32_t pos = (share >> 8) + rk;
+        {                                                           // the final sweep over what is left, in candidate order (Program.cs:680)
+            const bool el = ok && !taken;
+            const uint64_t m = w.ballot(el);
+            const uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0u;
+            uint32_t take = popc64(m);
+            take = take < room ? take : room;
+            const uint32_t r6 = w.rank(m);
+            if (el && r6 < take) { taken = true; pos = nr + r6; }
             nr += take;
         }
         if (nr < 3) return LEAN_NO(7);                              // the minimal fallback line (Program.cs:297-298)
@@ -690,24 +714,27 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
     w.tick(23);
     LEAN_STOP(6, fb ^ nf ^ pos_k0 ^ rank_f ^ f_fw ^ n_dropped ^ p_fl ^ p_fw ^ k_fw[0] ^ k_fw[1] ^ coverage)
 
-    LeanAcc acc = {0, 0xFFFFFFFFu, 0};
+    LeanAcc acc = {0, 0};
+    const uint32_t pos_k1 = pos_k0 + ((fb >> 1) & 1u), pos_f = nr + grown1 + grown2 + nact + rank_f;
     lean_emit(acc, fin32, (fb & 1u) != 0, p_val, p_fw, lane);
     lean_emit(acc, fin32, (fb & 2u) != 0, k_val[0], k_fw[0], pos_k0);
-    lean_emit(acc, fin32, (fb & 4u) != 0, k_val[1], k_fw[1], pos_k0 + ((fb >> 1) & 1u));
-    lean_emit(acc, fin32, (fb & 8u) != 0, f_val, f_fw, nr + grown1 + grown2 + nact + rank_f);
+    lean_emit(acc, fin32, (fb & 4u) != 0, k_val[1], k_fw[1], pos_k1);
+    lean_emit(acc, fin32, (fb & 8u) != 0, f_val, f_fw, pos_f);
+    uint32_t wide_safe_key = 0xFFFFFFFFu;
     if (wide) {
-        const LeanAcc wa = lean_emit_wide(w, t, L, fin32, fb, nr + grown1, nr + grown1 + grown2, any_deep, n_act);
-        acc.sum += wa.sum; acc.bits |= wa.bits; acc.safe_key = wa.safe_key < acc.safe_key ? wa.safe_key : acc.safe_key;
+        const LeanAcc wa = lean_emit_wide(w, t, L, fin32, fb, nr + grown1, nr + grown1 + grown2, any_deep, n_act, wide_safe_key);
+        acc.sum += wa.sum; acc.bits |= wa.bits;
     }
     const uint32_t all_bits = w.or_all(acc.bits);
-    const bool safe = (acc.bits & FW_SAFE) != 0;
     uint32_t flags = 0;
     if (!((all_bits & FW_FACE) && (all_bits & FW_OUTFIT))) flags |= TP_F_LOW;
     int safe_hit = -1;
     if (t.safe_mode && (all_bits & FW_SAFE)) {                      // first final tag in SafeModeRejectTags (Program.cs:942-945)
+        const uint32_t safe_key = min32(min32(lean_safe_key((fb & 1u) != 0, p_fw, lane), lean_safe_key((fb & 2u) != 0, k_fw[0], pos_k0)),
+                                        min32(min32(lean_safe_key((fb & 4u) != 0, k_fw[1], pos_k1), lean_safe_key((fb & 8u) != 0, f_fw, pos_f)), wide_safe_key));
         if (lane == 0) L.scratch[0] = 0xFFFFFFFFu;
         w.sync();
-        if (safe) w.lds_min(&L.scratch[0], acc.safe_key);
+        if (safe_key != 0xFFFFFFFFu) w.lds_min(&L.scratch[0], safe_key);
         w.sync();
         safe_hit = (int)(L.scratch[0] & 255u);
         flags |= TP_F_SAFE_REJECT;
