@@ -225,6 +225,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         // their files differ: a few thousand files go four to a wavefront, many files 64 to a wavefront.
         uint32_t fpw = 64;
         while (fpw > 4 && (uint64_t)n_slow / fpw < 2048) fpw >>= 1;   // measured on 4000 files: 64 per wavefront 10.4 ms, 16: 8.3, 4: 6.5, 1: 8.6
+        if (n_slow <= 1024) fpw = 1;                                  // a few hundred files (456 of 200k c3c files): 1 per wavefront 2.9 ms, 2: 3.3, 4: 3.7, 8: 4.3
         if (const char* e = std::getenv("TAGPIPE_GENERAL_FPW")) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) fpw = (uint32_t)v; }   // testing aid
         const uint64_t spread_budget = std::min<uint64_t>(c->ws_budget, (uint64_t)4 << 30);   // a workspace row is 64 lanes wide however few hold a file
         uint64_t n_waves = 0, ws_bytes = 0;
