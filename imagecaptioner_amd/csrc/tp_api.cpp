@@ -609,6 +609,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         d.lkey_hi = upload(c->table_mem, h.lkey_hi);
         d.attr2 = upload(c->table_mem, h.attr2);
         d.emit_rec = upload(c->table_mem, h.emit_rec);
+        d.emit_rec32 = upload(c->table_mem, h.emit_rec32);
         d.case_map = upload(c->table_mem, h.case_map);
         d.crec = upload(c->table_mem, h.crec);
         d.fw_tix = upload(c->table_mem, h.fw_tix);

@@ -351,6 +351,8 @@ struct DevTables {
     uint32_t tables_hold_twins;  // some table string holds such a character
     const uint32_t* emit_rec;    // per id, four words, for the caption writer: a string of up to 15 bytes itself (zero-padded) with its length in byte 15;
                                  //   a longer one as {offset into str_bytes, byte length, 0, 0xFF << 24}
+    const uint32_t* emit_rec32;  // per id, eight words, for the caption writer: a string of up to 31 bytes itself (zero-padded) with its length in byte 31;
+                                 //   a longer one as {offset into str_bytes, byte length, 0 ..., 0xFF << 24}
     const uint32_t* attr2;       // per id: flags, byte length (two words)
     const uint32_t* crec;        // per id, eight words, for the lean stage's back half: flags; its final-list word (FW_*); Rec::lit (12 bits,
                                  // CREC_LIT_NONE = none) | its target index << 12 (12 bits, TIX_NONE = none) | min(step count, 3) << 24 | CREC_TOO_LONG;

@@ -777,6 +777,175 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
     if (a.counters) cnt.flush_block(a.counters, blk_cnt);
 }
 
+// The same files, several to a wavefront.  The captions of consecutive files are consecutive in the output, so a run of
+// wave-kernel files is one list of tags in which the last tag of each file is followed by the line end instead of ", ".
+// A wavefront takes a group of RUN_FILES consecutive files: as one run when all of them are wave-kernel files and the run
+// fits (RUN_BLOCKS lane blocks of tags, RUN_STAGE caption bytes), else file by file.  Lanes 0 .. RUN_FILES load the
+// group's sizes, kinds and offsets (one instruction each for the whole group, one group ahead); every lane block of the
+// run then loads its tags' ids, then their 32-byte caption records (strings up to 31 bytes inline), and only then the
+// text is put together in LDS at the output's 16-byte phase and stored 16 bytes per lane.  Per file this takes about
+// two thirds of the instructions of one file per wavefront (c2's 73 tags fill 1.14 of that kernel's two lane blocks) and
+// a third of its dependent memory round trips.
+constexpr int RUN_FILES = 4;
+constexpr int RUN_BLOCKS = 5;
+constexpr uint32_t RUN_TAGS = 64 * RUN_BLOCKS;
+constexpr uint32_t RUN_STAGE = 6144;
+static_assert(RUN_STAGE >= FAST_CAPTION_MAX && RUN_TAGS >= FAST_FIN_MAX, "a single file always fits a run");
+#ifndef TP_EMIT_RUNS_WAVES_PER_SIMD
+#define TP_EMIT_RUNS_WAVES_PER_SIMD 4      // 128 registers: the records of five lane blocks stay in registers (measured: 0.79 ms against 0.82 at five waves with spills)
+#endif
+__global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu(TP_EMIT_RUNS_WAVES_PER_SIMD))) void k_emit_runs(DevTables t, EmitArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[EMIT_WAVES][RUN_STAGE + 48];
+    __shared__ unsigned long long blk_cnt[8];
+    const uint32_t lane = threadIdx.x & 63;
+    uint8_t* stage = stage_all[wave_in_block()];
+    const uint64_t wave_global = wave_index();
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_groups = (a.file_end - a.file0 + RUN_FILES - 1) / RUN_FILES;
+    uint32_t cnt[4] = {0, 0, 0, 0};                                // lane j < RUN_FILES counts the files number j of its groups: counter k in the
+                                                                   // 16 bits k & 1 of word k >> 1 (a wavefront sees far fewer than 65536 groups)
+
+    struct Meta { uint32_t n, slot, fl; uint64_t off; };
+    auto load_meta = [&](uint64_t g, Meta& m) {
+        m.n = 0; m.slot = 0; m.fl = 0; m.off = 0;
+        if (g >= n_groups) return;
+        const uint64_t f = a.file0 + g * RUN_FILES + lane;
+        if (lane < (uint32_t)RUN_FILES && f < a.file_end) { m.n = a.n_final[f]; m.slot = a.slot_of[f]; m.fl = a.verdicts[f].flags; }
+        if (lane <= (uint32_t)RUN_FILES && f <= a.file_end) m.off = a.caption_offsets[f];
+    };
+    auto lane_of = [](uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); };
+    Meta m0, m1;
+    load_meta(wave_global, m0);
+    for (uint64_t g = wave_global; g < n_groups; g += n_waves, m0 = m1) {
+        load_meta(g + n_waves, m1);
+        const uint64_t row0 = g * RUN_FILES;                         // the group's first file, relative to file0
+        const uint64_t left = a.file_end - a.file0 - row0;
+        const uint32_t nfile = left < (uint64_t)RUN_FILES ? (uint32_t)left : (uint32_t)RUN_FILES;
+        const bool fast = lane < nfile && m0.slot == SLOT_FAST;
+        const uint32_t fastmask = (uint32_t)__ballot(fast ? 1 : 0);
+        if (fast) {
+            const uint32_t fl = m0.fl;
+            cnt[0] += 1u | (uint32_t)((fl & TP_F_LOW) != 0) << 16;
+            cnt[1] += (uint32_t)((fl & TP_F_ELIGIBLE) != 0) | (uint32_t)((fl & TP_F_FOOTJOB) != 0) << 16;
+            cnt[2] += (uint32_t)((fl & TP_F_FALLBACK) != 0) | (uint32_t)((fl & TP_F_LINE_REJECTED) != 0) << 16;
+            cnt[3] += (uint32_t)((fl & TP_F_UNSUPPORTED) != 0) | (uint32_t)((fl & TP_F_SAFE_REJECT) != 0) << 16;
+        }
+        if (fastmask == 0) continue;
+        uint32_t n_[RUN_FILES];
+        uint64_t off_[RUN_FILES + 1];
+        for (int j = 0; j < RUN_FILES; ++j) n_[j] = lane_of(m0.n, j);
+        for (int j = 0; j <= RUN_FILES; ++j) off_[j] = lane_of((uint32_t)m0.off, j) | (uint64_t)lane_of((uint32_t)(m0.off >> 32), j) << 32;
+        uint32_t tags_all = 0;
+        for (int j = 0; j < RUN_FILES; ++j) tags_all += ((fastmask >> j) & 1u) ? n_[j] : 0u;
+        const bool whole = fastmask == (1u << nfile) - 1u && tags_all <= RUN_TAGS && off_[nfile] - off_[0] <= (uint64_t)RUN_STAGE;
+        // the runs of the group: [0, nfile) as a whole, or every wave-kernel file by itself
+        for (uint32_t lo = 0; lo < nfile; lo = whole ? nfile : lo + 1) {
+            const uint32_t hi = whole ? nfile : lo + 1;
+            if (!whole && !((fastmask >> lo) & 1u)) continue;
+            uint32_t nn[RUN_FILES];
+            for (int j = 0; j < RUN_FILES; ++j) nn[j] = ((uint32_t)j >= lo && (uint32_t)j < hi) ? n_[j] : 0u;
+            const uint32_t c1 = nn[0], c2 = c1 + nn[1], c3 = c2 + nn[2], T = c3 + nn[3];
+            static_assert(RUN_FILES == 4, "the cumulative counts above are written out for four files");
+            uint64_t out0 = off_[0], out1 = off_[RUN_FILES];
+            for (int j = 1; j < RUN_FILES; ++j) { if ((uint32_t)j == lo) out0 = off_[j]; if ((uint32_t)j == hi) out1 = off_[j]; }
+            const uint32_t total = (uint32_t)(out1 - out0);
+            if (T == 0 || total == 0) continue;
+            const uint32_t head = (uint32_t)((uintptr_t)(a.captions + out0) & 15);
+
+            // which file and which of its tags a lane holds in each lane block; the ids, then the records
+            uint32_t id[RUN_BLOCKS];                                   // bit 31: the last tag of its file
+            TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
+                const uint32_t gi = 64u * b + lane;
+                const uint32_t j = (uint32_t)(gi >= c1) + (uint32_t)(gi >= c2) + (uint32_t)(gi >= c3);
+                const uint32_t cj = j == 0 ? 0u : j == 1 ? c1 : j == 2 ? c2 : c3, nj = j == 0 ? nn[0] : j == 1 ? nn[1] : j == 2 ? nn[2] : nn[3];
+                const uint32_t kb = gi - cj;
+                id[b] = 0;
+                if (64u * b < T && gi < T) {
+#ifdef RUNS_X_NOIDS
+                    const uint32_t v = (uint32_t)(row0 + j + kb) & 1023u;
+#else
+                    const uint32_t v = a.fin32[(row0 + j) * FAST_FIN_MAX + kb];
+#endif
+                    id[b] = (v < t.n_strings ? v : 0) | (uint32_t)(kb + 1 == nj) << 31;
+                }
+            }
+            uint4 r0[RUN_BLOCKS], r1[RUN_BLOCKS];
+            TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
+                r0[b] = make_uint4(0, 0, 0, 0); r1[b] = r0[b];
+                if (64u * b < T) {
+#ifdef RUNS_X_NOGATHER
+                    r0[b] = make_uint4(id[b], id[b] * 3u, id[b] * 5u, 7u); r1[b] = make_uint4(0, 0, 0, 12u << 24);
+#else
+                    const uint4* rp = (const uint4*)(t.emit_rec32 + 8 * (size_t)(id[b] & 0x7FFFFFFFu));
+                    r0[b] = rp[0]; r1[b] = rp[1];
+#endif
+                }
+            }
+            uint32_t at = head;                                        // where the lane block's text begins in the staging area
+            TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
+                if (64u * b >= T) break;
+                const bool live = 64u * b + lane < T;
+                const uint32_t lenb = r1[b].w >> 24;
+                const bool in_rec = lenb != 0xFFu;
+                const uint32_t n = live ? (in_rec ? lenb : r0[b].y) : 0u;
+                const bool last = (id[b] >> 31) != 0;
+                const uint32_t seg = live ? n + (last ? t.newline_len : 2u) : 0u;
+                const uint32_t incl = wave_scan_incl(seg);
+                uint8_t* dst = stage + at + incl - seg;
+                uint64_t v[4];
+                v[0] = r0[b].x | (uint64_t)r0[b].y << 32; v[1] = r0[b].z | (uint64_t)r0[b].w << 32;
+                v[2] = r1[b].x | (uint64_t)r1[b].y << 32; v[3] = r1[b].z | (uint64_t)(r1[b].w & 0xFFFFFFu) << 32;
+                const uint8_t* sp = t.str_bytes + (in_rec ? 0u : r0[b].x);
+                if (!in_rec && n) {                                    // longer than the record: its first 32 bytes at once (the string arena has slack behind its end)
+                    __builtin_memcpy(&v[0], sp, 16);
+                    __builtin_memcpy(&v[2], sp + 16, 16);
+                }
+                const uint32_t n32 = n < 32 ? n : 32, nfull = n32 >> 3;
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (k < nfull) __builtin_memcpy(dst + 8 * k, &v[k], 8);
+                if (n32 & 7) {                                           // the last, partial word in pieces of 4, 2 and 1 bytes
+                    uint64_t x = nfull == 0 ? v[0] : (nfull == 1 ? v[1] : (nfull == 2 ? v[2] : v[3]));
+                    uint32_t o = 8 * nfull;
+                    if (n32 & 4) { uint32_t y = (uint32_t)x; __builtin_memcpy(dst + o, &y, 4); x >>= 32; o += 4; }
+                    if (n32 & 2) { uint16_t y = (uint16_t)x; __builtin_memcpy(dst + o, &y, 2); x >>= 16; o += 2; }
+                    if (n32 & 1) dst[o] = (uint8_t)x;
+                }
+                for (uint32_t done = 32; done < n; ++done) dst[done] = sp[done];
+                if (live) {
+                    if (last) { for (uint32_t q = 0; q < t.newline_len; ++q) dst[n + q] = t.newline[q]; }
+                    else { dst[n] = ','; dst[n + 1] = ' '; }
+                }
+                at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staging area is this wave's own: no wait for global traffic
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint8_t* gbase = a.captions + out0 - head;                    // 16-byte aligned
+            const uint32_t end = head + total, nchunks = (end + 15) >> 4;
+#ifdef RUNS_X_NOSTORE
+            if (total == 0xFFFFFFFFu)
+#endif
+            for (uint32_t c = lane; c < nchunks; c += 64) {
+                if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
+            }
+            if (lane < 32) {                                              // the partial first and last pieces, one byte per lane
+                const uint32_t c = lane < 16 ? 0u : nchunks - 1;
+                const uint32_t off = 16 * c + (lane & 15);
+                const bool partial = !(16 * c >= head && 16 * c + 16 <= end) && (lane < 16 || nchunks > 1);
+                if (partial && off >= head && off < end) gbase[off] = stage[off];
+            }
+            __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next run's are written
+        }
+    }
+    if (a.counters) {                                                     // added up per block in LDS, then one global atomic per block and counter
+        if (threadIdx.x < 8) blk_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        if (lane < (uint32_t)RUN_FILES) for (int k = 0; k < 8; ++k) { const uint32_t v = (cnt[k >> 1] >> (16 * (k & 1))) & 0xFFFFu; if (v) atomicAdd(&blk_cnt[k], (unsigned long long)v); }
+        __syncthreads();
+        if (threadIdx.x < 8 && blk_cnt[threadIdx.x]) atomicAdd((unsigned long long*)a.counters + threadIdx.x, blk_cnt[threadIdx.x]);
+    }
+}
+
 // Tag histogram of the wave-kernel files: ids id0 .. id0 + HIST_IDS are counted in LDS (a tag occurs at most once per file,
 // so a block's 16-bit counters cannot overflow before HIST_FILES_PER_FLUSH files), then added to the global histogram.
 // Wider id ranges take further launches.  One wavefront per file.
@@ -992,7 +1161,14 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
         uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
         static const unsigned per_cu = [] { const char* e = getenv("TAGPIPE_EMIT_BLOCKS_PER_CU"); return e ? (unsigned)atoi(e) : (unsigned)TP_EMIT_WAVES_PER_SIMD; }();
         unsigned blocks = (unsigned)(want < 256 * per_cu ? want : 256 * per_cu);   // as many blocks (of four wavefronts) per CU as fit at once
-        hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
+        static const bool by_file = [] { const char* e = getenv("TAGPIPE_EMIT_BY_FILE"); return e && e[0] == '1'; }();   // testing aid: one file per wavefront
+        if (by_file) hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
+        else {
+            want = ((n + RUN_FILES - 1) / RUN_FILES + EMIT_WAVES - 1) / EMIT_WAVES;
+            static const unsigned runs_per_cu = [] { const char* e = getenv("TAGPIPE_EMIT_BLOCKS_PER_CU"); return e ? (unsigned)atoi(e) : (unsigned)TP_EMIT_RUNS_WAVES_PER_SIMD; }();
+            blocks = (unsigned)(want < 256 * runs_per_cu ? want : 256 * runs_per_cu);
+            hipLaunchKernelGGL(k_emit_runs, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

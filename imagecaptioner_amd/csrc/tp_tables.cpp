@@ -1162,6 +1162,17 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
             std::memcpy(r, b, 16);
         } else { r[0] = out.str_off[i]; r[1] = (uint32_t)str.size(); r[2] = 0; r[3] = 0xFFu << 24; }
     }
+    out.emit_rec32.assign(8 * (size_t)N + 8, 0);
+    for (uint32_t i = 0; i < N; ++i) {
+        const std::string& str = out.strings[i];
+        uint32_t* r = &out.emit_rec32[8 * (size_t)i];
+        if (str.size() <= 31) {
+            uint8_t b[32] = {0};
+            std::memcpy(b, str.data(), str.size());
+            b[31] = (uint8_t)str.size();
+            std::memcpy(r, b, 32);
+        } else { r[0] = out.str_off[i]; r[1] = (uint32_t)str.size(); r[7] = 0xFFu << 24; }
+    }
     out.attr2.assign(2 * (size_t)N, 0);
     for (uint32_t i = 0; i < N; ++i) { out.attr2[2 * i] = out.flags[i]; out.attr2[2 * i + 1] = out.str_off[i + 1] - out.str_off[i]; }
     // final-list words and target indices (what can occur twice in a file's final list: steps, facet tags)
@@ -1514,6 +1525,7 @@ DevTables bind_host_pointers(const HostTables& ht) {
     t.lkey_hi = ht.lkey_hi.data();
     t.attr2 = ht.attr2.data();
     t.emit_rec = ht.emit_rec.data();
+    t.emit_rec32 = ht.emit_rec32.data();
     t.case_map = ht.case_map.data();
     t.crec = ht.crec.data();
     t.fw_tix = ht.fw_tix.data();

@@ -35,6 +35,7 @@ struct HostTables {
     std::vector<uint32_t> attr2, crec, fw_tix;
     std::vector<uint32_t> case_map;         // DevTables::case_map
     std::vector<uint32_t> emit_rec;         // DevTables::emit_rec
+    std::vector<uint32_t> emit_rec32;       // DevTables::emit_rec32
     std::vector<uint32_t> lkey_hi;          // DevTables::lkey_hi
     std::vector<uint8_t> basic_fixed;       // per id: the string is a fixed point of the normalisation before the alias lookup
     std::vector<HtInfo> ht_info;
