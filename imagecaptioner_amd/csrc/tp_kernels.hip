@@ -1110,18 +1110,27 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
     // Wavefronts stride over the files.  Many more blocks than fit at once (measured best around 80 per CU): blocks that
     // finish early make room for others, which evens out the files' different costs.  Later stages usually find little to do.
     static const unsigned max_blocks = [] { const char* e = getenv("TAGPIPE_FAST_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
-    const unsigned cap = a.stage == 1 ? max_blocks : 256u * 8u;
+    // Behind the lean stage (a.tables is set) the stages find few files as a rule: smaller grids, so that blocks which find
+    // nothing to do are not what these launches cost.
+    static const unsigned after_lean1 = [] { const char* e = getenv("TAGPIPE_AFTER_LEAN_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
+    static const unsigned after_lean2 = [] { const char* e = getenv("TAGPIPE_AFTER_LEAN_BLOCKS2"); return e ? (unsigned)atoi(e) : 512u; }();
+    const bool after_lean = a.tables != nullptr && a.stage >= 1 && a.stage <= 3;
+    const unsigned cap = after_lean ? (a.stage == 1 ? after_lean1 : after_lean2) : (a.stage == 1 ? max_blocks : 256u * 8u);
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     const bool tr = a.triage != 0;
     if (a.stage == 0) {
-        static const unsigned lean_blocks_a = [] { const char* e = getenv("TAGPIPE_LEAN_A_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
-        static const unsigned lean_blocks_b = [] { const char* e = getenv("TAGPIPE_LEAN_B_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
-        want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK;
+        // (measured on 1M c2 files, blocks: front / back ms: 1280: 0.89 / 1.47, 4096: 0.74 / 1.41, 20480: 0.71 / 1.33, 81920: 0.72 / 1.45)
+        static const unsigned lean_blocks_a = [] { const char* e = getenv("TAGPIPE_LEAN_A_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
+        static const unsigned lean_blocks_b = [] { const char* e = getenv("TAGPIPE_LEAN_B_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
+        // about a dozen files per wavefront (shorter loops leave the wavefronts of a CU in different phases of their files; far
+        // fewer files per wavefront and the per-block set-up and the per-wavefront hand-over of declined files begin to show)
+        want = (n + 12 * LEAN_WAVES_PER_BLOCK - 1) / (12 * LEAN_WAVES_PER_BLOCK);
+        if (want < 256u * 5u) want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK < 256u * 5u ? (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK : 256u * 5u;
         hipLaunchKernelGGL(k_lean_a, dim3((unsigned)(want < lean_blocks_a ? want : lean_blocks_a)), dim3(64 * LEAN_WAVES_PER_BLOCK), 0, s, a);
         if (between) { hipError_t e = hipEventRecord(between, s); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(k_lean_b, dim3((unsigned)(want < lean_blocks_b ? want : lean_blocks_b)), dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
     } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
-    else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
+    else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < (after_lean ? after_lean2 : 4096u) ? n : (after_lean ? after_lean2 : 4096u))), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     return hipGetLastError();
