@@ -961,11 +961,10 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
         const uint64_t c1 = c0 + HIST_FILES_PER_FLUSH < b1 ? c0 + HIST_FILES_PER_FLUSH : b1;
         for (uint32_t i = threadIdx.x; i < HIST_IDS / 2; i += blockDim.x) bins[i] = 0;
         __syncthreads();
-        // four files per step, so that their loads overlap; a lane takes two neighbouring ids of each (only the part of a
-        // row that holds ids is fetched)
-        constexpr int NF = 4;
-        for (uint64_t f = c0 + wave; f < c1; f += NF * waves) {
-            uint32_t nf[NF];
+        // eight files per step, so that their loads overlap; a lane takes two neighbouring ids of each (only the part of a
+        // row that holds ids is fetched); the sizes that say which part are loaded one step ahead
+        constexpr int NF = 8;
+        auto sizes = [&](uint64_t f, uint32_t (&nf)[NF]) {
             TP_UNROLL for (int k = 0; k < NF; ++k) {
                 const uint64_t g = f + (uint64_t)k * waves;
                 nf[k] = 0;
@@ -974,6 +973,11 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
                     if (a.slot_of[g] == SLOT_FAST || (general && n <= FAST_FIN_MAX)) nf[k] = n;
                 }
             }
+        };
+        uint32_t nf[NF], nf_next[NF];
+        sizes(c0 + wave, nf);
+        for (uint64_t f = c0 + wave; f < c1; f += NF * waves) {
+            sizes(f + NF * waves, nf_next);
             uint2 x[NF];
             TP_UNROLL for (int k = 0; k < NF; ++k) {
                 x[k] = make_uint2(0, 0);
@@ -984,6 +988,7 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
                 if (live && k < span) atomicAdd(&bins[k >> 1], 1u << (16 * (k & 1)));
             };
             TP_UNROLL for (int k = 0; k < NF; ++k) { count(x[k].x, 2 * lane < nf[k]); count(x[k].y, 2 * lane + 1 < nf[k]); }
+            TP_UNROLL for (int k = 0; k < NF; ++k) nf[k] = nf_next[k];
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < (span + 1) / 2; i += blockDim.x) {
