@@ -44,8 +44,12 @@ def main():
         if not k.startswith("k_"):
             continue
         kernels[k] = {c: {"avg": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()}
-    # HBM bytes of one step: every kernel's (2 x FETCH + WRITE) x launches, over the number of steps (k_emit runs once a step)
-    steps = kernels.get("k_emit", {}).get("FETCH_SIZE", {}).get("launches", 0)
+    # HBM bytes of one step: every kernel's (2 x FETCH + WRITE) x launches, over the number of steps (the caption writer runs once a step)
+    steps = 0
+    for once_a_step in ("k_emit_runs", "k_emit", "k_lean_a", "k_fast"):
+        steps = kernels.get(once_a_step, {}).get("FETCH_SIZE", {}).get("launches", 0)
+        if steps:
+            break
     if steps:
         total = 0.0
         per_kernel = {}
