@@ -242,7 +242,8 @@ def _picks(total, pool_n, seed, zipf_s=None):
 
 
 def make_corpus(name, n_files, seed=1234):
-    """One of the benchmark configurations (c1..c5, and c3c: c3 with the alias chains inside the vocabulary) as a Corpus."""
+    """One of the benchmark configurations (c1..c5; c3c: c3 with the alias chains inside the vocabulary; c2n: c2 without a
+    vocabulary file) as a Corpus."""
     name = name.lower()
     if name == "c1":
         with open(os.path.join(REFERENCE_DATA, "top_tags.txt"), "r", encoding="utf-8") as f:
@@ -254,7 +255,7 @@ def make_corpus(name, n_files, seed=1234):
                    required_facets=os.path.join(REFERENCE_DATA, "rules", "required_facets.json"),
                    profile=os.path.join(REFERENCE_DATA, "profiles", "sgrui.json"), vocabulary=os.path.join(REFERENCE_DATA, "top_tags.txt"),
                    minimal_subject_tags="1girl, solo")
-    elif name in ("c2", "c4"):
+    elif name in ("c2", "c4", "c2n"):
         vocab = make_vocabulary(20000, seed=1)
         lex = make_lexicon(vocab, 20000, seed=2)
         pool = vocab + list(lex["aliases"].keys())[:2000]          # alias keys do occur in the input
@@ -262,6 +263,9 @@ def make_corpus(name, n_files, seed=1234):
         picks = _picks(int(counts.sum()), len(pool), seed, zipf_s=1.1 if name == "c4" else None)
         cfg = dict(lexicon=json.dumps(lex).encode(), vocabulary=("\n".join(vocab) + "\n").encode(), vocabulary_is_json=0,
                    minimal_subject_tags="1girl, solo")
+        if name == "c2n":
+            # c2 without a vocabulary file: no strict vocabulary, so the tags in no table (a third of the pool) are kept
+            cfg["vocabulary"] = None
     elif name in ("c3", "c3c"):
         vocab = make_vocabulary(50000, seed=1)
         lex = make_lexicon(vocab, 100000, seed=2, chains=True)

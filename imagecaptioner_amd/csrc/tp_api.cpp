@@ -90,6 +90,14 @@ struct tp_ctx {
     DevTables dt;
     DevBuf dt_dev;                   // dt again, in device memory (the lean stage reads it from there)
     std::vector<void*> table_mem;
+    // Strings learned from the input (see learn_unknown_strings below)
+    tp_config cfg{};                                 // a copy of the configuration, its strings and blobs held in cfg_text
+    std::vector<std::unique_ptr<std::string>> cfg_text;
+    std::vector<std::string> public_strings;         // the configuration's interned strings (what tp_get_string hands out pointers into)
+    std::vector<std::string> learned;                // in the order they were learned
+    std::unordered_map<std::string, uint32_t> learned_set;
+    DevBuf unk_keys, unk_ent, unk_count, unk_out;
+    bool learning = false;
     WorkBufs own;                    // grown with hipMalloc as runs need them
     WorkBufs fixed;                  // pieces of this device's static scratch array: tp_run_lines_device_noalloc works in these
     WorkBufs* w = &own;
@@ -111,6 +119,7 @@ struct tp_ctx {
         for (void* p : table_mem) (void)hipFree(p);
         own.release();
         if (host_scalars) (void)hipHostFree(host_scalars);
+        for (DevBuf* b : {&unk_keys, &unk_ent, &unk_count, &unk_out}) b->release();
         for (DevBuf* b : {&dt_dev, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
                           &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits})
@@ -432,7 +441,7 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
             if (n_files) HIP_OK(hipMemcpyAsync(c->in_secondary.p, secondary_begin, n_files * 8, hipMemcpyHostToDevice, s));
         }
     }
-    const size_t hist_n = (size_t)t.n_strings + 1;
+    const size_t hist_n = (size_t)t.n_public + 1;
     c->out_offsets.need((n_files + 1) * 8);
     c->out_verdicts.need(std::max<uint64_t>(n_files, 1) * sizeof(tp_verdict));
     c->out_hist.need(hist_n * 8);
@@ -495,7 +504,7 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     out->verdicts = r->verdicts.data();
     out->counters = ctr;
     out->histogram = r->histogram.data();
-    out->histogram_other = r->histogram[t.n_strings];
+    out->histogram_other = r->histogram[t.n_public];
     out->fired = r->fired.data();
     out->facet_choice = r->facet_choice.data();
     out->opaque = r.release();
@@ -550,6 +559,131 @@ extern "C" {
 
 const char* tp_last_error(void) { return g_error.c_str(); }
 
+// Tags in no table, learned.  A run without a strict vocabulary keeps such tags, and a wave kernel that meets one hands
+// its file to the thread-per-file kernel, which is a hundred times slower per file.  The lean stage therefore notes every
+// such string once (DevTables::unk_keys), the entry points that take tag lines collect them when a run is over, and the
+// tables are compiled again with those strings interned behind the configuration's own (same ids for those, same attributes
+// for the new ones as the pipeline computes for a string in no table, counted with the tags in no table in the histogram).
+// The files of the run that met them went the slow way; later runs find them in the tables.
+constexpr uint32_t UNK_SLOTS = 1u << 20, UNK_HARVEST = 1u << 18, UNK_LEARN_MAX = 400000;
+
+void own_config(tp_ctx* c, const tp_config& cfg) {
+    c->cfg = cfg;
+    auto keep = [&](const char*& p) { if (p) { c->cfg_text.emplace_back(new std::string(p)); p = c->cfg_text.back()->c_str(); } };
+    auto keep_src = [&](tp_source& src) {
+        keep(src.path);
+        if (src.data) { c->cfg_text.emplace_back(new std::string((const char*)src.data, (size_t)src.len)); src.data = (const uint8_t*)c->cfg_text.back()->data(); }
+    };
+    for (tp_source* src : {&c->cfg.lexicon, &c->cfg.actions, &c->cfg.required_facets, &c->cfg.profile, &c->cfg.vocabulary, &c->cfg.allowlist, &c->cfg.denylist}) keep_src(*src);
+    keep(c->cfg.trigger); keep(c->cfg.auto_prefix_tags); keep(c->cfg.minimal_subject_tags); keep(c->cfg.newline);
+}
+
+void attach_unknown_set(tp_ctx* c) {
+    c->dt.unk_keys = c->learning ? c->unk_keys.as<unsigned long long>() : nullptr;
+    c->dt.unk_ent = c->learning ? c->unk_ent.as<unsigned long long>() : nullptr;
+    c->dt.unk_count = c->learning ? c->unk_count.as<uint32_t>() : nullptr;
+    c->dt.unk_mask = UNK_SLOTS - 1;
+    HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));
+}
+
+// Compiles the configuration (plus the learned strings) and puts the result in place of the context's tables.
+void load_tables(tp_ctx* c, const std::vector<std::string>* learned) {
+    HostTables fresh;
+    compile_tables(c->cfg, fresh, learned);
+    std::vector<void*> old_mem;
+    old_mem.swap(c->table_mem);
+    c->ht = std::move(fresh);
+    c->string_ids.clear();
+    const HostTables& h = c->ht;
+    DevTables& d = c->dt;
+    d = h.scalars;
+    d.str_bytes = upload(c->table_mem, h.str_bytes);
+    d.str_off = upload(c->table_mem, h.str_off);
+    d.flags = upload(c->table_mem, h.flags);
+    d.next = upload(c->table_mem, h.next);
+    d.alias1 = upload(c->table_mem, h.alias1);
+    d.lit = upload(c->table_mem, h.lit);
+    d.imp_off = upload(c->table_mem, h.imp_off);
+    d.imp_ids = upload(c->table_mem, h.imp_ids);
+    d.ht_hash = upload(c->table_mem, h.ht_hash);
+    d.ht_id = upload(c->table_mem, h.ht_id);
+    d.dfa_next = upload(c->table_mem, h.dfa_next);
+    d.dfa_out = upload(c->table_mem, h.dfa_out);
+    d.pool = upload(c->table_mem, h.pool);
+    d.rules = upload(c->table_mem, h.rules);
+    d.subs = upload(c->table_mem, h.subs);
+    d.facets = upload(c->table_mem, h.facets);
+    d.facet_rules = upload(c->table_mem, h.facet_rules);
+    d.rec = upload(c->table_mem, h.rec);
+    d.ht_info = upload(c->table_mem, h.ht_info);
+    d.str_words = upload(c->table_mem, h.str_words);
+    d.rc = upload(c->table_mem, h.rule_cache);
+    d.slots = upload(c->table_mem, h.slots);
+    d.lslots = h.lslots.empty() ? nullptr : upload(c->table_mem, h.lslots);
+    d.lkey_hi = upload(c->table_mem, h.lkey_hi);
+    d.attr2 = upload(c->table_mem, h.attr2);
+    d.emit_rec = upload(c->table_mem, h.emit_rec);
+    d.emit_rec32 = upload(c->table_mem, h.emit_rec32);
+    d.case_map = upload(c->table_mem, h.case_map);
+    d.crec = upload(c->table_mem, h.crec);
+    d.fw_tix = upload(c->table_mem, h.fw_tix);
+    d.step_off = upload(c->table_mem, h.step_off);
+    d.step_ids = upload(c->table_mem, h.step_ids);
+    d.reach_off = upload(c->table_mem, h.reach_off);
+    d.reach_ent = upload(c->table_mem, h.reach_ent);
+    compute_fallback(c);
+    c->use_lean = lean_ok(c->dt);
+    if (const char* b = std::getenv("TAGPIPE_NO_LEAN")) if (b[0] == '1') c->use_lean = false;
+    c->dt_dev.need(sizeof(DevTables));
+    HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));
+    for (void* p : old_mem) (void)hipFree(p);
+}
+
+// After a run over tag lines: the strings the lean stage noted are collected and, when there are new ones, the tables are
+// compiled again with them.  The stream must be idle.
+int learn_unknown_strings(tp_ctx* c, hipStream_t s) {
+    if (!c->learning) return TP_OK;
+    uint32_t noted = 0;
+    HIP_OK(hipMemcpy(&noted, c->unk_count.p, 4, hipMemcpyDeviceToHost));
+    if (noted == 0) return TP_OK;
+    uint32_t* d_out_count = c->unk_count.as<uint32_t>() + 1;
+    HIP_OK(hipMemsetAsync(c->unk_count.p, 0, 8, s));
+    HIP_OK(launch_collect_unknown(c->unk_keys.as<unsigned long long>(), c->unk_ent.as<unsigned long long>(), UNK_SLOTS, c->unk_out.as<uint8_t>(), UNK_HARVEST, d_out_count, s));
+    uint32_t got = 0;
+    HIP_OK(hipMemcpyAsync(&got, d_out_count, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    got = std::min(got, UNK_HARVEST);
+    std::vector<uint8_t> recs((size_t)got * 40);
+    if (got) HIP_OK(hipMemcpy(recs.data(), c->unk_out.p, recs.size(), hipMemcpyDeviceToHost));
+    if (c->string_ids.empty()) c->string_ids = index_strings(c->ht);
+    size_t fresh = 0;
+    for (uint32_t i = 0; i < got; ++i) {
+        uint32_t n = 0;
+        std::memcpy(&n, &recs[(size_t)i * 40 + 32], 4);
+        if (n == 0 || n > 32) continue;
+        std::string str((const char*)&recs[(size_t)i * 40], n);
+        if (c->string_ids.count(str) || c->learned_set.count(str)) continue;
+        c->learned_set.emplace(str, (uint32_t)c->learned.size());
+        c->learned.push_back(std::move(str));
+        ++fresh;
+    }
+    if (fresh == 0) return TP_OK;
+    if (c->learned.size() > UNK_LEARN_MAX) {                       // no room for more: what is learned so far stays, nothing further is noted
+        c->learned.resize(c->learned.size() - fresh);
+        c->learning = false;
+        attach_unknown_set(c);
+        return TP_OK;
+    }
+    const tp_timing run_timing = c->timing;                        // (the tables' load evaluates the fallback line with a run of its own)
+    const uint64_t run_slow = c->last_slow;
+    load_tables(c, &c->learned);
+    c->timing = run_timing;
+    c->last_slow = run_slow;
+    if (!c->use_lean) c->learning = false;
+    attach_unknown_set(c);
+    return TP_OK;
+}
+
 void tp_config_init(tp_config* cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof *cfg);
@@ -579,49 +713,19 @@ tp_ctx* tp_create(const tp_config* cfg) {
         HIP_OK(hipHostMalloc((void**)&c->host_scalars, 64, hipHostMallocDefault));
         std::memset(c->host_scalars, 0, 64);
         bind_fixed(c.get());
-        compile_tables(*cfg, c->ht);
-        const HostTables& h = c->ht;
-        DevTables& d = c->dt;
-        d = h.scalars;
-        d.str_bytes = upload(c->table_mem, h.str_bytes);
-        d.str_off = upload(c->table_mem, h.str_off);
-        d.flags = upload(c->table_mem, h.flags);
-        d.next = upload(c->table_mem, h.next);
-        d.alias1 = upload(c->table_mem, h.alias1);
-        d.lit = upload(c->table_mem, h.lit);
-        d.imp_off = upload(c->table_mem, h.imp_off);
-        d.imp_ids = upload(c->table_mem, h.imp_ids);
-        d.ht_hash = upload(c->table_mem, h.ht_hash);
-        d.ht_id = upload(c->table_mem, h.ht_id);
-        d.dfa_next = upload(c->table_mem, h.dfa_next);
-        d.dfa_out = upload(c->table_mem, h.dfa_out);
-        d.pool = upload(c->table_mem, h.pool);
-        d.rules = upload(c->table_mem, h.rules);
-        d.subs = upload(c->table_mem, h.subs);
-        d.facets = upload(c->table_mem, h.facets);
-        d.facet_rules = upload(c->table_mem, h.facet_rules);
-        d.rec = upload(c->table_mem, h.rec);
-        d.ht_info = upload(c->table_mem, h.ht_info);
-        d.str_words = upload(c->table_mem, h.str_words);
-        d.rc = upload(c->table_mem, h.rule_cache);
-        d.slots = upload(c->table_mem, h.slots);
-        d.lslots = h.lslots.empty() ? nullptr : upload(c->table_mem, h.lslots);
-        d.lkey_hi = upload(c->table_mem, h.lkey_hi);
-        d.attr2 = upload(c->table_mem, h.attr2);
-        d.emit_rec = upload(c->table_mem, h.emit_rec);
-        d.emit_rec32 = upload(c->table_mem, h.emit_rec32);
-        d.case_map = upload(c->table_mem, h.case_map);
-        d.crec = upload(c->table_mem, h.crec);
-        d.fw_tix = upload(c->table_mem, h.fw_tix);
-        d.step_off = upload(c->table_mem, h.step_off);
-        d.step_ids = upload(c->table_mem, h.step_ids);
-        d.reach_off = upload(c->table_mem, h.reach_off);
-        d.reach_ent = upload(c->table_mem, h.reach_ent);
-        compute_fallback(c.get());
-        c->use_lean = lean_ok(c->dt);
-        c->dt_dev.need(sizeof(DevTables));
-        HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));
-        if (const char* b = std::getenv("TAGPIPE_NO_LEAN")) if (b[0] == '1') c->use_lean = false;
+        own_config(c.get(), *cfg);
+        load_tables(c.get(), nullptr);
+        c->public_strings = c->ht.strings;
+        // Tags in no table are kept when no strict vocabulary drops them; the lean stage notes the ones it meets so that
+        // later calls find them interned (TAGPIPE_NO_LEARN=1: off)
+        c->learning = c->use_lean && !c->dt.drop_unknown;
+        if (const char* b = std::getenv("TAGPIPE_NO_LEARN")) if (b[0] == '1') c->learning = false;
+        if (c->learning) {
+            c->unk_keys.need((size_t)UNK_SLOTS * 8); c->unk_ent.need((size_t)UNK_SLOTS * 8); c->unk_count.need(64); c->unk_out.need((size_t)UNK_HARVEST * 40);
+            HIP_OK(hipMemset(c->unk_keys.p, 0, (size_t)UNK_SLOTS * 8));
+            HIP_OK(hipMemset(c->unk_count.p, 0, 64));
+            attach_unknown_set(c.get());
+        }
         return TP_OK;
     });
     if (rc != TP_OK) return nullptr;
@@ -633,7 +737,7 @@ void tp_destroy(tp_ctx* ctx) { delete ctx; }
 int tp_get_table_info(const tp_ctx* ctx, tp_table_info* out) {
     if (!ctx || !out) return fail(TP_E_INVALID_ARG, "null argument");
     const DevTables& t = ctx->dt;
-    out->n_strings = t.n_strings;
+    out->n_strings = t.n_public;                                   // learned strings have no histogram entry of their own and no public id
     out->n_action_rules = t.n_rules;
     out->n_action_subtypes = t.n_subs;
     out->n_facets = t.n_facets;
@@ -645,9 +749,9 @@ int tp_get_table_info(const tp_ctx* ctx, tp_table_info* out) {
 }
 
 int tp_get_string(const tp_ctx* ctx, uint32_t id, const char** utf8, uint32_t* len) {
-    if (!ctx || !utf8 || !len || id >= ctx->dt.n_strings) return fail(TP_E_INVALID_ARG, "bad string id");
-    *utf8 = ctx->ht.strings[id].c_str();
-    *len = (uint32_t)ctx->ht.strings[id].size();
+    if (!ctx || !utf8 || !len || id >= ctx->public_strings.size()) return fail(TP_E_INVALID_ARG, "bad string id");
+    *utf8 = ctx->public_strings[id].c_str();
+    *len = (uint32_t)ctx->public_strings[id].size();
     return TP_OK;
 }
 
@@ -677,7 +781,11 @@ int tp_get_name(const tp_ctx* ctx, int kind, uint32_t index, const char** utf8, 
 int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uint64_t n_files, tp_result* out) {
     if (!ctx || !out || !offsets || (n_files && offsets[n_files] && !arena)) return fail(TP_E_INVALID_ARG, "null argument");
     for (uint64_t i = 0; i < n_files; ++i) if (offsets[i + 1] < offsets[i]) return fail(TP_E_INVALID_ARG, "offsets must be non-decreasing");
-    return guarded([&]() { return run_host(ctx, arena, offsets[n_files], offsets, n_files + 1, nullptr, nullptr, nullptr, 0, n_files, out); });
+    return guarded([&]() {
+        const int rc = run_host(ctx, arena, offsets[n_files], offsets, n_files + 1, nullptr, nullptr, nullptr, 0, n_files, out);
+        if (rc == TP_OK) { const int lrc = learn_unknown_strings(ctx, nullptr); if (lrc != TP_OK) return lrc; }
+        return rc;
+    });
 }
 
 int tp_run_merged(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin,
@@ -816,7 +924,9 @@ int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_b
         r.captions = io->captions; r.caption_capacity = io->caption_capacity; r.grow_captions = false;
         r.caption_offsets = io->caption_offsets; r.verdicts = io->verdicts; r.histogram = io->histogram; r.counters = io->counters;
         r.fired = io->fired; r.facet_choice = io->facet_choice; r.stream = (hipStream_t)io->stream; r.mode = 0;
-        return run_device(ctx, r, caption_bytes);
+        const int rc = run_device(ctx, r, caption_bytes);
+        if (rc == TP_OK || rc == TP_E_CAPACITY) { const int lrc = learn_unknown_strings(ctx, r.stream); if (lrc != TP_OK) return lrc; }
+        return rc;
     });
 }
 

@@ -300,6 +300,15 @@ constexpr uint32_t FAST_FRULES_MAX = 512;      // facet rules the wave-per-file 
 struct DevTables {
     // interned strings
     uint32_t n_strings;
+    uint32_t n_public;           // ids below this are the configuration's strings (what the tag histogram has a count for); ids from here on are
+                                 // strings learned from earlier input (tp_api.cpp): counted with the tags in no table
+    // Tokens in no table that the lean stage meets while such tags are kept (no strict vocabulary) are noted here, once per
+    // string: a set of 64-bit hashes (0 = free) with the address and length of one occurrence each (address | length << 56).
+    // Null when nothing is to be noted.
+    unsigned long long* unk_keys;
+    unsigned long long* unk_ent;
+    uint32_t* unk_count;
+    uint32_t unk_mask;           // slots - 1
     const uint8_t* str_bytes;
     const uint32_t* str_off;     // n_strings + 1
     const uint32_t* flags;       // FL_*

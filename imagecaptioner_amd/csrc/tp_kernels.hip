@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     __shared__ DeclineBuf dbuf[LEAN_WAVES_PER_BLOCK];
     ConstTables& t = *(ConstTables*)(uintptr_t)a.tables;
     lean_shared_init(t, shared, threadIdx.x, blockDim.x);
+    if ((threadIdx.x & 63u) == 0) lds[wave_in_block()].cpos[LEAN_CPOS_NOTE] = 0;
     __syncthreads();
     uint32_t n_declined = 0;
     LeanFrontLds& L = lds[wave_in_block()];
@@ -236,12 +237,19 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
         if (len1 != 0xFFFFFFFFu) lean_fetch(w, a.arena + o1, len1, x1);
         bool done = false;
         uint32_t n_cand = 0;
+        const uint64_t fo_off = o0;
+        const uint32_t fo_len = len0;
         if (len0 != 0xFFFFFFFFu) done = lean_front(w, t, L, shared, a.arena + o0, len0, x0, a.fin32 + i * FAST_FIN_MAX, n_cand);
         o0 = o1; len0 = len1; o1 = o2; len1 = len2;
         x0[0] = x1[0]; x0[1] = x1[1]; x0[2] = x1[2]; x0[3] = x1[3];
         if (done) {
             if (w.lane() == 0) { a.n_final[f] = n_cand; a.slot_of[f] = SLOT_LEAN; }
         } else {
+            if (t.unk_keys != nullptr && fo_len != 0xFFFFFFFFu && L.cpos[LEAN_CPOS_NOTE] != 0) {   // declined over plain tokens in no table: note them
+                lean_note_tokens(w, t, L, a.arena + fo_off, fo_len);
+                w.sync();
+                if (w.lane() == 0) L.cpos[LEAN_CPOS_NOTE] = 0;
+            }
             decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
         }
         w.sync();
@@ -953,7 +961,9 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
 __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t id0, int general) {
     __shared__ uint32_t bins[HIST_IDS / 2];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    const uint32_t span = t.n_strings - id0 < HIST_IDS ? t.n_strings - id0 : HIST_IDS;
+    const uint32_t span = t.n_public - id0 < HIST_IDS ? t.n_public - id0 : HIST_IDS;
+    __shared__ uint32_t learned;                                // tags that are learned strings: counted with the tags in no table (first pass only)
+    if (threadIdx.x == 0) learned = 0;
     const uint64_t n = a.file_end - a.file0;
     const uint64_t per_block = (n + gridDim.x - 1) / gridDim.x;
     const uint64_t b0 = a.file0 + per_block * blockIdx.x, b1 = b0 + per_block < a.file_end ? b0 + per_block : a.file_end;
@@ -975,6 +985,7 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
             }
         };
         uint32_t nf[NF], nf_next[NF];
+        uint32_t n_learned = 0;
         sizes(c0 + wave, nf);
         for (uint64_t f = c0 + wave; f < c1; f += NF * waves) {
             sizes(f + NF * waves, nf_next);
@@ -986,11 +997,14 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
             auto count = [&](uint32_t id, bool live) {
                 const uint32_t k = id - id0;
                 if (live && k < span) atomicAdd(&bins[k >> 1], 1u << (16 * (k & 1)));
+                n_learned += (uint32_t)(live && id0 == 0 && id >= t.n_public && id < t.n_strings);
             };
             TP_UNROLL for (int k = 0; k < NF; ++k) { count(x[k].x, 2 * lane < nf[k]); count(x[k].y, 2 * lane + 1 < nf[k]); }
             TP_UNROLL for (int k = 0; k < NF; ++k) nf[k] = nf_next[k];
         }
+        if (n_learned) atomicAdd(&learned, n_learned);
         __syncthreads();
+        if (threadIdx.x == 0 && learned) { atomicAdd((unsigned long long*)&a.histogram[t.n_public], (unsigned long long)learned); learned = 0; }
         for (uint32_t i = threadIdx.x; i < (span + 1) / 2; i += blockDim.x) {
             const uint32_t v = bins[i];
             if (v & 0xFFFFu) atomicAdd((unsigned long long*)&a.histogram[id0 + 2 * i], (unsigned long long)(v & 0xFFFFu));
@@ -1068,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
     }
     if (a.histogram) {
         for (int d = 32; d >= 1; d >>= 1) c_other += __shfl_xor(c_other, d);
-        if (lane == 0 && c_other) atomicAdd((unsigned long long*)&a.histogram[t.n_strings], (unsigned long long)c_other);
+        if (lane == 0 && c_other) atomicAdd((unsigned long long*)&a.histogram[t.n_public], (unsigned long long)c_other);
     }
     if (a.counters && lane == 0) cnt.flush(a.counters);
 }
@@ -1103,6 +1117,26 @@ hipError_t noalloc_scratch(int device, void** ptr, size_t* bytes) {
     }
     *ptr = known[device];
     return hipSuccess;
+}
+
+// The strings the lean stage noted (tp_lean.h, lean_note_unknown): every used slot's text goes to `out` and the slot is freed.
+__global__ __launch_bounds__(256) void k_collect_unknown(unsigned long long* keys, const unsigned long long* ent, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots || keys[i] == 0) return;
+    keys[i] = 0;
+    const unsigned long long e = ent[i];
+    const uint8_t* p = (const uint8_t*)(uintptr_t)(e & 0x00FFFFFFFFFFFFFFull);
+    const uint32_t n = (uint32_t)(e >> 56);
+    const uint32_t at = atomicAdd(out_count, 1u);
+    if (at >= out_cap || n == 0 || n > 32 || p == nullptr) return;
+    uint8_t* o = out + (size_t)at * 40;
+    for (uint32_t k = 0; k < 32; ++k) o[k] = k < n ? p[k] : 0;
+    *(uint32_t*)(o + 32) = n;
+    *(uint32_t*)(o + 36) = 0;
+}
+hipError_t launch_collect_unknown(unsigned long long* keys, const unsigned long long* ent, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_collect_unknown, dim3((slots + 255) / 256), dim3(256), 0, s, keys, ent, slots, out, out_cap, out_count);
+    return hipGetLastError();
 }
 
 uint32_t fast_fin_stride() { return FAST_FIN_MAX; }
@@ -1195,7 +1229,7 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
         uint64_t hb = (n + 1023) / 1024;                      // a block is worth launching for a thousand files
         unsigned hblocks = (unsigned)(hb < 256 ? hb : 256);   // one per CU: the counters take most of its LDS
         const int general = a.n_items ? 1 : 0;
-        for (uint32_t id0 = 0; id0 < t.n_strings; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0, general);
+        for (uint32_t id0 = 0; id0 < t.n_public; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0, general);
     }
     return hipGetLastError();
 }

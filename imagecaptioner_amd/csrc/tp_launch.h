@@ -119,6 +119,9 @@ uint64_t scan_tiles_needed(uint64_t n);
 hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_t s);
 hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s);
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s);
+// The strings noted in DevTables::unk_keys / unk_ent, as records of 40 bytes {32 bytes of text, length, 0} in `out` (at most
+// out_cap of them; *out_count receives how many there were); the set is emptied.
+hipError_t launch_collect_unknown(unsigned long long* keys, const unsigned long long* ent, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count, hipStream_t s);
 uint32_t fast_fin_stride();
 bool lean_ok(const DevTables& t);   // the lean stage (tp_lean.h) can serve this configuration
 

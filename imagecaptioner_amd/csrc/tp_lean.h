@@ -72,9 +72,11 @@ struct LeanCr { uint32_t w[4]; };
 struct LeanDeep { uint32_t val, fw, pad0, pad1; };
 
 // The front half's LDS state per wavefront (line scan, token lookup, Distinct) ...
+constexpr uint32_t LEAN_CPOS_NOTE = 67;
 struct alignas(16) LeanFrontLds {
     uint8_t line[16 + 1024 + 48];             // 16 spare bytes in front, 64 pieces, slack for 32-byte token reads
-    uint32_t cpos[68];                        // cpos[1 + k]: position of comma k in the text; cpos[0] = -1, cpos[T] = len
+    uint32_t cpos[68];                        // cpos[1 + k]: position of comma k in the text; cpos[0] = -1, cpos[T] = len;
+                                              // cpos[LEAN_CPOS_NOTE]: set when the file was declined over plain tokens in no table
     static constexpr uint32_t TAB_BITS = 8, TAB = 1u << TAB_BITS;   // slots per min-order table
     uint32_t tab[2 * TAB];                    // two min-order tables
 };
@@ -172,6 +174,49 @@ TP_HD bool lean_plain_unknown(const uint8_t* p, uint32_t n) {
         prev = c;
     }
     return true;
+}
+
+// A token in no table that this stage has to decline because such tags are kept (no strict vocabulary): noted once per
+// string in DevTables::unk_keys (64-bit hash, 0 = free; linear probing) with where it stands, so that the host can add it
+// to the tables for later runs.  p: the token in the input (device memory that outlives the run), n <= 32 bytes.
+template <class TT>
+TP_HD void lean_note_unknown(const TT& t, const uint8_t* p, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t h1 = 2166136261u, h2 = 0x9E3779B9u ^ n;               // two byte-wise 32-bit hashes
+    for (uint32_t k = 0; k < n; ++k) { const uint32_t c = p[k]; h1 = (h1 ^ c) * 16777619u; h2 = (h2 + c) * 0x85EBCA77u; h2 ^= h2 >> 15; }
+    const unsigned long long h = ((unsigned long long)h1 << 32 | h2) | 1ull;
+    uint32_t slot = (h1 ^ (h2 >> 7)) & t.unk_mask;
+    for (uint32_t probe = 0; probe < 32; ++probe) {
+        const unsigned long long old = atomicCAS(&t.unk_keys[slot], 0ull, h);
+        if (old == 0ull) {
+            t.unk_ent[slot] = (unsigned long long)(uintptr_t)p | (unsigned long long)n << 56;
+            atomicAdd(t.unk_count, 1u);
+            return;
+        }
+        if (old == h) return;
+        slot = (slot + 1) & t.unk_mask;
+    }
+#else
+    (void)t; (void)p; (void)n;
+#endif
+}
+// The plain tokens of a file that lean_front has just declined over such tokens (L still holds its line and commas),
+// noted whether a table holds them or not: the host leaves out what it knows.  A pass of its own, for declined files
+// only, so that the front half itself carries none of this.
+template <class W, class TT>
+TP_HD void lean_note_tokens(W& w, const TT& t, LeanFrontLds& L, const uint8_t* text, uint32_t len) {
+    const uint32_t lane = w.lane();
+    const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
+    const uint8_t* s = L.line + 16 + shift;
+    uint32_t T = 0;
+    for (uint32_t k = 1; k <= 65; ++k) if (L.cpos[k] == len) { T = k; break; }   // cpos[T] = len (commas lie below len)
+    if (lane < T) {
+        uint32_t i = L.cpos[lane] + 1, j = L.cpos[lane + 1];
+        if (i < j && ws1(s[i])) ++i;
+        if (j > i && ws1(s[j - 1])) --j;
+        const uint32_t n = j - i;
+        if (n >= 1 && n <= 32 && lean_plain_unknown(s + i, n)) lean_note_unknown(t, text + i, n);
+    }
 }
 
 // One record of the rule cache against the evidence bitset (MatchesFacetRule and its kin, Program.cs:777-794).
@@ -442,7 +487,13 @@ TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, c
         if (w.ballot(miss) != 0) {
             // in no table as it stands: dropped under strict vocabulary, provided it is plain (then normalisation leaves it
             // alone and it is in no table at all); otherwise the general stages normalise it
-            if (miss && !(t.drop_unknown && lean_plain_unknown(s + i2, n))) decline = true;
+            bool keep_it = false;                                   // a plain token in no table, and such tags are kept: declined, and worth noting
+            if (miss) {
+                const bool plain = lean_plain_unknown(s + i2, n);
+                if (!(t.drop_unknown && plain)) decline = true;
+                keep_it = plain && !t.drop_unknown;
+            }
+            if (w.ballot(keep_it) != 0 && lane == 0) L.cpos[LEAN_CPOS_NOTE] = 1;
         }
         // LooksBad's phrases and code fences are looked for in the raw line (Program.cs:592-596): any token holding one declines
         if (id != NO_ID && (f & (FL_PHRASE | FL_FENCE))) decline = true;

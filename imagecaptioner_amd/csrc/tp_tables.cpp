@@ -687,7 +687,7 @@ bool less_ordinal_ignore_case(const std::string& a, const std::string& b) {
     return folded(from_utf8((const uint8_t*)a.data(), a.size())) < folded(from_utf8((const uint8_t*)b.data(), b.size()));
 }
 
-void compile_tables(const tp_config& cfg, HostTables& out) {
+void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std::string>* learned) {
     Loader ld;
     try {
         // ---- Main's load sequence, Program.cs:156-165 ----
@@ -754,12 +754,26 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
         for (auto& tok : split_tags(fl)) in.id(normalize_basic(tok));
     }
     // close under NormalizeTagBasic, the alias lookup and NormalizeTag
-    for (size_t i = 0; i < in.text.size(); ++i) {
-        W s = in.text[i];
-        in.id(ld.alias_of(s));
-        W nb = normalize_basic(s);
-        in.id(nb);
-        in.id(ld.alias_of(nb));
+    size_t closed = 0;
+    auto close = [&]() {
+        for (; closed < in.text.size(); ++closed) {
+            W s = in.text[closed];
+            in.id(ld.alias_of(s));
+            W nb = normalize_basic(s);
+            in.id(nb);
+            in.id(ld.alias_of(nb));
+        }
+    };
+    close();
+    const uint32_t n_public = (uint32_t)in.text.size();
+    if (learned) {
+        for (const std::string& u : *learned) {
+            const W wu = from_utf8((const uint8_t*)u.data(), u.size());
+            if (in.exact.count(wu) || in.by_fold.count(folded(wu))) continue;
+            if (blank(wu) || normalize_basic(wu) != wu) continue;     // only strings that normalisation leaves alone are learned
+            in.id(wu);
+        }
+        close();
     }
     const uint32_t N = (uint32_t)in.text.size();
 
@@ -940,6 +954,8 @@ void compile_tables(const tp_config& cfg, HostTables& out) {
     DevTables& sc = out.scalars;
     std::memset(&sc, 0, sizeof sc);
     sc.n_strings = N;
+    sc.n_public = n_public;
+    sc.unk_keys = nullptr; sc.unk_ent = nullptr; sc.unk_count = nullptr; sc.unk_mask = 0;
     sc.ht_mask = slots - 1;
     sc.n_lits = n_lits;
     sc.lit_words = (n_lits + 31) / 32;
@@ -1423,7 +1439,7 @@ void set_fallback(const HostTables& ht, DevTables& dt, const uint32_t* ids, uint
 
 std::string top_tags_text(const HostTables& h, const uint64_t* histogram) {
     std::vector<uint32_t> ids;
-    for (uint32_t i = 0; i < (uint32_t)h.strings.size(); ++i) if (histogram[i]) ids.push_back(i);
+    for (uint32_t i = 0; i < h.scalars.n_public; ++i) if (histogram[i]) ids.push_back(i);
     std::sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
         if (histogram[a] != histogram[b]) return histogram[a] > histogram[b];
         return h.strings[a] < h.strings[b];

@@ -55,7 +55,10 @@ struct HostTables {
 };
 
 // Throws ConfigError (malformed JSON or table content this build cannot represent).
-void compile_tables(const tp_config& cfg, HostTables& out);
+// learned: strings met in the input that are in none of the configuration's tables (UTF-8; see tp_api.cpp), interned behind
+// every string of the configuration (ids below DevTables::n_public are the same with and without them) with the attributes
+// the pipeline computes for such a string; one that an interned string already covers is skipped.
+void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std::string>* learned = nullptr);
 
 // Stores the SelectTags result of the minimal fallback line (ids, evaluated by the pipeline kernel at load time) and
 // derives the final-set form the wave-per-file kernel starts from.

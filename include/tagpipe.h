@@ -192,6 +192,19 @@ typedef struct tp_result {
  * Line ingest (ParseTagCandidatesFromLine, Program.cs:574-587): file i's raw
  * text is arena[offsets[i] .. offsets[i+1]).  Host pointers; the call uploads,
  * runs the kernels and downloads the result.
+ *
+ * Tags in no table.  When no strict vocabulary drops them (no vocabulary file,
+ * or --strict-known-tags off: Program.cs:999-1002, 1131) such tags are kept,
+ * and a file that holds one takes the slow thread-per-file kernel.  This call
+ * and tp_run_lines_device therefore note the plain strings of that kind they
+ * meet ([a-z0-9_()!/-], up to 32 bytes) and, when the run is over, compile the
+ * context's tables again with those strings added, so that later calls find
+ * them.  Nothing a caller can see changes by that: results are the same
+ * before and after, the configuration's strings keep their ids, n_strings
+ * and the histogram's length stay as tp_get_table_info reported them, and a
+ * learned tag is counted in histogram_other like any tag in no table.  The
+ * compile takes a few tenths of a second and happens only after a call that
+ * met new strings.  TAGPIPE_NO_LEARN=1 in the environment turns this off.
  */
 int tp_run_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, uint64_t n_files, tp_result* out);
 
@@ -306,7 +319,9 @@ int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_b
  * tp_get_last_timing reports zeros after this call.  Every context on a GPU
  * shares that GPU's array: calls that overlap in time on one GPU race, also
  * from different contexts or streams; the array keeps the last call's contents
- * and the call clears what it needs cleared.
+ * and the call clears what it needs cleared.  The call does not compile tables
+ * again (see tp_run_lines on tags in no table): what it meets is learned by
+ * the next tp_run_lines / tp_run_lines_device call on the context.
  */
 #define TP_NOALLOC_MAX_FILES 16384
 int tp_run_lines_device_noalloc(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes);

@@ -44,6 +44,8 @@ def sim_lib():
         L.sim_last_error.restype = C.c_char_p
         L.sim_create.restype = C.c_void_p
         L.sim_create.argtypes = [C.POINTER(tp_config)]
+        L.sim_create_learned.restype = C.c_void_p
+        L.sim_create_learned.argtypes = [C.POINTER(tp_config), C.c_char_p, C.c_uint64]
         L.sim_destroy.argtypes = [C.c_void_p]
         L.sim_info.argtypes = [C.c_void_p, C.POINTER(tp_table_info)]
         L.sim_string.restype = C.c_char_p
@@ -76,10 +78,16 @@ class SimResult:
 class HostSim:
     """The kernel's per-file pipeline source compiled for the host (tests/hostsim) — logic checks only."""
 
-    def __init__(self, config):
+    def __init__(self, config, learned=None):
+        """learned: strings interned behind the configuration's own, as the library does with the strings in no table that it
+        meets in its input."""
         self._cfg = config
         self._L = sim_lib()
-        self._h = self._L.sim_create(C.byref(config.struct))
+        if learned is None:
+            self._h = self._L.sim_create(C.byref(config.struct))
+        else:
+            blob = "\n".join(learned).encode("utf-8")
+            self._h = self._L.sim_create_learned(C.byref(config.struct), blob, len(blob))
         if not self._h:
             raise RuntimeError(self._L.sim_last_error().decode("utf-8", "replace"))
         self.info = tp_table_info()

@@ -54,7 +54,7 @@ void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint
     o.verdicts.assign(n, tp_verdict{});
     o.fired.assign(std::max<size_t>(n * t.fired_words, 1), 0);   // never empty: a non-null pointer asks for the detail outputs
     o.facets.assign(n * t.n_facets, 0xFFFF);
-    o.hist.assign((size_t)t.n_strings + 1, 0);
+    o.hist.assign((size_t)t.n_public + 1, 0);
     std::memset(&o.ctr, 0, sizeof o.ctr);
     if (fin_lists) fin_lists->assign(n, {});
     for (uint64_t w0 = 0; w0 < n; w0 += 64) {
@@ -84,8 +84,8 @@ void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint
                 for (uint32_t k = 0; k < fo.n_final; ++k) {
                     H h = ws.fin[k];
                     if (k) { o.captions.push_back(','); o.captions.push_back(' '); }
-                    if (h_is_dyn(h)) { o.captions.insert(o.captions.end(), ws.norm + h_off(h), ws.norm + h_off(h) + h_len(h)); o.hist[t.n_strings]++; }
-                    else { const uint8_t* p = str_ptr(t, h_id(h)); o.captions.insert(o.captions.end(), p, p + str_len(t, h_id(h))); o.hist[h_id(h)]++; }
+                    if (h_is_dyn(h)) { o.captions.insert(o.captions.end(), ws.norm + h_off(h), ws.norm + h_off(h) + h_len(h)); o.hist[t.n_public]++; }
+                    else { const uint8_t* p = str_ptr(t, h_id(h)); o.captions.insert(o.captions.end(), p, p + str_len(t, h_id(h))); o.hist[std::min<uint32_t>(h_id(h), t.n_public)]++; }
                 }
                 o.captions.insert(o.captions.end(), t.newline, t.newline + t.newline_len);
                 if (o.captions.size() - before != fo.caption_len) { g_err = "caption_len mismatch"; }
@@ -105,10 +105,17 @@ extern "C" {
 
 const char* sim_last_error(void) { return g_err.c_str(); }
 
-void* sim_create(const tp_config* cfg) {
+// learned: strings to intern behind the configuration's own (what the library learns from its input), '\n'-separated; may be null
+void* sim_create_learned(const tp_config* cfg, const char* learned, uint64_t learned_len) {
     try {
         std::unique_ptr<Sim> s(new Sim());
-        compile_tables(*cfg, s->ht);
+        std::vector<std::string> extra;
+        if (learned) {
+            std::string cur;
+            for (uint64_t i = 0; i < learned_len; ++i) { if (learned[i] == '\n') { if (!cur.empty()) extra.push_back(cur); cur.clear(); } else cur.push_back(learned[i]); }
+            if (!cur.empty()) extra.push_back(cur);
+        }
+        compile_tables(*cfg, s->ht, learned ? &extra : nullptr);
         s->dt = bind_host_pointers(s->ht);
         // minimal fallback line, as tp_create evaluates it (mode 1, weight 1.0, source OpenAI)
         DevTables saved = s->dt;
@@ -130,12 +137,13 @@ void* sim_create(const tp_config* cfg) {
         return nullptr;
     }
 }
+void* sim_create(const tp_config* cfg) { return sim_create_learned(cfg, nullptr, 0); }
 void sim_destroy(void* h) { delete (Sim*)h; }
 
 int sim_info(void* h, tp_table_info* out) {
     Sim* s = (Sim*)h;
     std::memset(out, 0, sizeof *out);
-    out->n_strings = s->dt.n_strings; out->n_action_rules = s->dt.n_rules; out->n_action_subtypes = s->dt.n_subs; out->n_facets = s->dt.n_facets;
+    out->n_strings = s->dt.n_public; out->n_action_rules = s->dt.n_rules; out->n_action_subtypes = s->dt.n_subs; out->n_facets = s->dt.n_facets;
     out->fired_words = s->dt.fired_words; out->n_known_tags = s->ht.n_known; out->strict_known = s->ht.strict; out->known_found = s->ht.known_found;
     return 0;
 }
@@ -223,7 +231,7 @@ static int run_lines_staged(void* h, const uint8_t* arena_in, const uint64_t* of
     o->verdicts.assign(n, tp_verdict{});
     o->fired.assign(std::max<size_t>(n * t.fired_words, 1), 0);
     o->facets.assign(n * t.n_facets, 0xFFFF);
-    o->hist.assign((size_t)t.n_strings + 1, 0);
+    o->hist.assign((size_t)t.n_public + 1, 0);
     uint64_t slow = 0, n_lean_files = 0;
     emu::Shared sh;
     for (uint64_t f = 0; f < n; ++f) {
@@ -293,7 +301,7 @@ static int run_lines_staged(void* h, const uint8_t* arena_in, const uint64_t* of
                 if (k) { o->captions.push_back(','); o->captions.push_back(' '); }
                 const uint8_t* p = str_ptr(t, id);
                 o->captions.insert(o->captions.end(), p, p + str_len(t, id));
-                o->hist[id]++;
+                o->hist[std::min<uint32_t>(id, t.n_public)]++;
             }
             o->captions.insert(o->captions.end(), t.newline, t.newline + t.newline_len);
             if (o->captions.size() - before != fo.caption_len) g_err = "fast caption_len mismatch";
@@ -336,7 +344,7 @@ int sim_run_scored_fast(void* h, const uint8_t* arena_in, const uint64_t* tag_of
     o->verdicts.assign(n, tp_verdict{});
     o->fired.assign(std::max<size_t>(n * t.fired_words, 1), 0);
     o->facets.assign(n * t.n_facets, 0xFFFF);
-    o->hist.assign((size_t)t.n_strings + 1, 0);
+    o->hist.assign((size_t)t.n_public + 1, 0);
     uint64_t slow = 0;
     emu::Shared sh;
     for (uint64_t f = 0; f < n; ++f) {
@@ -368,7 +376,7 @@ int sim_run_scored_fast(void* h, const uint8_t* arena_in, const uint64_t* tag_of
                 if (k) { o->captions.push_back(','); o->captions.push_back(' '); }
                 const uint8_t* p = str_ptr(t, id);
                 o->captions.insert(o->captions.end(), p, p + str_len(t, id));
-                o->hist[id]++;
+                o->hist[std::min<uint32_t>(id, t.n_public)]++;
             }
             o->captions.insert(o->captions.end(), t.newline, t.newline + t.newline_len);
             if (o->captions.size() - before != fo.caption_len) g_err = "fast caption_len mismatch";

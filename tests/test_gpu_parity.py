@@ -623,3 +623,31 @@ def test_bench_two_ranks_share_this_gpu():
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["files_per_gpu"] == 30000 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_strings_in_no_table_are_learned():
+    """c2 without a vocabulary file: tags in no table are kept (Program.cs:1121-1133 with KnownTagDictionaryFound false), and a
+    file that holds one takes the thread-per-file kernel.  The library notes such strings and compiles its tables again
+    with them interned behind the configuration's own, so the second call over the same kind of input stays in the wave
+    kernels; results, ids and histogram are the same before and after (a learned tag counts with the tags in no table)."""
+    from imagecaptioner_amd.corpus import make_corpus
+    n = 6000
+    c = make_corpus("c2n", n, seed=4243)
+    cfg = Config(**c.config_kwargs)
+    want = Oracle(cfg).run_lines(c.arena, c.offsets, threads=16)
+    p = pipe_for(cfg)
+    n_strings = p.info.n_strings
+    got = p.run_lines(c.arena, c.offsets)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "c2n, first call")
+    first = p.last_timing()["general_files"]
+    assert first > n // 2, "nearly every file holds a tag in no table"
+    got = p.run_lines(c.arena, c.offsets)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "c2n, second call")
+    second = p.last_timing()["general_files"]
+    print("c2n: %d of %d files in the general kernel on the first call, %d on the second" % (first, n, second))
+    assert second <= n // 100
+    assert p.info.n_strings == n_strings and got.histogram_other > 0
+    # other files of the same corpus: mostly strings met before, the rest is learned in turn
+    c2 = make_corpus("c2n", n, seed=999)
+    got = p.run_lines(c2.arena, c2.offsets)
+    assert_same_results(got, Oracle(cfg).run_lines(c2.arena, c2.offsets, threads=16), p.histogram_dict(got.histogram), "c2n, other files")

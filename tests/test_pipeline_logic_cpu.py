@@ -336,3 +336,37 @@ def test_unusual_finite_scores():
     assert_same_results(got, want, s.histogram_dict(got.histogram), "finite scores")
     got = s.run_scored_fast(*args)
     assert_same_results(got, want, s.histogram_dict(got.histogram), "finite scores, wave kernel")
+
+
+# ---- strings in no table, learned: the tables compiled again with them interned (what the library does between calls) ------
+@pytest.mark.parametrize("strict_off_with_vocabulary", [False, True])
+def test_learned_strings_change_nothing_but_the_path(strict_off_with_vocabulary):
+    """c2 without its vocabulary file (or with it and strict vocabulary switched off): tags in no table are kept, and the wave
+    stages hand a file that holds one to the general pipeline.  With the corpus's strings learned - interned behind the
+    configuration's own, ids and histogram entries of the configuration's strings unchanged, a learned tag counted with
+    the tags in no table - the results are the same and the lean stage takes the files."""
+    n = 300
+    c = make_corpus("c2", n, seed=77)
+    kw = dict(c.config_kwargs)
+    if strict_off_with_vocabulary:
+        # half the vocabulary, strict vocabulary switched off explicitly: unknown tags are kept and counted (GetUnknownTags)
+        vocab = kw["vocabulary"].decode().split("\n")
+        kw["vocabulary"] = ("\n".join(vocab[::2]) + "\n").encode()
+        kw.update(strict_known=False, strict_known_explicit=True)
+    else:
+        kw["vocabulary"] = None
+    cfg = Config(**kw)
+    want = Oracle(cfg).run_lines(c.arena, c.offsets, threads=8)
+    plain = HostSim(cfg)
+    before = plain.run_lines_lean(c.arena, c.offsets, details=False)
+    assert before.n_lean < n // 10, "without learning nearly every file holds a tag in no table"
+    learned = HostSim(cfg, learned=c.pool + ["Not_Plain", "red_hair"])     # strings the tables hold already are skipped
+    assert learned.info.n_strings == plain.info.n_strings
+    assert learned.strings() == plain.strings()
+    got = learned.run_lines_lean(c.arena, c.offsets, details=False)
+    skipped = got.verdicts["n_evidence"] == 0xFFFF
+    got.verdicts["n_evidence"][skipped] = want.verdicts["n_evidence"][skipped]
+    got.fired = want.fired
+    assert_same_results(got, want, learned.histogram_dict(got.histogram), "c2 with learned strings")
+    assert got.n_lean >= 0.9 * n and got.n_general <= n // 50
+    assert got.histogram_other > 0                                        # (compared with the oracle's pooled count above)
