@@ -236,6 +236,28 @@ TP_HD bool dedupe_first(W& w, BackLds& L, const uint32_t key[2], const bool vali
     return !any_full;
 }
 
+// The same with an order of the caller's choosing: first[blk] marks the element whose val is the lowest among those with
+// its key (vals are distinct).
+template <class W>
+TP_HD bool dedupe_lowest(W& w, BackLds& L, const uint32_t key[2], const bool valid[2], const uint32_t val[2], bool first[2], int nblk = 2) {
+    set_clear(w, L);
+    uint32_t slot[2] = {NO_ID, NO_ID};
+    bool full = false;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+        if (valid[blk]) {
+            bool created;
+            slot[blk] = set_put(w, L, key[blk], val[blk], created);
+            if (slot[blk] == NO_ID) full = true;
+        }
+    }
+    w.sync();
+    first[0] = first[1] = false;
+    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) first[blk] = valid[blk] && slot[blk] != NO_ID && L.set_min[slot[blk]] == val[blk];
+    bool any_full = w.ballot(full) != 0;
+    w.sync();
+    return !any_full;
+}
+
 TP_HD bool lds_match(const uint8_t* s, uint32_t pos, uint32_t end, const char* pat, uint32_t plen) {
     if (pos + plen > end) return false;
     for (uint32_t k = 0; k < plen; ++k) {
@@ -1155,11 +1177,6 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         if (mh && hop) f3 = t.rec[t3[blk]].flags;
         ok3[blk] = uniq[blk] && !(f3 & FL_BLANK) && (f3 & FL_VALID) && !(f3 & FL_DROP) && !(f3 & FL_PREFIX);   // AddOne's tests; prefix tags are already in
     }
-    if (m_hop3) {
-        bool fst[2];
-        if (!dedupe_first(w, L, t3, ok3, fst, nblk)) return false;
-        if (w.ballot((ok3[0] && !fst[0]) || (ok3[1] && !fst[1]))) return false;   // two candidates end in one tag: their AddOne order decides, leave it to the general kernel
-    }
     uint32_t nr = t.n_prefix;
     bool settled = false;
     // per-position columns of the selected tags' implied tags; they reuse the line buffer, which is not read after S4
@@ -1171,18 +1188,37 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         const int caps[6] = {3, 10, 8, 6, 4, style_cap};
         bool taken[2] = {false, false};
         uint32_t pos[2] = {0, 0};
-        for (uint32_t bk = 0; bk <= 6; ++bk) {                    // FillBucket for the six capped buckets in order, then (bk == 6) the final sweep (Program.cs:670-680)
-            bool el0 = ok3[0] && !taken[0] && (bk == 6 || fl_bucket(r2[0].flags) == bk);
-            bool el1 = ok3[1] && !taken[1] && (bk == 6 || fl_bucket(r2[1].flags) == bk);
-            uint64_t m0 = w.ballot(el0), m1 = nblk > 1 ? w.ballot(el1) : 0;
-            uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
-            uint32_t take = popc64(m0) + popc64(m1);
-            if (bk < 6 && take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
-            if (take > room) take = room;
-            uint32_t rank0 = w.rank(m0), rank1 = popc64(m0) + w.rank(m1);
-            if (el0 && rank0 < take) { taken[0] = true; pos[0] = nr + rank0; }
-            if (el1 && rank1 < take) { taken[1] = true; pos[1] = nr + rank1; }
-            nr += take;
+        for (uint32_t pass = 0;; ++pass) {
+            nr = t.n_prefix;
+            taken[0] = taken[1] = false;
+            for (uint32_t bk = 0; bk <= 6; ++bk) {                // FillBucket for the six capped buckets in order, then (bk == 6) the final sweep (Program.cs:670-680)
+                bool el0 = ok3[0] && !taken[0] && (bk == 6 || fl_bucket(r2[0].flags) == bk);
+                bool el1 = ok3[1] && !taken[1] && (bk == 6 || fl_bucket(r2[1].flags) == bk);
+                uint64_t m0 = w.ballot(el0), m1 = nblk > 1 ? w.ballot(el1) : 0;
+                uint32_t room = nr < (uint32_t)MAX_TOTAL_TAGS ? (uint32_t)MAX_TOTAL_TAGS - nr : 0;
+                uint32_t take = popc64(m0) + popc64(m1);
+                if (bk < 6 && take > (uint32_t)caps[bk]) take = (uint32_t)caps[bk];
+                if (take > room) take = room;
+                uint32_t rank0 = w.rank(m0), rank1 = popc64(m0) + w.rank(m1);
+                if (el0 && rank0 < take) { taken[0] = true; pos[0] = nr + rank0; }
+                if (el1 && rank1 < take) { taken[1] = true; pos[1] = nr + rank1; }
+                nr += take;
+            }
+            if (!m_hop3) break;
+            // AddOne's own NormalizeTag (Program.cs:693) moved a tag: two candidates may now name one tag, and the one whose
+            // AddOne comes second fails (selected.Add, Program.cs:696) without using up its bucket's share (:688).  Positions are
+            // the order of the successful AddOne calls, and up to the first such failure the fills above are what the
+            // reference does: the candidate that fails there leaves, and the fills are done again without it.
+            bool fst[2];
+            if (!dedupe_lowest(w, L, t3, taken, pos, fst, nblk)) return false;
+            const bool lose0 = taken[0] && !fst[0], lose1 = taken[1] && !fst[1];
+            const uint32_t lo = w.or_all((lose0 && pos[0] < 32 ? 1u << pos[0] : 0u) | (lose1 && pos[1] < 32 ? 1u << pos[1] : 0u));
+            const uint32_t hi = w.or_all((lose0 && pos[0] >= 32 ? 1u << (pos[0] - 32) : 0u) | (lose1 && pos[1] >= 32 ? 1u << (pos[1] - 32) : 0u));
+            if ((lo | hi) == 0) break;
+            if (pass >= 16) return false;
+            const uint32_t first_fail = lo ? ctz32(lo) : 32u + ctz32(hi);
+            if (lose0 && pos[0] == first_fail) ok3[0] = false;
+            if (lose1 && pos[1] == first_fail) ok3[1] = false;
         }
         // A file is on the settled-tags path when NormalizeTag leaves every selected tag alone and every selected tag's
         // implied tags are settled leaves (FL_LEAF2): then flags and lengths of everything the final list can hold are known

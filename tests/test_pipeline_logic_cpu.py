@@ -370,3 +370,15 @@ def test_learned_strings_change_nothing_but_the_path(strict_off_with_vocabulary)
     assert_same_results(got, want, learned.histogram_dict(got.histogram), "c2 with learned strings")
     assert got.n_lean >= 0.9 * n and got.n_general <= n // 50
     assert got.histogram_other > 0                                        # (compared with the oracle's pooled count above)
+
+
+def test_candidates_that_end_in_one_tag_stay_in_the_wave_stages():
+    """c3c: alias chains inside the vocabulary, so AddOne's own NormalizeTag (Program.cs:693) moves tags, and now and then two
+    candidates of a file end in one tag: the second AddOne fails (Program.cs:696) without using up its bucket's share.  The wave
+    stages repeat the bucket fills without the candidate that fails first; no such file is left to the general pipeline."""
+    c = make_corpus("c3c", 4000, seed=4242)
+    cfg = Config(**c.config_kwargs)
+    s = HostSim(cfg)
+    got, want = s.run_lines_lean(c.arena, c.offsets, details=True), Oracle(cfg).run_lines(c.arena, c.offsets, threads=8)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "c3c")
+    assert got.n_general == 0
