@@ -104,7 +104,7 @@ struct tp_ctx {
     uint64_t* host_scalars = nullptr;   // pinned host words the runs read device scalars back into
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
-    DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets, out_review_bits;
+    DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets, out_review_bits, aud32;
     std::unordered_map<std::string, uint32_t> string_ids;   // text of every interned string -> id (made on first use by tp_decode_joytag_replies)
     bool audit = false;              // tp_set_audit: the host-pointer runs also return the audit row's tag lists
     std::vector<hipEvent_t> events;
@@ -113,6 +113,7 @@ struct tp_ctx {
     bool no_fast = false;            // TAGPIPE_NO_FAST=1: every file takes the general kernel (testing aid)
     bool use_lean = false;           // the lean stage runs ahead of the wave stages (TAGPIPE_NO_LEAN=1 turns it off: testing aid)
     uint64_t last_slow = 0;
+    uint32_t last_fpw = 64;          // files per wavefront of the last general-kernel run (the stride of its workspace rows)
 
     ~tp_ctx() {
         (void)hipSetDevice(device);
@@ -122,7 +123,7 @@ struct tp_ctx {
         for (DevBuf* b : {&unk_keys, &unk_ent, &unk_count, &unk_out}) b->release();
         for (DevBuf* b : {&dt_dev, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
-                          &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits})
+                          &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits, &aud32})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
@@ -168,7 +169,9 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     uint32_t* d_status = (uint32_t*)(d_total + 2);
     uint32_t* d_slow_count = d_status + 1;
     const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast && !io.audit;   // tagger replies: the wave kernel's scored front
-    const bool use_fast = use_scored || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast && !io.audit);
+    // audit mode over tag lines: the lean stage lists what it takes (interned ids, tp_lean.h), everything else takes the general kernel
+    const bool audit_lean = io.audit && c->use_lean && c->dt.fast_ok && !io.tag_begin && io.mode == 0 && !c->no_fast;
+    const bool use_fast = use_scored || audit_lean || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast && !io.audit);
 
     c->w->cap_len.need(n * 4); c->w->n_final.need(n * 4); c->w->slot_of.need(n * 4);
     uint32_t* cap_len = c->w->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
@@ -194,6 +197,15 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
             fa.tag_begin = io.tag_begin; fa.scores = io.scores; fa.sources = io.sources; fa.secondary_begin = io.secondary_begin; fa.secondary_cap = io.secondary_cap;
             fa.stage = 4; fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.item_list = nullptr; fa.item_count = nullptr;
             HIP_OK(launch_fast(c->dt, fa, s));
+        } else if (audit_lean) {
+            c->aud32.need(n * AUD_STRIDE * 4); c->audit_cnt.need(n * AUDIT_COLS * 4); c->audit_len.need(n * AUDIT_COLS * 4);
+            fa.aud32 = c->aud32.as<uint32_t>(); fa.audit_cnt = c->audit_cnt.as<uint32_t>(); fa.audit_len = c->audit_len.as<uint32_t>(); fa.review_bits = io.review_bits + f0;
+            fa.item_list = nullptr; fa.item_count = nullptr;
+            fa.stage = 0; fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.tables = c->dt_dev.as<DevTables>();
+            hipEvent_t pm = next_event(), pe = next_event();
+            HIP_OK(launch_fast(c->dt, fa, s, pm));
+            record(pe);
+            if (st.timed) st.lean_ev.push_back({p0, pm, pe});
         } else {
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
         // through the long-file stage, and what is left to the general kernel.  Later stages learn their item counts on the device.
@@ -229,6 +241,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     const bool want_ids = use_fast || (io.histogram != nullptr && io.mode == 0);   // rows of tag ids: the wave kernels' output, and what the histogram kernel counts
     if (want_ids && !use_fast) c->w->fin32.need(n * fast_fin_stride() * 4);
     c->last_slow += n_slow;
+    uint32_t fpw_used = 64;
     if (n_slow) {
         // The general kernel runs one file per lane, and the lanes of a wavefront wait for one another at every branch where
         // their files differ: a few thousand files go four to a wavefront, many files 64 to a wavefront.
@@ -267,6 +280,8 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
         pa.secondary_begin = io.secondary_begin; pa.secondary_cap = io.secondary_cap;
         pa.item_list = item_list; pa.file0 = f0; pa.n_items = n_slow; pa.fpw = fpw;
+        fpw_used = fpw;
+        c->last_fpw = fpw;
         pa.wave_T = c->w->wave_T.as<uint32_t>(); pa.wave_LB = c->w->wave_LB.as<uint32_t>(); pa.wave_off = c->w->wave_off.as<uint64_t>();
         pa.workspace = c->w->workspace.as<uint8_t>();
         pa.verdicts = io.verdicts; pa.n_final = n_final; pa.cap_len = cap_len; pa.slot_of = slot_of;
@@ -303,14 +318,16 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     ea.wave_T = c->w->wave_T.as<uint32_t>(); ea.wave_LB = c->w->wave_LB.as<uint32_t>(); ea.wave_off = c->w->wave_off.as<uint64_t>(); ea.workspace = c->w->workspace.as<uint8_t>();
     ea.fin32 = want_ids ? c->w->fin32.as<uint32_t>() : nullptr; ea.fast_ran = use_fast ? 1 : 0; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
     ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
-    ea.histogram = io.histogram; ea.counters = io.counters;
+    ea.histogram = io.histogram; ea.counters = io.counters; ea.fpw = fpw_used;
     hipEvent_t q0 = next_event(), q1 = next_event();
     record(q0);
     HIP_OK(launch_emit(c->dt, ea, s));
     record(q1);
     if (st.timed) st.emit_ev.emplace_back(q0, q1);
-    if (io.audit && n_slow) {
-        // offsets of the range's audit columns, continuing the running total, then their text out of the workspaces
+    if (io.audit) {
+        // offsets of the range's audit columns, continuing the running total, then their text out of the workspaces (files of
+        // the general kernel) and the id rows (files of the lean stage)
+        c->audit_len.need(n * AUDIT_COLS * 4);
         uint64_t* d_atotal = d_total + 4;
         c->w->tile_sums.need(scan_tiles_needed(n * AUDIT_COLS) * 8);
         HIP_OK(launch_scan_u32(c->audit_len.as<uint32_t>(), n * AUDIT_COLS, io.audit_offsets + f0 * AUDIT_COLS, c->w->tile_sums.as<uint64_t>(),
@@ -321,7 +338,8 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         ++st.audit_chunk;
         c->out_audit.need(std::max<uint64_t>(st.audit_total, 16), true, s);
         AuditArgs aa{};
-        aa.file0 = f0; aa.n_items = n_slow; aa.item_list = item_list; aa.slot_of = slot_of;
+        aa.file0 = f0; aa.n_items = n; aa.item_list = nullptr; aa.slot_of = slot_of; aa.fpw = fpw_used;
+        aa.fin32 = audit_lean ? c->w->fin32.as<uint32_t>() : nullptr; aa.aud32 = audit_lean ? c->aud32.as<uint32_t>() : nullptr;
         aa.wave_T = c->w->wave_T.as<uint32_t>(); aa.wave_LB = c->w->wave_LB.as<uint32_t>(); aa.wave_off = c->w->wave_off.as<uint64_t>(); aa.workspace = c->w->workspace.as<uint8_t>();
         aa.audit_cnt = c->audit_cnt.as<uint32_t>(); aa.offsets = io.audit_offsets; aa.text = c->out_audit.as<uint8_t>();
         HIP_OK(launch_audit(c->dt, aa, s));
@@ -546,7 +564,7 @@ void compute_fallback(tp_ctx* c) {
     std::vector<uint32_t> ids(nfin);
     for (uint32_t k = 0; k < nfin; ++k) {
         uint64_t h = 0;
-        HIP_OK(hipMemcpy(&h, c->w->workspace.as<uint8_t>() + lay.o_fin + (size_t)k * 64 * 8, 8, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(&h, c->w->workspace.as<uint8_t>() + lay.o_fin + (size_t)k * c->last_fpw * 8, 8, hipMemcpyDeviceToHost));
         if (h >> 32) throw ConfigError("internal: fallback tag outside the tables");
         ids[k] = (uint32_t)h;
     }

@@ -14,8 +14,12 @@
 #if defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define TP_HD __host__ __device__ inline
+// Always inlined, whatever the number of call sites: a function body that two kernels of one file share is otherwise inlined
+// at a later stage, and the register allocation of both kernels gets worse for it (spills in the lean stage's back half).
+#define TP_HD_FLAT __host__ __device__ __attribute__((always_inline)) inline
 #else
 #define TP_HD inline
+#define TP_HD_FLAT inline
 #endif
 
 namespace tp {
@@ -264,6 +268,14 @@ enum : uint32_t {
     FW_FIX = 1u << 27,         // FL_FIX
     FW_EDGE = 1u << 28,        // FL_EDGE
 };
+// Columns of list text in audit mode (see tp_pipeline.h) and the review record's bits (bit k < N_BANNED: banned tag k is among
+// the normalised raw candidates, Program.cs:828; then the subject-token tests of Program.cs:835-837)
+constexpr int AUDIT_KEPT = 0, AUDIT_EVIDENCE = 1, AUDIT_DROPPED = 2, AUDIT_TOP = 3, AUDIT_UNKNOWN = 4, AUDIT_COLS = 5;
+constexpr uint32_t AUDIT_REASON_LEN = 12;   // ":invalid_tag" and ":policy_drop" have the same length (Program.cs:630-631)
+constexpr uint32_t REVIEW_MALE = 1u << 16, REVIEW_GIRL = 1u << 17, REVIEW_MULTI = 1u << 18;
+// One file's list entries of the audit row and the review record as the lean stage leaves them (interned ids): the evidence
+// set in insertion order, the dropped candidates (bit 31: dropped by policy, else invalid), the first TOP_TAGS candidates.
+constexpr uint32_t AUD_EVIDENCE = 0, AUD_DROPPED = 192, AUD_TOP = 256, AUD_STRIDE = 288;
 constexpr uint32_t LEAN_TIX_MAX = 512;             // target indices the lean stage's direct first-occurrence table has room for
 constexpr uint32_t TIX_NONE = 0xFFFu;
 TP_HD uint32_t rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); }   // 0 < r < 32

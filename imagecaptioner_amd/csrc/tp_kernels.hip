@@ -259,7 +259,9 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     w.flush();
 #endif
 }
-__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_B_WAVES_PER_SIMD))) void k_lean_b(FastArgs a) {
+// DETAIL: the run wants the fired rules, the facets' choices or the audit lists (a.fired, a.facet_choice, a.aud32); the plain run's build has no code for either
+template <bool DETAIL>
+__device__ __forceinline__ void lean_b_body(const FastArgs& a) {
     __shared__ LeanLds lds[LEAN_WAVES_PER_BLOCK];
     __shared__ LeanShared shared;
     __shared__ DeclineBuf dbuf[LEAN_WAVES_PER_BLOCK];
@@ -307,8 +309,10 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
         };
         if (n0 != 0xFFFFFFFFu) {
             FastOut out;
-            const bool done = lean_back(w, t, L, shared, rc_lds, w.lane() < n0 ? id0 : NO_ID, n0, out, a.fin32 + i * FAST_FIN_MAX,
-                                        a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, records_free);
+            LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
+            if (DETAIL && a.aud32) { aud.row = a.aud32 + i * AUD_STRIDE; aud.cnt = a.audit_cnt + i * AUDIT_COLS; aud.len = a.audit_len + i * AUDIT_COLS; aud.rbits = a.review_bits + i; }
+            const bool done = lean_back<DETAIL>(w, t, L, shared, rc_lds, w.lane() < n0 ? id0 : NO_ID, n0, out, a.fin32 + i * FAST_FIN_MAX,
+                                        a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, records_free, aud);
             if (done) {
                 if (w.lane() == 0) {
                     a.verdicts[f] = out.verdict;
@@ -329,6 +333,11 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
     w.flush();
 #endif
 }
+__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_B_WAVES_PER_SIMD))) void k_lean_b(FastArgs a) { lean_b_body<false>(a); }
+#ifndef TP_LEAN_B_DETAIL_WAVES_PER_SIMD
+#define TP_LEAN_B_DETAIL_WAVES_PER_SIMD 4                            // the lists want more registers: 5 waves spill about twenty
+#endif
+__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_B_DETAIL_WAVES_PER_SIMD))) void k_lean_b_detail(FastArgs a) { lean_b_body<true>(a); }
 
 // Scored candidates (tagger replies as text and score per tag) through the wave kernel's scored front, two candidates per lane.
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables t, FastArgs a) {
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
     uint64_t w = th >> 6;
     uint32_t lane = (uint32_t)(th & 63);
     WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
-    FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, lane);
+    FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, lane, a.fpw);
     FileIn in;
     if (a.tag_begin) {
         in.text = nullptr; in.len = 0;
@@ -583,9 +592,23 @@ __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
     for (uint64_t i = wave_global; i < a.n_items; i += n_waves) {
         const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
         const uint32_t slot = a.slot_of[f];
-        const uint64_t w = slot >> 6;
-        WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
-        FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63);
+        // a file of the lean stage: its lists are interned ids in its rows of fin32 and aud32; else they are in its workspace
+        const bool lean_file = a.aud32 != nullptr && slot == SLOT_FAST;
+        const uint32_t* fin_row = lean_file ? a.fin32 + (f - a.file0) * FAST_FIN_MAX : nullptr;
+        const uint32_t* aud_row = lean_file ? a.aud32 + (f - a.file0) * AUD_STRIDE : nullptr;
+        const uint64_t w = lean_file ? 0 : slot >> 6;
+        WsLayout L{};
+        FileWs ws{};
+        if (!lean_file) { L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words); ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63, a.fpw); }
+        auto lean_elem = [&](int col, uint32_t k) {
+            const uint32_t v = col == AUDIT_KEPT || col == AUDIT_UNKNOWN ? fin_row[k] : col == AUDIT_EVIDENCE ? aud_row[AUD_EVIDENCE + k] : col == AUDIT_DROPPED ? aud_row[AUD_DROPPED + k] : aud_row[AUD_TOP + k];
+            const uint32_t id = v & 0x7FFFFFFFu;
+            AuditElem e;
+            e.keep = col != AUDIT_UNKNOWN || (t.known_active && !(t.flags[id] & FL_KNOWN));
+            e.p = str_ptr(t, id); e.len = str_len(t, id);
+            e.reason = col != AUDIT_DROPPED ? nullptr : (v >> 31) ? ":policy_drop" : ":invalid_tag";
+            return e;
+        };
         for (int c = 0; c < AUDIT_COLS; ++c) {
             const uint32_t cnt = a.audit_cnt[(f - a.file0) * AUDIT_COLS + c];
             uint8_t* out = a.text + a.offsets[f * AUDIT_COLS + c];
@@ -594,7 +617,7 @@ __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
             for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 AuditElem e{nullptr, 0, nullptr, false};
-                if (k < cnt) e = audit_elem(t, ws, c, k);
+                if (k < cnt) e = lean_file ? lean_elem(c, k) : audit_elem(t, ws, c, k);
                 const bool live = e.keep;
                 const uint64_t m = __ballot(live ? 1 : 0);
                 const bool first = kept_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0;
@@ -1036,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_emit_general(DevTables t, EmitArgs a) {
         const uint32_t slot = a.slot_of[f];
         const uint64_t w = slot >> 6;
         WsLayout L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words);
-        FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63);
+        FileWs ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63, a.fpw);
         uint32_t running = 0;
         const bool ids_out = a.fin32 != nullptr && nfin <= FAST_FIN_MAX;
         for (uint32_t k0 = 0; k0 < nfin; k0 += 64) {
@@ -1167,7 +1190,9 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
         if (want < 256u * 5u) want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK < 256u * 5u ? (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK : 256u * 5u;
         hipLaunchKernelGGL(k_lean_a, dim3((unsigned)(want < lean_blocks_a ? want : lean_blocks_a)), dim3(64 * LEAN_WAVES_PER_BLOCK), 0, s, a);
         if (between) { hipError_t e = hipEventRecord(between, s); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k_lean_b, dim3((unsigned)(want < lean_blocks_b ? want : lean_blocks_b)), dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
+        const dim3 grid_b((unsigned)(want < lean_blocks_b ? want : lean_blocks_b));
+        if (a.fired || a.facet_choice || a.aud32) hipLaunchKernelGGL(k_lean_b_detail, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
+        else hipLaunchKernelGGL(k_lean_b, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
     } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < (after_lean ? after_lean2 : 4096u) ? n : (after_lean ? after_lean2 : 4096u))), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);

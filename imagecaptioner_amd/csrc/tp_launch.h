@@ -36,6 +36,12 @@ struct FastArgs {
     uint32_t* fired;
     uint16_t* facet_choice;
     const DevTables* tables;      // the lean stage: the table image in device memory (the other kernels take it as an argument)
+    // audit mode (the lean stage only; null otherwise): per file AUD_STRIDE words of list entries (LeanAudit in tp_lean.h) and the
+    // entries, bytes and review bits the general kernel reports in the same arrays (PipelineArgs)
+    uint32_t* aud32;              // indexed by file - file0
+    uint32_t* audit_cnt;          // AUDIT_COLS per file, indexed by file - file0
+    uint32_t* audit_len;
+    uint32_t* review_bits;        // indexed by file - file0
 };
 
 // General kernel: items are files file0 + i, or slow_list[i] when a list is given.  Item i uses lane i & 63 of
@@ -82,6 +88,9 @@ struct AuditArgs {
     const uint32_t* audit_cnt;    // indexed by (file - file0) * AUDIT_COLS + column
     const uint64_t* offsets;      // indexed by file * AUDIT_COLS + column; the column's text is text[offsets[k] .. offsets[k + 1])
     uint8_t* text;
+    uint32_t fpw;                 // files per wavefront of the general kernel's run (the stride of its workspace rows)
+    const uint32_t* fin32;        // files of the lean stage (slot_of == SLOT_FAST): their caption's tag ids, FAST_FIN_MAX per file, and
+    const uint32_t* aud32;        //   their other lists' entries, AUD_STRIDE per file, both indexed by file - file0 (null: no such files)
 };
 
 struct EmitArgs {
@@ -102,6 +111,7 @@ struct EmitArgs {
     uint8_t* captions;
     uint64_t* histogram;          // n_strings + 1, accumulated; may be null
     tp_counters* counters;        // accumulated; may be null
+    uint32_t fpw;                 // files per wavefront of the general kernel's run (the stride of its workspace rows)
 };
 
 // Address and size of this device's static working memory (see tp_kernels.hip); `device` must be the current device.

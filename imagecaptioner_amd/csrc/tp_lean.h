@@ -101,7 +101,7 @@ struct alignas(16) LeanShared {
     uint32_t prefix_ids[MAX_TOTAL_TAGS], prefix_flags[MAX_TOTAL_TAGS], prefix_fw[MAX_TOTAL_TAGS], prefix_tix[MAX_TOTAL_TAGS];
 };
 template <class TT>
-TP_HD void lean_shared_init(const TT& t, LeanShared& S, uint32_t tid, uint32_t nthreads) {
+TP_HD_FLAT void lean_shared_init(const TT& t, LeanShared& S, uint32_t tid, uint32_t nthreads) {
     for (uint32_t k = tid; k < 33 * 4; k += nthreads) S.tail_mask[k >> 2][k & 3] = word_mask(k >> 2, k & 3);
     for (uint32_t k = tid; k < (uint32_t)MAX_TOTAL_TAGS; k += nthreads) {
         S.prefix_ids[k] = k < t.n_prefix ? t.prefix_ids[k] : NO_ID;
@@ -118,21 +118,21 @@ inline bool lean_tables_ok(const DevTables& t) {
 }
 
 // Bit k of the result: byte k of x differs from the byte pat repeats (exact for any bytes).
-TP_HD uint32_t ne_nibble(uint32_t x, uint32_t pat) {
+TP_HD_FLAT uint32_t ne_nibble(uint32_t x, uint32_t pat) {
     const uint32_t z = x ^ pat;
     uint32_t t = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;   // 0x80 where the byte differs
     t |= t << 7;
     t |= t << 14;
     return t >> 28;
 }
-TP_HD uint32_t ws1(uint32_t c) { return (uint32_t)(c == 0x20u) | (uint32_t)(c - 9u <= 4u); }   // char.IsWhiteSpace below U+0080
-TP_HD uint32_t lean_val(uint32_t order, uint32_t id, bool live) { return live ? (order << LEAN_ID_BITS) | id : LEAN_DEAD; }
+TP_HD_FLAT uint32_t ws1(uint32_t c) { return (uint32_t)(c == 0x20u) | (uint32_t)(c - 9u <= 4u); }   // char.IsWhiteSpace below U+0080
+TP_HD_FLAT uint32_t lean_val(uint32_t order, uint32_t id, bool live) { return live ? (order << LEAN_ID_BITS) | id : LEAN_DEAD; }
 
 // First occurrences by min-order tables.  val[e] = order << 20 | id describes element e of this lane (orders are distinct
 // and below 2^12, ids below 2^20), LEAN_DEAD means no element.  Bit e of the result is set for the element with the lowest
 // order among those with its id; bit 31 is set when elements are left undecided after LEAN_ROUNDS rounds (wave-uniform).
 template <int NE, class W, class LDS>
-TP_HD __attribute__((always_inline)) uint32_t lean_first(W& w, LDS& L, const uint32_t (&val)[NE]) {
+TP_HD_FLAT __attribute__((always_inline)) uint32_t lean_first(W& w, LDS& L, const uint32_t (&val)[NE]) {
     uint32_t pend = 0, first = 0;
     TP_UNROLL for (int e = 0; e < NE; ++e) pend |= (uint32_t)(val[e] != LEAN_DEAD) << e;
     for (uint32_t round = 0; round < LEAN_ROUNDS; ++round) {
@@ -164,7 +164,7 @@ TP_HD __attribute__((always_inline)) uint32_t lean_first(W& w, LDS& L, const uin
 
 // A token in no table, dropped under strict vocabulary whatever else it is (Program.cs:1131), provided normalisation
 // leaves its bytes alone and the line scan's phrase test (LooksBad, Program.cs:1141-1147) cannot hit inside it.
-TP_HD bool lean_plain_unknown(const uint8_t* p, uint32_t n) {
+TP_HD_FLAT bool lean_plain_unknown(const uint8_t* p, uint32_t n) {
     uint32_t prev = 0;
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t c = p[k];
@@ -180,7 +180,7 @@ TP_HD bool lean_plain_unknown(const uint8_t* p, uint32_t n) {
 // string in DevTables::unk_keys (64-bit hash, 0 = free; linear probing) with where it stands, so that the host can add it
 // to the tables for later runs.  p: the token in the input (device memory that outlives the run), n <= 32 bytes.
 template <class TT>
-TP_HD void lean_note_unknown(const TT& t, const uint8_t* p, uint32_t n) {
+TP_HD_FLAT void lean_note_unknown(const TT& t, const uint8_t* p, uint32_t n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t h1 = 2166136261u, h2 = 0x9E3779B9u ^ n;               // two byte-wise 32-bit hashes
     for (uint32_t k = 0; k < n; ++k) { const uint32_t c = p[k]; h1 = (h1 ^ c) * 16777619u; h2 = (h2 + c) * 0x85EBCA77u; h2 ^= h2 >> 15; }
@@ -204,7 +204,7 @@ TP_HD void lean_note_unknown(const TT& t, const uint8_t* p, uint32_t n) {
 // noted whether a table holds them or not: the host leaves out what it knows.  A pass of its own, for declined files
 // only, so that the front half itself carries none of this.
 template <class W, class TT>
-TP_HD void lean_note_tokens(W& w, const TT& t, LeanFrontLds& L, const uint8_t* text, uint32_t len) {
+TP_HD_FLAT void lean_note_tokens(W& w, const TT& t, LeanFrontLds& L, const uint8_t* text, uint32_t len) {
     const uint32_t lane = w.lane();
     const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
     const uint8_t* s = L.line + 16 + shift;
@@ -220,7 +220,7 @@ TP_HD void lean_note_tokens(W& w, const TT& t, LeanFrontLds& L, const uint8_t* t
 }
 
 // One record of the rule cache against the evidence bitset (MatchesFacetRule and its kin, Program.cs:777-794).
-TP_HD bool lean_rc_match(const uint32_t* ebits, const uint32_t* rc, uint32_t rec) {
+TP_HD_FLAT bool lean_rc_match(const uint32_t* ebits, const uint32_t* rc, uint32_t rec) {
     const uint32_t* r = rc + rec;
     const uint32_t cnts = r[2], n_all = cnts & 255u, n_any = (cnts >> 8) & 255u, n_forb = (cnts >> 16) & 255u, tot = n_all + n_any + n_forb;
     const uint32_t* lits = tot <= 4 ? r + 4 : rc + (r[3] & 0x7FFFu);
@@ -249,7 +249,7 @@ TP_HD bool lean_rc_match(const uint32_t* ebits, const uint32_t* rc, uint32_t rec
 struct LeanAcc { uint32_t sum, bits; };
 constexpr uint32_t LA_UNKNOWN_SHIFT = 20;
 static_assert(FW_UNKNOWN == 1u << LA_UNKNOWN_SHIFT, "a word's unknown bit sits where the sum counts unknown tags");
-TP_HD void lean_emit(LeanAcc& a, uint32_t* fin32, bool first, uint32_t val, uint32_t fw, uint32_t at) {
+TP_HD_FLAT void lean_emit(LeanAcc& a, uint32_t* fin32, bool first, uint32_t val, uint32_t fw, uint32_t at) {
     if (first) {
         a.bits |= fw;
         a.sum += fw & FW_SUM_MASK;
@@ -258,14 +258,14 @@ TP_HD void lean_emit(LeanAcc& a, uint32_t* fin32, bool first, uint32_t val, uint
 }
 // The first safe-mode hit of the final list (Program.cs:942-945) as position << 8 | index in SafeModeRejectTags; looked for
 // only in a file whose list holds such a tag at all.
-TP_HD uint32_t lean_safe_key(bool first, uint32_t fw, uint32_t at) { return first && (fw & FW_SAFE) ? (at << 8) | ((fw >> FW_SAFE_IDX_SHIFT) & 31u) : 0xFFFFFFFFu; }
-TP_HD uint32_t min32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+TP_HD_FLAT uint32_t lean_safe_key(bool first, uint32_t fw, uint32_t at) { return first && (fw & FW_SAFE) ? (at << 8) | ((fw >> FW_SAFE_IDX_SHIFT) & 31u) : 0xFFFFFFFFu; }
+TP_HD_FLAT uint32_t min32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // InferActionTags (Program.cs:731-753) for a file whose evidence holds a literal some rule tests positively: the tags of
 // the rules and subtypes that match go to L.act in rule order, their bits to `fired` (when asked for).  Returns how many
 // tags there are, LEAN_DEAD when the file is not for this stage.
 template <class W, class TT>
-TP_HD TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uint32_t* rc, uint32_t* fired) {
+TP_HD_FLAT TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uint32_t* rc, uint32_t* fired) {
     const uint32_t lane = w.lane();
     uint32_t* firedw = L.tab;                                       // the table area is idle here
     static_assert(FAST_FIRED_WORDS <= 2 * LeanLds::TAB, "the fired bitmap fits the table area");
@@ -315,7 +315,7 @@ TP_HD TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uin
 // appends in the next round of ExpandImpliedTags (Program.cs:1160-1179); at most two steps, at most two of those tags per
 // selected tag, and nothing beyond them, or the file is not for this stage (returns true).  The tags go to L.deep.
 template <class W, class TT>
-TP_HD TP_NOINLINE bool lean_deep(W& w, const TT& t, LeanLds& L, bool deep, uint32_t k_cnt, uint32_t kv0, uint32_t kv1, uint32_t kw0, uint32_t kw1) {
+TP_HD_FLAT TP_NOINLINE bool lean_deep(W& w, const TT& t, LeanLds& L, bool deep, uint32_t k_cnt, uint32_t kv0, uint32_t kv1, uint32_t kw0, uint32_t kw1) {
     const uint32_t lane = w.lane();
     w.sync();                                                       // the candidates' records have been read: their place is taken by the deeper tags
     bool bad_deep = deep && k_cnt > 2;
@@ -348,7 +348,7 @@ TP_HD TP_NOINLINE bool lean_deep(W& w, const TT& t, LeanLds& L, bool deep, uint3
 // The first-occurrence pass of a file with deeper tags or action tags: seven elements per lane.
 struct LeanWide { uint32_t fb, grown2, nact; };
 template <class W>
-TP_HD TP_NOINLINE LeanWide lean_first_wide(W& w, LeanLds& L, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, bool any_deep, uint32_t n_act) {
+TP_HD_FLAT TP_NOINLINE LeanWide lean_first_wide(W& w, LeanLds& L, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, bool any_deep, uint32_t n_act) {
     const uint32_t lane = w.lane();
     const uint32_t v7[7] = {v0, v1, v2, v3, any_deep ? L.deep[0][lane].val : LEAN_DEAD, any_deep ? L.deep[1][lane].val : LEAN_DEAD, lane < n_act ? L.act[lane][0] : LEAN_DEAD};
     LeanWide r;
@@ -359,7 +359,7 @@ TP_HD TP_NOINLINE LeanWide lean_first_wide(W& w, LeanLds& L, uint32_t v0, uint32
 }
 // ... and what its deeper tags (from position base_g on) and action tags (from base_a on) add to the final list.
 template <class W, class TT>
-TP_HD TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uint32_t* fin32, uint32_t fb, uint32_t base_g, uint32_t base_a, bool any_deep, uint32_t n_act,
+TP_HD_FLAT TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uint32_t* fin32, uint32_t fb, uint32_t base_g, uint32_t base_a, bool any_deep, uint32_t n_act,
                                          uint32_t& safe_key) {
     const uint32_t lane = w.lane();
     LeanAcc a = {0, 0};
@@ -382,7 +382,7 @@ TP_HD TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uint32_t
 // The piece of the line this lane scans: the aligned 16 bytes number `lane` from the 16-byte boundary at or before the
 // line's start (zeros behind the line's last piece).  A caller may fetch it well before lean_file needs it.
 template <class W>
-TP_HD void lean_fetch(W& w, const uint8_t* text, uint32_t len, uint32_t (&x)[4]) {
+TP_HD_FLAT void lean_fetch(W& w, const uint8_t* text, uint32_t len, uint32_t (&x)[4]) {
     const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
     x[0] = x[1] = x[2] = x[3] = 0;
     if (len <= LEAN_LINE_MAX && 16 * w.lane() < shift + len) w.load16(text - shift + 16 * w.lane(), x);
@@ -393,7 +393,7 @@ TP_HD void lean_fetch(W& w, const uint8_t* text, uint32_t len, uint32_t (&x)[4])
 // TT: DevTables, or DevTables in the constant address space (the GPU kernels read the table scalars with scalar loads
 // where they are used).
 template <class W, class TT>
-TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, const uint8_t* text, uint32_t len, const uint32_t (&x)[4], uint32_t* row, uint32_t& n_cand) {
+TP_HD_FLAT bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, const uint8_t* text, uint32_t len, const uint32_t (&x)[4], uint32_t* row, uint32_t& n_cand) {
     const uint32_t lane = w.lane();
     if (len > LEAN_LINE_MAX || len == 0) return LEAN_NO(1);
     w.tick(16);
@@ -520,14 +520,25 @@ TP_HD bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared& S, c
 // point from which L.cr is no longer read (a caller that fills it for the next file ahead of time may start then; it is
 // not called on every path).  rc: the rule cache; fin32: the caption's tag ids (FAST_FIN_MAX entries); fired (fired_words
 // words) and facet_choice may be null; with fired the evidence set is counted (tp_verdict::n_evidence).  false = declined.
-template <class W, class TT, class RF>
-TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const uint32_t* rc, uint32_t id, uint32_t n_cand, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice, RF&& records_free) {
+// aud (audit mode; row null otherwise): where the file's other lists go - the evidence set in insertion order, the dropped
+// candidates with their reason, the first TOP_TAGS candidates (AUD_* in tp_common.h) - with their entry counts, text
+// lengths and the review record's bits, as the general kernel reports them in audit mode (tp_pipeline.h); the kept tags
+// and the caption tags outside the vocabulary are read from fin32 by whoever writes the text.
+struct LeanAudit { uint32_t* row; uint32_t* cnt; uint32_t* len; uint32_t* rbits; };
+// DETAIL false (the plain run's build of the kernel): aud is taken as null whatever is passed, and with fired a file with a
+// seed whose closure has more than two members is declined (the evidence set is counted, not listed).
+template <bool DETAIL = true, class W, class TT, class RF>
+TP_HD_FLAT bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const uint32_t* rc, uint32_t id, uint32_t n_cand, FastOut& out, uint32_t* fin32,
+                     uint32_t* fired_or_null, uint16_t* facet_choice_or_null, RF&& records_free, const LeanAudit aud_or_null = LeanAudit{nullptr, nullptr, nullptr, nullptr}) {
+    uint32_t* const fired = fired_or_null;
+    uint16_t* const facet_choice = facet_choice_or_null;
+    const LeanAudit aud = DETAIL ? aud_or_null : LeanAudit{nullptr, nullptr, nullptr, nullptr};
     const uint32_t lane = w.lane();
     const bool act = lane < n_cand;
     const uint32_t ci = lane;
     // the candidate's record: what NormalizeTag, ClassifyTag, the rules and ExpandImpliedTags need to know of the string
     uint32_t f = FL_BLANK, lit = CREC_LIT_NONE, s_info = CREC_LIT_NONE | CREC_LIT_NONE << 16, ev_step[2] = {NO_ID, NO_ID};
+    uint32_t own_len = 0, step_fw[2] = {0, 0}, own_cnt = 0;         // (for the evidence set as a list: lengths, the steps' words, the step count)
     {
         bool too_long = false;
         if (act) {
@@ -535,6 +546,7 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
             w.load16((const uint8_t*)&L.cr[0][lane], c0);
             w.load16((const uint8_t*)&L.cr[1][lane], c1);
             f = c0[0]; lit = c0[2] & CREC_LIT_NONE; s_info = c0[3];
+            if (DETAIL && (fired || aud.row)) { own_len = c0[1] & FW_LEN_MASK; step_fw[0] = c1[2]; step_fw[1] = c1[3]; own_cnt = (c0[2] >> 24) & 3u; }
             too_long = (c0[2] & CREC_TOO_LONG) != 0;
             ev_step[0] = c1[0] == NO_ID ? NO_ID : c1[0] & LEAN_ID_MASK; ev_step[1] = c1[1] == NO_ID ? NO_ID : c1[1] & LEAN_ID_MASK;
             L.ids[lane] = id;
@@ -567,14 +579,15 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
             ev_feet = (f & FL_NFEET) != 0; ev_penis = (f & FL_NPENIS) != 0;
             if ((f & FL_EDGE) && !(f & FL_REACH2)) {
                 const uint32_t m0 = t.reach_off[id], m1 = t.reach_off[id + 1];
-                if (fired && m1 - m0 > 2) ev_far = true;           // more members than this lane can hand to the count
+                if (!DETAIL && fired && m1 - m0 > 2) ev_far = true;   // (the plain run's build) more members than this lane can hand to the count
                 for (uint32_t m = m0; m < m1; ++m) {
                     const uint32_t info = t.reach_ent[2 * m + 1], li = info & 0xFFFFFFu;
                     if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
                     ev_feet |= ((info >> 24) & 1u) != 0;
                     ev_penis |= ((info >> 25) & 1u) != 0;
-                    if (m - m0 < 2) ev_id[1 + (m - m0)] = t.reach_ent[2 * m];
+                    if (!DETAIL && m - m0 < 2) ev_id[1 + (m - m0)] = t.reach_ent[2 * m];
                 }
+                if (DETAIL) { ev_id[1] = ev_step[0]; ev_id[2] = ev_step[1]; }
             } else if (f & FL_EDGE) {
                 const uint32_t l0 = s_info & CREC_LIT_NONE, l1 = (s_info >> 16) & CREC_LIT_NONE;   // absent steps have no literal and no bits
                 if (l0 != CREC_LIT_NONE) w.lds_or(&L.ebits[l0 >> 5], 1u << (l0 & 31));
@@ -586,13 +599,83 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
         }
         ev_feet = w.ballot(ev_feet) != 0;
         ev_penis = w.ballot(ev_penis) != 0;
-        if (fired) {                                                // the evidence set's size is a detail output: distinct ids among seeds and their closures
+        if constexpr (!DETAIL) {
+            if (fired) {                                            // the evidence set's size only: distinct ids among seeds and their closures
+                if (w.ballot(ev_far) != 0) return LEAN_NO(9);
+                const uint32_t v3[3] = {lean_val(3 * lane, ev_id[0], seed), lean_val(3 * lane + 1, ev_id[1], seed && ev_id[1] != NO_ID),
+                                        lean_val(3 * lane + 2, ev_id[2], seed && ev_id[2] != NO_ID)};
+                const uint32_t fb = lean_first<3>(w, L, v3);
+                if (fb >> 31) return LEAN_NO(10);
+                n_evidence = popc64(w.ballot(fb & 1u)) + popc64(w.ballot(fb & 2u)) + popc64(w.ballot(fb & 4u));
+            }
+        } else if (fired || aud.row) {
+            // The evidence set as a list, in insertion order (BuildEvidenceTags, then ExpandImpliedTags' rounds: Program.cs:721-729,
+            // 1160-1179): the seeds in candidate order; then what the first round appends, the seeds' steps by seed; then what the
+            // second round appends, the steps of those steps that lead further, by the step they belong to.  A seed whose closure
+            // goes beyond that (more than two steps, a step's step that leads further still) is not for this stage.  Its size is
+            // a detail output (n_evidence), the list itself goes into the audit row.
+            const bool two_levels = seed && (f & FL_EDGE) && !(f & FL_REACH2);
+            const bool any_two = w.ballot(two_levels) != 0;
+            uint32_t l2[4] = {NO_ID, NO_ID, NO_ID, NO_ID}, l2_len[4] = {0, 0, 0, 0};
+            if (two_levels) {
+                if (own_cnt > 2) ev_far = true;
+                for (uint32_t j = 0; j < 2; ++j) {
+                    const uint32_t e = ev_step[j];
+                    if (e == NO_ID || !(step_fw[j] & FW_EDGE)) continue;
+                    const Rec re = t.rec[e];
+                    if (!(re.flags & FL_REACH2) || re.step_cnt > 2) { ev_far = true; continue; }
+                    if (re.step_cnt > 0) l2[2 * j] = re.step0;
+                    if (re.step_cnt > 1) l2[2 * j + 1] = re.step1;
+                }
+                if (aud.row) for (uint32_t q = 0; q < 4; ++q) if (l2[q] != NO_ID) {
+                    l2_len[q] = t.fw_tix[2 * (size_t)l2[q]] & FW_LEN_MASK;
+                    if (l2_len[q] == FW_LEN_MASK) ev_far = true;
+                }
+            }
             if (w.ballot(ev_far) != 0) return LEAN_NO(9);
-            const uint32_t v3[3] = {lean_val(3 * lane, ev_id[0], seed), lean_val(3 * lane + 1, ev_id[1], seed && ev_id[1] != NO_ID),
-                                    lean_val(3 * lane + 2, ev_id[2], seed && ev_id[2] != NO_ID)};
-            const uint32_t fb = lean_first<3>(w, L, v3);
+            const uint32_t v7[7] = {lean_val(lane, ev_id[0], seed), lean_val(64 + 2 * lane, ev_id[1], seed && ev_id[1] != NO_ID),
+                                    lean_val(65 + 2 * lane, ev_id[2], seed && ev_id[2] != NO_ID),
+                                    lean_val(192 + 4 * lane, l2[0], l2[0] != NO_ID), lean_val(193 + 4 * lane, l2[1], l2[1] != NO_ID),
+                                    lean_val(194 + 4 * lane, l2[2], l2[2] != NO_ID), lean_val(195 + 4 * lane, l2[3], l2[3] != NO_ID)};
+            uint32_t fb;
+            if (any_two) fb = lean_first<7>(w, L, v7);
+            else { const uint32_t v3[3] = {v7[0], v7[1], v7[2]}; fb = lean_first<3>(w, L, v3); }
             if (fb >> 31) return LEAN_NO(10);
-            n_evidence = popc64(w.ballot(fb & 1u)) + popc64(w.ballot(fb & 2u)) + popc64(w.ballot(fb & 4u));
+            const uint64_t ms = w.ballot(fb & 1u), m0 = w.ballot(fb & 2u), m1 = w.ballot(fb & 4u);
+            uint64_t mq[4] = {0, 0, 0, 0};
+            if (any_two) for (uint32_t q = 0; q < 4; ++q) mq[q] = w.ballot(fb & (8u << q));
+            const uint32_t n0 = popc64(ms), n1 = popc64(m0) + popc64(m1), n2 = popc64(mq[0]) + popc64(mq[1]) + popc64(mq[2]) + popc64(mq[3]);
+            n_evidence = n0 + n1 + n2;
+            if (aud.row && n_evidence > AUD_DROPPED - AUD_EVIDENCE) return LEAN_NO(9);   // no room in the row
+            if (aud.row) {
+                const uint32_t at1 = n0 + w.rank(m0) + w.rank(m1);
+                if (fb & 1u) aud.row[AUD_EVIDENCE + w.rank(ms)] = ev_id[0];
+                if (fb & 2u) aud.row[AUD_EVIDENCE + at1] = ev_id[1];
+                if (fb & 4u) aud.row[AUD_EVIDENCE + at1 + ((fb >> 1) & 1u)] = ev_id[2];
+                uint32_t mine = ((fb & 1u) ? own_len : 0u) + ((fb & 2u) ? step_fw[0] & FW_LEN_MASK : 0u) + ((fb & 4u) ? step_fw[1] & FW_LEN_MASK : 0u);
+                if (any_two) {
+                    uint32_t at2 = n0 + n1 + w.rank(mq[0]) + w.rank(mq[1]) + w.rank(mq[2]) + w.rank(mq[3]);
+                    for (uint32_t q = 0; q < 4; ++q) if (fb & (8u << q)) { aud.row[AUD_EVIDENCE + at2++] = l2[q]; mine += l2_len[q]; }
+                }
+                const uint32_t bytes = w.sum(mine);
+                if (lane == 0) { aud.cnt[AUDIT_EVIDENCE] = n_evidence; aud.len[AUDIT_EVIDENCE] = bytes + (n_evidence ? n_evidence - 1 : 0u); }
+            }
+        }
+        if (aud.row) {
+            // DroppedTagsWithReason (Program.cs:630-631, 682), the first TOP_TAGS raw candidates (Program.cs:860), the review record's bits
+            const uint64_t mb = w.ballot(bad);
+            if (bad) aud.row[AUD_DROPPED + w.rank(mb)] = id | ((f & FL_VALID) ? 0x80000000u : 0u);
+            const uint32_t ntop = n_cand < (uint32_t)TOP_TAGS ? n_cand : (uint32_t)TOP_TAGS;
+            if (lane < ntop) aud.row[AUD_TOP + lane] = id;
+            const uint32_t dbytes = w.sum(bad ? own_len + AUDIT_REASON_LEN : 0u), tbytes = w.sum(lane < ntop ? own_len : 0u);
+            uint32_t rbits = w.or_all(nonblank ? (f & (FL_SUBJ_MALE | FL_SUBJ_GIRL | FL_SUBJ_MULTI)) >> 10 : 0u);
+            if (w.ballot(nonblank && (f & FL_BANNED)) != 0)
+                for (int k = 0; k < N_BANNED; ++k) if (w.ballot(nonblank && id == t.banned_ids[k]) != 0) rbits |= 1u << k;
+            if (lane == 0) {
+                aud.cnt[AUDIT_DROPPED] = n_dropped; aud.len[AUDIT_DROPPED] = dbytes + (n_dropped ? n_dropped - 1 : 0u);
+                aud.cnt[AUDIT_TOP] = ntop; aud.len[AUDIT_TOP] = tbytes + (ntop ? ntop - 1 : 0u);
+                *aud.rbits = rbits;
+            }
         }
     }
     w.sync();
@@ -792,6 +875,19 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
     }
     const uint32_t sums = w.sum(acc.sum);
     const uint32_t bytes = sums & ((1u << LA_UNKNOWN_SHIFT) - 1u), unknown = t.known_active ? sums >> LA_UNKNOWN_SHIFT : 0u;
+    if (aud.row) {                                                  // the kept tags are the final list; the unknown column walks it and keeps what qualifies
+        auto ulen = [](bool first, uint32_t fw) { return first && (fw & FW_UNKNOWN) ? fw & FW_LEN_MASK : 0u; };
+        uint32_t mine = ulen((fb & 1u) != 0, p_fw) + ulen((fb & 2u) != 0, k_fw[0]) + ulen((fb & 4u) != 0, k_fw[1]) + ulen((fb & 8u) != 0, f_fw);
+        if (wide && unknown) {
+            if (any_deep) mine += ulen((fb & 16u) != 0, L.deep[0][lane].fw) + ulen((fb & 32u) != 0, L.deep[1][lane].fw);
+            if (lane < n_act) mine += ulen((fb & 64u) != 0, L.act[lane][1]);
+        }
+        const uint32_t ubytes = unknown ? w.sum(mine) : 0u;
+        if (lane == 0) {
+            aud.cnt[AUDIT_KEPT] = nf; aud.len[AUDIT_KEPT] = bytes + (nf - 1);
+            aud.cnt[AUDIT_UNKNOWN] = nf; aud.len[AUDIT_UNKNOWN] = ubytes + (unknown ? unknown - 1 : 0u);
+        }
+    }
     if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (all_bits & FW_FOOTJOB) flags |= TP_F_FOOTJOB; }
     tp_verdict& v = out.verdict;
     v.coverage = (uint8_t)coverage;
@@ -811,8 +907,8 @@ TP_HD bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const u
 
 // Both halves in a row (the host-side logic test; the GPU runs them as two kernels with the candidates' ids in between).
 template <class W, class TT>
-TP_HD bool lean_file(W& w, const TT& t, LeanFrontLds& LF, LeanLds& L, const LeanShared& S, const uint32_t* rc, const uint8_t* text, uint32_t len, const uint32_t (&x)[4],
-                     uint32_t* row, FastOut& out, uint32_t* fin32, uint32_t* fired, uint16_t* facet_choice) {
+TP_HD_FLAT bool lean_file(W& w, const TT& t, LeanFrontLds& LF, LeanLds& L, const LeanShared& S, const uint32_t* rc, const uint8_t* text, uint32_t len, const uint32_t (&x)[4],
+                     uint32_t* row, FastOut& out, uint32_t* fin32, uint32_t* fired, uint16_t* facet_choice, const LeanAudit aud = LeanAudit{nullptr, nullptr, nullptr, nullptr}) {
     uint32_t n_cand = 0;
     if (!lean_front(w, t, LF, S, text, len, x, row, n_cand)) return false;
     w.sync();
@@ -825,7 +921,7 @@ TP_HD bool lean_file(W& w, const TT& t, LeanFrontLds& LF, LeanLds& L, const Lean
         w.store16((uint8_t*)&L.cr[1][w.lane()], c1);
     }
     w.sync();
-    return lean_back(w, t, L, S, rc, id, n_cand, out, fin32, fired, facet_choice, []() {});
+    return lean_back(w, t, L, S, rc, id, n_cand, out, fin32, fired, facet_choice, []() {}, aud);
 }
 
 }  // namespace tp

@@ -16,11 +16,14 @@
 
 namespace tp {
 
-// Element k of a lane-private array: rows of 64 elements, one per lane.
+// Element k of a lane-private array: rows of `stride` elements, one per lane that holds a file (64 when every lane does: the
+// lanes' accesses to one element coalesce; 1 when a wavefront holds one file: that file's elements are then neighbours in
+// memory, which its many searches through its own lists like much better than one cache line per element).
 template <class T>
 struct LaneArr {
     T* base;
-    TP_HD T& operator[](uint32_t k) const { return base[(size_t)k * 64]; }
+    uint32_t stride = 64;
+    TP_HD T& operator[](uint32_t k) const { return base[(size_t)k * stride]; }
 };
 
 // Byte layout of one wavefront's workspace (64 files).  T = the largest token
@@ -67,8 +70,13 @@ struct FileWs {
     uint8_t* norm;   // thread-contiguous, cap_norm bytes: bytes of dynamic strings
     uint32_t cap_t, cap_e, cap_snap, cap_f, cap_norm;
 };
-TP_HD FileWs ws_bind(uint8_t* wave_base, const WsLayout& L, uint32_t lane) {
+// stride: files per wavefront (the layout's offsets leave room for 64)
+TP_HD FileWs ws_bind(uint8_t* wave_base, const WsLayout& L, uint32_t lane, uint32_t stride = 64) {
     FileWs w;
+    w.hnd.stride = w.dl.stride = w.ev.stride = w.snap.stride = w.fin.stride = w.top.stride = stride;
+    w.score.stride = w.top_score.stride = stride;
+    w.order.stride = w.sorted.stride = w.ebits.stride = w.top_order.stride = stride;
+    w.src.stride = stride;
     w.hnd.base = (H*)(wave_base + L.o_hnd) + lane;
     w.score.base = (double*)(wave_base + L.o_score) + lane;
     w.order.base = (uint32_t*)(wave_base + L.o_order) + lane;
@@ -114,7 +122,6 @@ struct FileOut {
     uint32_t review_bits;  // REVIEW_* : which banned tags the raw candidates held, and the subject-token tests
 };
 // review_bits: bit k (k < N_BANNED) = DevTables::banned_ids[k] is among the normalised raw candidates (bannedDetected, Program.cs:828)
-constexpr uint32_t REVIEW_MALE = 1u << 16, REVIEW_GIRL = 1u << 17, REVIEW_MULTI = 1u << 18;   // Program.cs:835-837 without the banned part of hasMale
 
 // The tag-list columns of the audit row (Program.cs:966): keptTags = finalTags as they stand after EnsureRequiredFacets
 // (Program.cs:307), evidenceTags after ExpandImpliedTags (Program.cs:302), finalSelection.DroppedTagsWithReason (Program.cs:682).
@@ -122,8 +129,7 @@ constexpr uint32_t REVIEW_MALE = 1u << 16, REVIEW_GIRL = 1u << 17, REVIEW_MULTI 
 // Two more columns feed the review record (Program.cs:860-861): the TopJoyTags (the 20 best raw candidates' tags) and the
 // caption tags outside the vocabulary (GetUnknownTags before its sort, Program.cs:817-821); their entries are separated by "\n",
 // which no normalised tag holds.  The unknown column walks the caption's tags (ws.fin) and keeps those that qualify.
-constexpr int AUDIT_KEPT = 0, AUDIT_EVIDENCE = 1, AUDIT_DROPPED = 2, AUDIT_TOP = 3, AUDIT_UNKNOWN = 4, AUDIT_COLS = 5;
-constexpr uint32_t AUDIT_REASON_LEN = 12;   // ":invalid_tag" and ":policy_drop" have the same length (Program.cs:630-631)
+// (AUDIT_* and REVIEW_* are in tp_common.h: the lean stage reports the same lists)
 
 // ================================================================================================
 // string helpers

@@ -4,6 +4,7 @@
 // imagecaptioner_amd/ loads it, the C ABI never routes here, and the GPU tests do not use it.
 // The lane-interleaved workspace layout is kept exactly as the kernel uses it (lane = file & 63).
 #define TP_LEAN_STATS 1
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -258,7 +259,12 @@ static int run_lines_staged(void* h, const uint8_t* arena_in, const uint64_t* of
                 emu::Wave w{&sh, (uint32_t)lane};
                 uint32_t piece[4];
                 lean_fetch(w, text, len, piece);
-                done[lane] = lean_file(w, t, flds, llds, lshared, t.rc, text, len, piece, row.data(), outs[lane], fin32.data(), fired_f, t.n_facets ? &o->facets[f * t.n_facets] : nullptr);
+                // SIM_LEAN_AUDIT=1: the lean stage also lists what the audit row needs (into scratch arrays: which files it then
+                // declines is what a test may want to know)
+                static const bool with_audit = [] { const char* e = std::getenv("SIM_LEAN_AUDIT"); return e && e[0] == '1'; }();
+                static uint32_t aud_row[AUD_STRIDE], aud_cnt[AUDIT_COLS], aud_len[AUDIT_COLS], aud_bits;
+                const LeanAudit aud = with_audit ? LeanAudit{aud_row, aud_cnt, aud_len, &aud_bits} : LeanAudit{nullptr, nullptr, nullptr, nullptr};
+                done[lane] = lean_file(w, t, flds, llds, lshared, t.rc, text, len, piece, row.data(), outs[lane], fin32.data(), fired_f, t.n_facets ? &o->facets[f * t.n_facets] : nullptr, aud);
             });
             for (int l = 1; l < 64; ++l) if (done[l] != done[0]) { g_err = "lanes disagree on the lean verdict"; }
             lean_done = done[0];
