@@ -13,7 +13,11 @@
 
 #if defined(__HIP__)
 #include <hip/hip_runtime.h>
+#ifdef TP_HD_ALL_FLAT                                               // experiment: every helper always inlined
+#define TP_HD __host__ __device__ __attribute__((always_inline)) inline
+#else
 #define TP_HD __host__ __device__ inline
+#endif
 // Always inlined, whatever the number of call sites: a function body that two kernels of one file share is otherwise inlined
 // at a later stage, and the register allocation of both kernels gets worse for it (spills in the lean stage's back half).
 #define TP_HD_FLAT __host__ __device__ __attribute__((always_inline)) inline
@@ -275,7 +279,8 @@ constexpr uint32_t AUDIT_REASON_LEN = 12;   // ":invalid_tag" and ":policy_drop"
 constexpr uint32_t REVIEW_MALE = 1u << 16, REVIEW_GIRL = 1u << 17, REVIEW_MULTI = 1u << 18;
 // One file's list entries of the audit row and the review record as the lean stage leaves them (interned ids): the evidence
 // set in insertion order, the dropped candidates (bit 31: dropped by policy, else invalid), the first TOP_TAGS candidates.
-constexpr uint32_t AUD_EVIDENCE = 0, AUD_DROPPED = 192, AUD_TOP = 256, AUD_STRIDE = 288;
+// AUD_FLAGS: 1 when the final list is not the caption's list (a tag NormalizeTag changes); the final list is then at AUD_KEPT.
+constexpr uint32_t AUD_EVIDENCE = 0, AUD_DROPPED = 192, AUD_TOP = 256, AUD_FLAGS = 287, AUD_KEPT = 288, AUD_STRIDE = 288 + 128;
 constexpr uint32_t LEAN_TIX_MAX = 512;             // target indices the lean stage's direct first-occurrence table has room for
 constexpr uint32_t TIX_NONE = 0xFFFu;
 TP_HD uint32_t rotl32(uint32_t x, uint32_t r) { return (x << r) | (x >> (32u - r)); }   // 0 < r < 32
@@ -300,6 +305,7 @@ constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
 constexpr int MAX_TOTAL_TAGS = 42;        // Program.cs:38
 constexpr int N_BANNED = 9;               // BannedFinalTags, Program.cs:33-35
 constexpr int TOP_TAGS = 20;              // TopJoyTags of a review record, Program.cs:860
+static_assert(AUD_TOP + TOP_TAGS <= AUD_FLAGS, "the flag word lies behind the top tags");
 constexpr int MAX_ALWAYS_ADD = 64;
 constexpr int MAX_FALLBACK = MAX_TOTAL_TAGS;
 constexpr uint32_t RC_REC_WORDS = 12;

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
         FileWs ws{};
         if (!lean_file) { L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words); ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63, a.fpw); }
         auto lean_elem = [&](int col, uint32_t k) {
-            const uint32_t v = col == AUDIT_KEPT || col == AUDIT_UNKNOWN ? fin_row[k] : col == AUDIT_EVIDENCE ? aud_row[AUD_EVIDENCE + k] : col == AUDIT_DROPPED ? aud_row[AUD_DROPPED + k] : aud_row[AUD_TOP + k];
+            const uint32_t v = col == AUDIT_UNKNOWN ? fin_row[k] : col == AUDIT_KEPT ? (aud_row[AUD_FLAGS] ? aud_row[AUD_KEPT + k] : fin_row[k]) : col == AUDIT_EVIDENCE ? aud_row[AUD_EVIDENCE + k] : col == AUDIT_DROPPED ? aud_row[AUD_DROPPED + k] : aud_row[AUD_TOP + k];
             const uint32_t id = v & 0x7FFFFFFFu;
             AuditElem e;
             e.keep = col != AUDIT_UNKNOWN || (t.known_active && !(t.flags[id] & FL_KNOWN));

@@ -263,9 +263,11 @@ TP_HD_FLAT uint32_t min32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // InferActionTags (Program.cs:731-753) for a file whose evidence holds a literal some rule tests positively: the tags of
 // the rules and subtypes that match go to L.act in rule order, their bits to `fired` (when asked for).  Returns how many
-// tags there are, LEAN_DEAD when the file is not for this stage.
-template <class W, class TT>
-TP_HD_FLAT TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uint32_t* rc, uint32_t* fired) {
+// tags there are, LEAN_DEAD when the file is not for this stage.  A tag NormalizeTag changes stays in the final list as it is
+// (Program.cs:738, 745) and is normalised when the caption is put together (Program.cs:972): with CHANGING such tags are
+// allowed and bit q of `chg` says that tag q is one (lean_caption_fix deals with them); without, the file is declined.
+template <bool CHANGING, class W, class TT>
+TP_HD_FLAT TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, const uint32_t* rc, uint32_t* fired, uint64_t& chg) {
     const uint32_t lane = w.lane();
     uint32_t* firedw = L.tab;                                       // the table area is idle here
     static_assert(FAST_FIRED_WORDS <= 2 * LeanLds::TAB, "the fired bitmap fits the table area");
@@ -282,8 +284,9 @@ TP_HD_FLAT TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, cons
             const uint32_t* rr = rc + (r0 + ctz64(m)) * RC_REC_WORDS;
             m &= m - 1;
             const uint32_t sub_off = rr[1], sub_cnt = rr[3] >> 16;
-            if ((rr[3] & 0x8000u) || (rr[10] & FW_LEN_MASK) == FW_LEN_MASK) changes = true;   // a tag NormalizeTag changes, or too long for its final-list word
             if (n_act >= 64) return LEAN_DEAD;
+            if ((rr[10] & FW_LEN_MASK) == FW_LEN_MASK || (rr[8] & FL_BLANK)) changes = true;   // too long for its final-list word, or blank
+            else if (rr[3] & 0x8000u) { if (CHANGING) chg |= 1ull << n_act; else changes = true; }   // a tag NormalizeTag changes
             if (lane == 0) { L.act[n_act][0] = lean_val(640 + n_act, rr[0], true); L.act[n_act][1] = rr[10]; }
             ++n_act;
             for (uint32_t s0 = 0; s0 < sub_cnt; s0 += 64) {
@@ -296,9 +299,13 @@ TP_HD_FLAT TP_NOINLINE uint32_t lean_actions(W& w, const TT& t, LeanLds& L, cons
                     const uint32_t bit = t.n_rules + sub_off + si;                           // "subtype:{parent}:{tag}" (Program.cs:748)
                     w.lds_or(&firedw[bit >> 5], 1u << (bit & 31));
                     const uint32_t* sr = rc + srec;
-                    if ((sr[3] & 0x8000u) || (sr[10] & FW_LEN_MASK) == FW_LEN_MASK) changes = true;
+                    if ((sr[10] & FW_LEN_MASK) == FW_LEN_MASK || (sr[8] & FL_BLANK) || (!CHANGING && (sr[3] & 0x8000u))) changes = true;
                     const uint32_t q = n_act + w.rank(ms);
                     L.act[q][0] = lean_val(640 + q, sr[0], true); L.act[q][1] = sr[10];
+                }
+                if (CHANGING) {
+                    uint64_t mc = w.ballot(shit && (rc[srec + 3] & 0x8000u) != 0);
+                    while (mc) { const uint32_t l = ctz64(mc); mc &= mc - 1; chg |= 1ull << (n_act + popc64(ms & ((1ull << l) - 1))); }
                 }
                 n_act += popc64(ms);
             }
@@ -377,6 +384,66 @@ TP_HD_FLAT TP_NOINLINE LeanAcc lean_emit_wide(W& w, const TT& t, LeanLds& L, uin
         safe_key = min32(safe_key, lean_safe_key((fb & 64u) != 0, L.act[lane][1], base_a + w.rank(ma)));
     }
     return a;
+}
+
+// A final list with action tags NormalizeTag changes (bits of chg; fb bit 6: the tag is in the list; its position is base_a +
+// its rank among those).  The list in fin32[0 .. nf) stays what the verdict and the audit row speak of; the caption's list
+// is that list with NormalizeTag applied and first occurrences kept (FormatCaptionSingleLine, Program.cs:971-974): only a
+// changed tag's new form can meet another element.  The caption's list replaces the final list in fin32; the final list goes
+// to aud_row (AUD_KEPT) when there is one.  GetUnknownTags (Program.cs:817-824) normalises the same way, so the tags outside
+// the vocabulary are counted in the caption's list (unknown, their bytes in ubytes).  n = LEAN_DEAD: not for this stage.
+struct LeanCap { uint32_t n, bytes, unknown, ubytes; };
+template <class W, class TT>
+TP_HD_FLAT TP_NOINLINE LeanCap lean_caption_fix(W& w, const TT& t, LeanLds& L, uint32_t* fin32, uint32_t fb, uint32_t base_a, uint32_t n_act, uint64_t chg, uint32_t nf,
+                                                uint32_t* aud_row) {
+    const uint32_t lane = w.lane();
+    w.sync();                                                       // the final list is in fin32
+    uint32_t* cN = L.tab;                                           // the changed tags' new forms and positions (the table area is idle here)
+    uint32_t* cP = L.tab + 64;
+    const uint64_t ma = w.ballot(fb & 64u);
+    const bool mine = lane < n_act && (fb & 64u) != 0 && ((chg >> lane) & 1ull) != 0;
+    const uint64_t mc = w.ballot(mine);
+    bool bad = false;
+    if (mine) {
+        const uint32_t N = t.next[L.act[lane][0] & LEAN_ID_MASK];
+        const uint32_t fwN = t.fw_tix[2 * (size_t)N];
+        bad = (fwN & FW_BLANK) != 0 || (fwN & FW_LEN_MASK) == FW_LEN_MASK;
+        cN[w.rank(mc)] = N; cP[w.rank(mc)] = base_a + w.rank(ma);
+    }
+    if (w.ballot(bad) != 0) return LeanCap{LEAN_DEAD, 0, 0, 0};
+    w.sync();
+    const uint32_t nc = popc64(mc);
+    uint32_t id[2], cap[2];
+    bool have[2], keep[2];
+    for (uint32_t e = 0; e < 2; ++e) {
+        const uint32_t j = lane + 64 * e;
+        have[e] = j < nf;
+        id[e] = have[e] ? fin32[j] : NO_ID;
+        cap[e] = id[e];
+        keep[e] = have[e];
+    }
+    for (uint32_t c = 0; c < nc; ++c) for (uint32_t e = 0; e < 2; ++e) if (lane + 64 * e == cP[c]) cap[e] = cN[c];
+    for (uint32_t c = 0; c < nc; ++c) {
+        const uint32_t N = cN[c], P = cP[c];
+        bool earlier = false;
+        for (uint32_t e = 0; e < 2; ++e) {
+            const uint32_t j = lane + 64 * e;
+            if (have[e] && j != P && cap[e] == N) { if (j < P) earlier = true; else keep[e] = false; }
+        }
+        if (w.ballot(earlier) != 0) for (uint32_t e = 0; e < 2; ++e) if (lane + 64 * e == P) keep[e] = false;
+    }
+    uint32_t len = 0, unk = 0, ulen = 0;
+    for (uint32_t e = 0; e < 2; ++e) if (keep[e]) {
+        const uint32_t fw = t.fw_tix[2 * (size_t)cap[e]];
+        len += fw & FW_LEN_MASK;
+        if (t.known_active && (fw & FW_UNKNOWN)) { ++unk; ulen += fw & FW_LEN_MASK; }
+    }
+    const uint64_t k0 = w.ballot(keep[0]), k1 = w.ballot(keep[1]);
+    if (aud_row) for (uint32_t e = 0; e < 2; ++e) if (have[e]) aud_row[AUD_KEPT + lane + 64 * e] = id[e];
+    w.sync();                                                       // every lane has read its part of the list
+    if (keep[0]) fin32[w.rank(k0)] = cap[0];
+    if (keep[1]) fin32[popc64(k0) + w.rank(k1)] = cap[1];
+    return LeanCap{popc64(k0) + popc64(k1), w.sum(len), w.sum(unk), w.sum(ulen)};
 }
 
 // The piece of the line this lane scans: the aligned 16 bytes number `lane` from the 16-byte boundary at or before the
@@ -685,6 +752,7 @@ TP_HD_FLAT bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, co
     // ---- InferActionTags / EnsureRequiredFacets (Program.cs:731-775): both read the evidence only -------------------------
     bool frules_possible;
     uint32_t n_act = 0;                                             // tags the action rules offer (in L.act)
+    uint64_t chg = 0;                                               // those of them NormalizeTag changes (the detail build takes such files)
     {
         bool lit_r = false, lit_f = false;
         for (uint32_t k = lane; k < t.lit_words; k += 64) {
@@ -695,7 +763,7 @@ TP_HD_FLAT bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, co
         frules_possible = t.frules_vacuous || w.ballot(lit_f) != 0;
         const bool rules_possible = w.ballot(lit_r) != 0;           // the evidence holds a literal some action rule tests positively: look closer
         if (rules_possible) {
-            n_act = lean_actions(w, t, L, rc, fired);
+            n_act = lean_actions<DETAIL>(w, t, L, rc, fired, chg);
             if (n_act == LEAN_DEAD) return LEAN_NO(11);
         } else if (fired && lane < t.fired_words) fired[lane] = 0;
     }
@@ -899,8 +967,20 @@ TP_HD_FLAT bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, co
     v.n_evidence = (uint16_t)n_evidence;
     v.n_unknown = (uint16_t)unknown;
     v.n_dropped = (uint16_t)n_dropped;
-    out.n_final = nf;
-    out.caption_len = bytes + 2 * (nf - 1) + t.newline_len;
+    uint32_t n_cap = nf, cap_bytes = bytes;                         // the caption's list is the final list, unless NormalizeTag changes one of its tags
+    if constexpr (DETAIL) {
+        if (chg != 0) {
+            const LeanCap c = lean_caption_fix(w, t, L, fin32, fb, nr + grown1 + grown2, n_act, chg, nf, aud.row);
+            if (c.n == LEAN_DEAD) return LEAN_NO(16);
+            n_cap = c.n; cap_bytes = c.bytes;
+            v.n_tags = (uint16_t)n_cap;
+            v.n_unknown = (uint16_t)c.unknown;
+            if (aud.row && lane == 0) { aud.cnt[AUDIT_UNKNOWN] = n_cap; aud.len[AUDIT_UNKNOWN] = c.ubytes + (c.unknown ? c.unknown - 1 : 0u); }
+        }
+        if (aud.row && lane == 0) aud.row[AUD_FLAGS] = chg != 0 ? 1u : 0u;
+    }
+    out.n_final = n_cap;
+    out.caption_len = cap_bytes + 2 * (n_cap - 1) + t.newline_len;
     w.tick(24);
     return out.caption_len <= FAST_CAPTION_MAX;
 }
