@@ -592,7 +592,17 @@ TP_HD bool has_refusal_phrase_nocolon(const uint8_t* s, uint32_t a, uint32_t b) 
 // (used once at load time to evaluate the minimal fallback line, Program.cs:298).
 // mode 3: whole span, and the lists of the audit row are kept and sized (see FileOut).
 // ================================================================================================
+#if defined(TP_PIPE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define TP_PIPE_STAMP(k) pipe_stamp[k] = wall_clock64();
+#define TP_PIPE_STAMP_DECL unsigned long long pipe_stamp[16] = {0}; pipe_stamp[0] = wall_clock64();
+#define TP_PIPE_STAMP_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) { printf("pipe stamps (100 MHz ticks):"); for (int q = 1; q < 16; ++q) printf(" %d:%llu", q, pipe_stamp[q] ? pipe_stamp[q] - pipe_stamp[0] : 0ull); printf("\n"); }
+#else
+#define TP_PIPE_STAMP(k)
+#define TP_PIPE_STAMP_DECL
+#define TP_PIPE_STAMP_PRINT
+#endif
 TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOut& out, uint32_t* fired, uint16_t* facet_choice, int mode) {
+    TP_PIPE_STAMP_DECL
     tp_verdict& v = out.verdict;
     v.coverage = 0; v.flags = 0; v.n_tags = 0; v.n_candidates = 0; v.n_selected = 0; v.safe_hit = -1; v.n_evidence = 0; v.n_unknown = 0; v.n_dropped = 0;
     out.n_final = 0;
@@ -686,6 +696,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             if (has_colon ? has_refusal_phrase(s, a, b) : has_refusal_phrase_nocolon(s, a, b)) rejected = true;
             else if (commas < 2 && (has_high ? utf16_units(s + a, b - a) : b - a) > 40) rejected = true;   // s.Length: UTF-16 units (Program.cs:1146)
         }
+        TP_PIPE_STAMP(12)
         if (!rejected) {
             // SplitTags -> NormalizeTag -> Length >= 2 -> !ShouldDropTag -> Distinct (Program.cs:598-602); the join and the second
             // SplitTags (Program.cs:604, 578) return the same strings because no surviving tag holds ',' or white space.
@@ -711,6 +722,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
                 i = j + 1;
             }
         }
+        TP_PIPE_STAMP(13)
         if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
         if (mode == 2) {
             // Existing-caption triage stops here: LooksBad of the kept tags joined with ", " (Program.cs:206-207, 604, 1141-1147)
@@ -821,6 +833,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     }
     v.n_candidates = (uint16_t)(n > 0xFFFF ? 0xFFFF : n);
 
+    TP_PIPE_STAMP(1)
     // ---------------- DetermineStyleQualityCap (Program.cs:702-710) ----------------
     int style_cap;
     {
@@ -836,6 +849,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         style_cap = ns < 2 ? 2 : ns;                             // Clamp(n, 2, 4)
     }
 
+    TP_PIPE_STAMP(2)
     // ---------------- SelectTags, first half (Program.cs:625-655) + BuildEvidenceTags (Program.cs:721-729) ----------------
     // Both walk the candidates in order applying NormalizeTag once, so they share the walk.  The unique list is compacted
     // in place: entry nu is written only after candidate i >= nu has been read.
@@ -911,6 +925,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         ws.sorted[pos] = k;
     }
 
+    TP_PIPE_STAMP(3)
     // ---------------- SelectTags, second half (Program.cs:661-699) ----------------
     uint32_t nr = 0;   // result list, built in ws.fin
     auto add_one = [&](H tag) -> bool {                           // AddOne, Program.cs:692-699
@@ -956,6 +971,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     v.n_selected = (uint16_t)nr;
     if (mode == 1) { out.n_final = nr; return; }
 
+    TP_PIPE_STAMP(4)
     // ---------------- EvaluateCoverage (Program.cs:1056-1095) and normalizedFinalSet (Program.cs:303) ----------------
     // Both start from Select(NormalizeTag).Where(non-blank).Distinct() of the selected tags: computed once, in place.
     uint32_t nf = 0;
@@ -994,6 +1010,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         }
     }
 
+    TP_PIPE_STAMP(5)
     // ---------------- evidence closure (Program.cs:301-302) ----------------
     expand_implied(t, ws, ws.ev, ne, ws.cap_e, overflow);
     v.n_evidence = (uint16_t)((ne > 0xFFFF || !fired) ? 0xFFFF : ne);   // counted for callers that take the detail arrays
@@ -1015,9 +1032,11 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         }
     }
 
+    TP_PIPE_STAMP(6)
     // ---------------- final set closure (Program.cs:304-305) ----------------
     expand_implied(t, ws, ws.fin, nf, ws.cap_f, overflow);
 
+    TP_PIPE_STAMP(7)
     // ---------------- InferActionTags (Program.cs:731-753) ----------------
     {
         uint32_t ni = 0;
@@ -1045,6 +1064,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             }
         }
     }
+    TP_PIPE_STAMP(8)
     // ---------------- EnsureRequiredFacets (Program.cs:755-775) ----------------
     for (uint32_t f = 0; f < t.n_facets; ++f) {
         const DFacet& facet = t.facets[f];
@@ -1059,6 +1079,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         if (!lfind(ws, ws.fin, nf, (H)selected)) { if (nf >= ws.cap_f) overflow = true; else ws.fin[nf++] = selected; }
     }
 
+    TP_PIPE_STAMP(9)
     // ---------------- verdicts on the final list (Program.cs:319, 329) ----------------
     {
         bool face = false, outfit = false;
@@ -1074,6 +1095,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         if (t.safe_mode && safe >= 0) { flags |= TP_F_SAFE_REJECT; v.safe_hit = (int16_t)safe; }
     }
 
+    TP_PIPE_STAMP(10)
     // ---------------- the audit row's lists (Program.cs:334, 966) ----------------
     // keptTags is the final list as it stands here, before FormatCaptionSingleLine normalises it again: a copy goes to
     // ws.snap, which the closures no longer need (cap_snap >= cap_f >= nf).
@@ -1086,6 +1108,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         for (uint32_t i = 0; i < ntop; ++i) alen[AUDIT_TOP] += hbytes(t, ws.top[i]) + (i ? 1u : 0u);
     }
 
+    TP_PIPE_STAMP(11)
     // ---------------- FormatCaptionSingleLine (Program.cs:971-974) and GetUnknownTags (Program.cs:817-824) ----------------
     // Both take Select(NormalizeTag).Where(non-blank).Distinct() of the final list.
     uint32_t nc = 0, bytes = 0, unknown = 0;
@@ -1112,6 +1135,8 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         out.review_bits = rbits;
         for (int c = 0; c < AUDIT_COLS; ++c) out.audit_len[c] = alen[c];
     }
+    TP_PIPE_STAMP(14)
+    TP_PIPE_STAMP_PRINT
     out.caption_len = bytes + (nc ? 2 * (nc - 1) : 0) + t.newline_len;    // string.Join(", ", …) + Environment.NewLine, Program.cs:316-317
 }
 
