@@ -238,6 +238,28 @@ def test_review_rows(name):
         assert any(b"male_subject_token" in x for x in got.review_jsonl)
 
 
+def test_audit_mode_stays_in_the_wave_stage_on_c2():
+    """c2 in audit mode: the lean stage lists what the audit row and the review record want, so only files it cannot take
+    (more than 64 tags) reach the thread-per-file kernel.  Among its files are those whose final list holds an action tag
+    NormalizeTag changes (Program.cs:738): the row's final_tags keep the tag as the rule names it, the caption has its
+    normalised form (Program.cs:972)."""
+    from imagecaptioner_amd.corpus import make_corpus
+    n = 6000
+    c = make_corpus("c2", n, seed=77)
+    cfg = Config(**c.config_kwargs)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    audit = _review_args(n)
+    got, want = p.run_lines(c.arena, c.offsets, audit=audit), o.run_lines(c.arena, c.offsets, threads=16, detail=True, audit=audit)
+    assert p.last_timing()["general_files"] <= n // 500
+    _check_audit(got, want)
+    _check_review(got, want)
+    assert np.array_equal(got.captions, want.captions) and got.verdicts.tobytes() == want.verdicts.tobytes()
+    differ = sum(1 for i in range(n) if got.audit_lists[i][0].replace(b";", b", ") != got.caption(i).rstrip(b"\n"))
+    assert differ >= 5, differ
+    plain = p.run_lines(c.arena, c.offsets)
+    assert plain.verdicts.tobytes() == got.verdicts.tobytes() and np.array_equal(plain.captions, got.captions)
+
+
 def test_audit_mode_takes_text_outside_ascii():
     """Audit mode (thread-per-file kernel) on lines with characters outside ASCII; the JSON line escapes them the way
     System.Text.Json does."""
