@@ -208,8 +208,8 @@ TP_HD_FLAT void lean_note_tokens(W& w, const TT& t, LeanFrontLds& L, const uint8
     const uint32_t lane = w.lane();
     const uint32_t shift = (uint32_t)((uintptr_t)text & 15);
     const uint8_t* s = L.line + 16 + shift;
-    uint32_t T = 0;
-    for (uint32_t k = 1; k <= 65; ++k) if (L.cpos[k] == len) { T = k; break; }   // cpos[T] = len (commas lie below len)
+    const uint64_t at = w.ballot(L.cpos[lane + 1] == len);         // cpos[T] = len (commas lie below len), 1 <= T <= 65
+    const uint32_t T = at ? ctz64(at) + 1 : (L.cpos[65] == len ? 65u : 0u);
     if (lane < T) {
         uint32_t i = L.cpos[lane] + 1, j = L.cpos[lane + 1];
         if (i < j && ws1(s[i])) ++i;
