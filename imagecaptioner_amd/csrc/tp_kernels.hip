@@ -611,6 +611,7 @@ __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
         };
         for (int c = 0; c < AUDIT_COLS; ++c) {
             const uint32_t cnt = a.audit_cnt[(f - a.file0) * AUDIT_COLS + c];
+            if (a.offsets[f * AUDIT_COLS + c + 1] == a.offsets[f * AUDIT_COLS + c]) continue;   // no text: none of the entries qualifies (the usual unknown-tag column)
             uint8_t* out = a.text + a.offsets[f * AUDIT_COLS + c];
             const uint8_t sep = c >= AUDIT_TOP ? (uint8_t)'\n' : (uint8_t)';';
             uint32_t running = 0, kept_before = 0;
