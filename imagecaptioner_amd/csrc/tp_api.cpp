@@ -446,6 +446,7 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     c->in_arena.need(arena_bytes + 64);
     c->in_offsets.need(n_offsets * 8);
     if (arena_bytes) HIP_OK(hipMemcpyAsync(c->in_arena.p, arena, arena_bytes, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemsetAsync((uint8_t*)c->in_arena.p + arena_bytes, 0, 64, s));   // the lean stage reads whole 16-byte pieces: what lies behind the last line is not left to chance (a byte outside ASCII there sends that file the long way)
     HIP_OK(hipMemcpyAsync(c->in_offsets.p, offsets, n_offsets * 8, hipMemcpyHostToDevice, s));
     if (tag_begin) {
         c->in_tag_begin.need((n_files + 1) * 8); c->in_scores.need(std::max<uint64_t>(n_tags, 1) * 8); c->in_sources.need(std::max<uint64_t>(n_tags, 1));
@@ -835,6 +836,7 @@ static int triage_host(tp_ctx* c, const uint8_t* arena, const uint64_t* offsets,
     c->in_arena.need(arena_bytes + 64);
     c->in_offsets.need((n_files + 1) * 8);
     if (arena_bytes) HIP_OK(hipMemcpyAsync(c->in_arena.p, arena, arena_bytes, hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemsetAsync((uint8_t*)c->in_arena.p + arena_bytes, 0, 64, s));   // the lean stage reads whole 16-byte pieces: what lies behind the last line is not left to chance (a byte outside ASCII there sends that file the long way)
     HIP_OK(hipMemcpyAsync(c->in_offsets.p, offsets, (n_files + 1) * 8, hipMemcpyHostToDevice, s));
     c->out_offsets.need((n_files + 1) * 8);
     c->out_verdicts.need(n_files * sizeof(tp_verdict));

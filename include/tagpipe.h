@@ -291,7 +291,7 @@ void tp_release_replies(tp_replies* replies);
  * set histogram and counters back to what they held before the failed call.
  */
 typedef struct tp_device_io {
-    const uint8_t*  arena;            /* in; 16 bytes past offsets[n_files] must be readable (the kernels fetch texts in aligned pieces) */
+    const uint8_t*  arena;            /* in; 16 bytes past offsets[n_files] must be readable (the kernels fetch texts in aligned pieces; zeros there keep the last file on the fastest path) */
     const uint64_t* offsets;          /* in, n_files + 1 */
     uint64_t        n_files;
     uint8_t*        captions;         /* out */

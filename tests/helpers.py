@@ -623,3 +623,31 @@ def check_joytag_replies(engine, oracle):
     want = oracle.run_replies([b for b, _ in BAD_REPLIES])
     assert [int(x) for x in want.reply_status] == [st if st != 2 else 0 for _, st in BAD_REPLIES]
     assert all(d["tag_begin"][i + 1] == d["tag_begin"][i] for i, (_, st) in enumerate(BAD_REPLIES) if st)
+
+
+def changed_action_case():
+    """A configuration whose action rules name tags NormalizeTag changes (lexicon aliases and the built-in "fellatio"), and
+    lines on which the changed tag meets an earlier element of the final list, a later one, another changed tag, or none."""
+    import json
+    lex = {"aliases": {"bj": "blowjob", "oral_act": "blowjob", "hj": "handjob"}, "implied": {"barefoot": ["feet"]}}
+    actions = [
+        {"parent_tag": "bj", "required_all": ["penis"], "required_any": ["mouth", "oral"], "forbidden_any": [],
+         "subtypes": [{"tag": "oral_act", "match_any": ["oral"], "match_all": []}, {"tag": "deepthroat", "match_any": ["deepthroat"], "match_all": []}]},
+        {"parent_tag": "hj", "required_all": ["penis", "hand"], "required_any": [], "forbidden_any": [], "subtypes": []},
+        {"parent_tag": "blowjob", "required_all": ["penis", "sucking"], "required_any": [], "forbidden_any": [],
+         "subtypes": [{"tag": "fellatio", "match_any": ["sucking"], "match_all": []}]},
+    ]
+    facets = {"act": {"default": "blowjob", "rules": [{"tag": "handjob", "match_any": ["hand"], "match_all": []}]},
+              "view": {"default": "unknown_view", "rules": []}}
+    vocab = ("\n".join(["1girl", "solo", "smile", "penis", "mouth", "dress", "oral", "blowjob", "hand", "sucking", "deepthroat", "barefoot", "feet",
+                        "long_hair", "standing", "handjob", "unknown_view"]) + "\n").encode()
+    cfg = Config(lexicon=json.dumps(lex).encode(), actions=json.dumps(actions).encode(), required_facets=json.dumps(facets).encode(),
+                 vocabulary=vocab, vocabulary_is_json=0, minimal_subject_tags="1girl, solo")
+    lines = ["1girl, smile, penis, mouth, dress",                       # bj -> blowjob, the facet's default blowjob comes later
+             "1girl, smile, penis, oral, dress",                        # bj and oral_act: two changed tags with one new form
+             "1girl, smile, penis, oral, blowjob, dress",               # the new form is a selected tag already
+             "1girl, smile, penis, hand, mouth, dress",                 # hj -> handjob meets the facet rule's handjob; bj as well
+             "1girl, smile, penis, sucking, dress",                     # blowjob, then fellatio -> blowjob
+             "1girl, smile, penis, sucking, oral, hand, deepthroat, barefoot, dress",
+             "1girl, smile, dress, long_hair, standing"]
+    return cfg, lines

@@ -260,6 +260,23 @@ def test_audit_mode_stays_in_the_wave_stage_on_c2():
     assert plain.verdicts.tobytes() == got.verdicts.tobytes() and np.array_equal(plain.captions, got.captions)
 
 
+def test_audit_rows_with_action_tags_normalize_tag_changes():
+    """The audit row keeps a rule's tag as the rule names it; the caption and the unknown-tag list have its normalised form
+    (Program.cs:738, 972, 819).  Crafted collisions, all in the lean stage's detail build."""
+    from helpers import changed_action_case
+    cfg, lines = changed_action_case()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    audit = _review_args(len(lines))
+    got, want = p.run_texts(lines, audit=audit), o.run_texts(lines, detail=True, audit=audit)
+    assert p.last_timing()["general_files"] == 0
+    _check_audit(got, want)
+    _check_review(got, want)
+    assert np.array_equal(got.captions, want.captions) and got.verdicts.tobytes() == want.verdicts.tobytes()
+    assert b";bj" in got.audit_lists[0][0] and b"bj" not in got.caption(0).replace(b"blowjob", b"")
+    plain = p.run_texts(lines)
+    assert plain.verdicts.tobytes() == got.verdicts.tobytes() and np.array_equal(plain.captions, got.captions)
+
+
 def test_audit_mode_takes_text_outside_ascii():
     """Audit mode (thread-per-file kernel) on lines with characters outside ASCII; the JSON line escapes them the way
     System.Text.Json does."""

@@ -382,3 +382,17 @@ def test_candidates_that_end_in_one_tag_stay_in_the_wave_stages():
     got, want = s.run_lines_lean(c.arena, c.offsets, details=True), Oracle(cfg).run_lines(c.arena, c.offsets, threads=8)
     assert_same_results(got, want, s.histogram_dict(got.histogram), "c3c")
     assert got.n_general == 0
+
+
+def test_action_tags_that_normalize_tag_changes_stay_in_the_lean_stage():
+    """InferActionTags adds a rule's tag as the rule names it (Program.cs:738, 745); FormatCaptionSingleLine and GetUnknownTags
+    normalise the final list again and keep first occurrences (Program.cs:972, 819).  The lean stage's detail build takes such
+    files: the changed tag meets an earlier element (the built-in subtype "fellatio" behind its parent "blowjob"), a later one
+    (a facet's default tag), another changed tag, or nothing."""
+    from helpers import changed_action_case
+    cfg, lines = changed_action_case()
+    o, s = Oracle(cfg), HostSim(cfg)
+    want, got = o.run_texts(lines), s.run_texts_lean(lines)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), "changed action tags")
+    assert got.n_general == 0 and got.n_lean == len(lines)
+    assert b"bj" not in want.caption(0).replace(b"blowjob", b"") and want.caption(0).count(b"blowjob") == 1
