@@ -398,8 +398,9 @@ int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t
  *   TP_AUDIT_TOP       TopJoyTags: the tags of the 20 best raw candidates by score, then order (Program.cs:860)
  *   TP_AUDIT_UNKNOWN   the caption's tags outside the vocabulary, in caption order (GetUnknownTags before its sort, Program.cs:817-821)
  * Column c of file i is text[offsets[TP_AUDIT_COLS * i + c] .. offsets[TP_AUDIT_COLS * i + c + 1]); tp_get_audit's pointers live
- * as long as the result.  In audit mode every file takes the thread-per-file kernel (the wave-per-file kernels do not keep these lists),
- * so a run is slower than without it.  n_selected in the verdicts is exact in every mode; n_evidence is counted.
+ * as long as the result.  In audit mode the first wave-per-file stage keeps these lists for the files it takes; a file it
+ * declines takes the thread-per-file kernel (the later wave-per-file stages do not keep them), so a run is slower than without
+ * it.  n_selected in the verdicts is exact in every mode; n_evidence is counted.
  */
 #define TP_AUDIT_KEPT     0
 #define TP_AUDIT_EVIDENCE 1

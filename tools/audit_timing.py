@@ -1,5 +1,5 @@
-"""Device time of a run in audit mode (tp_set_audit: every file through the thread-per-file kernel, the audit row's tag lists kept
-and emitted as text) beside the same run without it, and the host time of tp_format_audit_rows."""
+"""Device time of a run in audit mode (tp_set_audit: the audit row's tag lists kept by the lean stage, or by the thread-per-file kernel
+for the files it declines, and emitted as text) beside the same run without it, and the host time of tp_format_audit_rows."""
 import os
 import sys
 import time
