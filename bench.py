@@ -4,8 +4,13 @@
 One "step" is one pass of the whole hot path (tp_run_lines_device: workspace sizing, the per-file pipeline
 kernels, caption-offset scan, caption/histogram emit) over one resident shard of synthetic tag files, plus —
 on more than one GPU — the RCCL all-reduce of the tag histogram and counters.  Inputs are in HBM before
-the timed region starts.  Weak scaling: every rank owns `--files` files (default 1,000,000: BASELINE
-config 2, "1M tag files, ~40 tags/file, 20k-entry lexicon, single MI355X").
+the timed region starts.  Weak scaling (the default): every rank owns `--files` files (default 1,000,000: BASELINE
+config 2, "1M tag files, ~40 tags/file, 20k-entry lexicon, single MI355X").  `--scaling strong` (BASELINE config 3's
+shape: ONE corpus sharded over the GPUs): `--files` is the whole job's file count, rank r takes the contiguous range
+shard_range(files, r, N) of that one seeded corpus, and after the timed region rank 0 checks that the shards, in rank
+order, are the single-GPU output (per-shard sha256 against its own run over the whole corpus, when that fits
+`--verify-files`), that the all-reduced histogram and counters equal the single-GPU ones, and - at the committed golden
+size - that the whole run's digest is the one in tests/golden/corpus_digests.json.
 
 `--gpus N` with N > 1, started as a plain `python bench.py`, starts N child processes of this same script (one
 per GPU, before this process has imported torch or made any GPU call) and waits for them; started under
@@ -43,6 +48,9 @@ def main():
     ap.add_argument("--cpu-single-sample", type=int, default=20_000, help="files timed on ONE host thread; 0 = skip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (RCCL) is the measured configuration; gloo (sums on the host) is for rehearsals")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (RCCL refuses two ranks on one GPU: use --backend gloo)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --files per GPU; strong: --files in all, one corpus sharded by rank")
+    ap.add_argument("--verify-files", type=int, default=2_000_000, help="strong scaling: rank 0 reruns the whole corpus on its own GPU to check the shards when the corpus has at most this many files")
+    ap.add_argument("--e2e-runs", type=int, default=2, help="1 GPU: timed calls of tp_run_lines (host buffers in, host results out) for the end-to-end rate; 0 = skip")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -75,9 +83,17 @@ def main():
     from imagecaptioner_amd._abi import tp_device_io
     from imagecaptioner_amd.corpus import make_corpus
 
-    # ---- synthetic shard of this rank (seeded; every rank draws its own files from the same tables) ----
+    # ---- synthetic shard of this rank ----
+    # weak: every rank draws its own --files files from the same tables (seeded by rank);
+    # strong: ONE corpus of --files files, of which this rank builds and owns the contiguous range shard_range gives it
+    from imagecaptioner_amd.dist import check_shards_against_whole, shard_digest, shard_range
+    strong = args.scaling == "strong"
     t0 = time.time()
-    corpus = make_corpus(args.config, args.files, seed=args.seed + 7919 * rank)
+    if strong:
+        shard_lo, shard_hi = shard_range(args.files, rank, world)
+        corpus = make_corpus(args.config, args.files, seed=args.seed, file_range=(shard_lo, shard_hi))
+    else:
+        corpus = make_corpus(args.config, args.files, seed=args.seed + 7919 * rank)
     gen_s = time.time() - t0
     cfg = Config(device=local_rank, **corpus.config_kwargs)
     pipe = TagPipe(cfg)
@@ -90,7 +106,7 @@ def main():
     cap_capacity = max(4 * in_bytes, 1 << 20)
     captions = torch.empty(cap_capacity, dtype=torch.uint8, device=dev)
     cap_offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    verdicts = torch.empty(n * 16, dtype=torch.uint8, device=dev)
+    verdicts = torch.empty(max(n, 1) * 16, dtype=torch.uint8, device=dev)
     hist = torch.zeros(pipe.info.n_strings + 1, dtype=torch.int64, device=dev)
     counters = torch.zeros(8, dtype=torch.int64, device=dev)
 
@@ -144,11 +160,61 @@ def main():
         if int(hist.sum().item()) != int(tags.item()):
             raise SystemExit("bench.py: the all-reduced histogram does not add up to the ranks' tag counts")
 
+    # ---- strong scaling: the shards in rank order are the single-GPU output; the summed histogram is the single-GPU one ----
+    strong_check = None
+    if strong:
+        mine = shard_digest(captions[:int(cap_bytes)].cpu().numpy(), range(n + 1))
+        digests = [mine]
+        if world > 1:
+            digests = [None] * world
+            dist.all_gather_object(digests, mine)
+        if rank == 0:
+            strong_check = {"files_in_all": args.files, "shard_files": [d[2] for d in digests], "shard_caption_bytes": [d[1] for d in digests],
+                            "whole_run_checked": False, "golden_checked": False}
+            if args.files <= args.verify_files:
+                import hashlib
+                full = corpus if world == 1 else make_corpus(args.config, args.files, seed=args.seed)
+                fa = torch.cat([torch.from_numpy(full.arena).to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)])
+                fo = torch.from_numpy(full.offsets.astype(np.int64)).to(dev)
+                fcap_n = max(4 * int(full.offsets[-1]), 1 << 20)
+                fcap = torch.empty(fcap_n, dtype=torch.uint8, device=dev)
+                fcoff = torch.empty(args.files + 1, dtype=torch.int64, device=dev)
+                fver = torch.empty(max(args.files, 1) * 16, dtype=torch.uint8, device=dev)
+                fhist, fctr = torch.zeros_like(hist), torch.zeros_like(counters)
+                fio = tp_device_io()
+                fio.arena, fio.offsets, fio.n_files = fa.data_ptr(), fo.data_ptr(), args.files
+                fio.captions, fio.caption_capacity, fio.caption_offsets = fcap.data_ptr(), fcap_n, fcoff.data_ptr()
+                fio.verdicts, fio.histogram, fio.counters = fver.data_ptr(), fhist.data_ptr(), fctr.data_ptr()
+                fio.fired, fio.facet_choice = None, None
+                fio.stream = torch.cuda.current_stream().cuda_stream
+                fbytes = pipe.run_lines_device(fio)
+                torch.cuda.synchronize()
+                whole_caps = fcap[:fbytes].cpu().numpy()
+                whole_offs = fcoff.cpu().numpy().astype(np.uint64)
+                msg = check_shards_against_whole(digests, whole_caps, whole_offs, world)
+                if msg is None and not torch.equal(fhist, hist):
+                    msg = "the all-reduced histogram differs from the single-GPU histogram"
+                if msg is None and not torch.equal(fctr, counters):
+                    msg = "the all-reduced counters differ from the single-GPU counters"
+                if msg is not None:
+                    raise SystemExit("bench.py --scaling strong: " + msg)
+                strong_check["whole_run_checked"] = True
+                try:
+                    with open(os.path.join(ROOT, "tests", "golden", "corpus_digests.json")) as f:
+                        g = json.load(f).get(args.config)
+                except OSError:
+                    g = None
+                if g and g["n_files"] == args.files and args.seed == 1234:
+                    if hashlib.sha256(whole_caps.tobytes()).hexdigest() != g["captions_sha256"]:
+                        raise SystemExit("bench.py --scaling strong: the captions' digest is not the committed golden digest")
+                    strong_check["golden_checked"] = True
+                del fa, fo, fcap, fcoff, fver
+
     # ---- correctness spot check outside the timed region: device result == oracle on a prefix ----
     check_n = min(n, 2000)
     from oracle.oracle_py import Oracle
     oracle = Oracle(Config(**corpus.config_kwargs))
-    want = oracle.run_lines(corpus.arena, corpus.offsets[:check_n + 1], threads=8)
+    want = oracle.run_lines(corpus.arena, corpus.offsets[:check_n + 1], threads=8)   # (a rank whose shard is empty checks an empty prefix)
     got_off = cap_offsets[:check_n + 1].cpu().numpy().astype(np.uint64)
     got_cap = captions[:int(got_off[-1])].cpu().numpy()
     got_ver = verdicts[:check_n * 16].cpu().numpy().copy().view(want.verdicts.dtype)
@@ -165,7 +231,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    files_total = n * world
+    files_total = args.files if strong else n * world
     value = files_total * args.steps / elapsed
     # algorithmic bytes per file: input line + input offset + caption line + caption offset + verdict record
     alg_bytes = in_bytes + 8 * n + int(cap_bytes) + 8 * n + 16 * n
@@ -195,15 +261,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "%s: %d tag files per GPU, %.0f input bytes/file" % (args.config, n, in_bytes / n),
+        "config": {"workload": ("%s: ONE corpus of %d tag files sharded over %d GPU(s), %.0f input bytes/file" % (args.config, args.files, world, in_bytes / max(n, 1))) if strong
+                               else "%s: %d tag files per GPU, %.0f input bytes/file" % (args.config, n, in_bytes / n),
                    "files_per_gpu": n, "input_bytes_per_file": in_bytes / n, "caption_bytes_per_file": cap_bytes / n,
                    "kernel_ms": kernel_ms,
                    "files_in_general_kernel": int(gen_files),
                    "parallelism": ("files sharded by rank; histogram all-reduce (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal")) if world > 1 else "single GPU",
+                   "collective": {"backend": (args.backend if world > 1 else None), "world_size_seen": (dist.get_world_size() if world > 1 else 1)},
+                   "strong_scaling_check": strong_check,
                    "corpus_gen_s": gen_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": step_ms,
@@ -211,6 +280,32 @@ def main():
                                    "the step, all kernels; traffic = HBM bytes of all kernels of one step from the FETCH_SIZE/WRITE_SIZE passes",
                      "longest_kernel": dominant, "longest_kernel_ms": kernel_ms[dominant]},
     }
+
+    if world == 1 and args.e2e_runs > 0:
+        # End to end through tp_run_lines: pinned host buffers in (H2D), the same kernels, every result back in host memory
+        # (D2H: captions, offsets, verdicts, histogram, detail arrays).  File-system time is not part of it.  Never `value`.
+        h_arena = torch.from_numpy(corpus.arena).pin_memory()
+        h_offs = torch.from_numpy(corpus.offsets.astype(np.int64)).pin_memory()
+        L, h = pipe._L, pipe._h
+        from imagecaptioner_amd._abi import tp_result
+        best = None
+        for k in range(args.e2e_runs + 1):                       # the first call grows the library's staging buffers
+            res = tp_result()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rc = L.tp_run_lines(h, h_arena.data_ptr(), h_offs.data_ptr(), n, C.byref(res))
+            dt = time.perf_counter() - t1
+            if rc != 0:
+                raise SystemExit("bench.py: tp_run_lines failed: %s" % L.tp_last_error().decode())
+            assert int(res.caption_offsets[n]) == int(cap_bytes)
+            L.tp_release(h, C.byref(res))
+            if k > 0:
+                best = dt if best is None else min(best, dt)
+        out["config"]["end_to_end_files_per_s"] = n / best
+        out["config"]["end_to_end"] = {"files_per_s": n / best, "ms_per_call": best * 1e3, "calls_timed": args.e2e_runs,
+                                       "what": "tp_run_lines: pinned host arena + offsets in (H2D %.2f GB), all kernels, captions + offsets + verdicts + histogram + "
+                                               "detail arrays back to host memory (D2H %.2f GB); best of the timed calls; no file-system time" %
+                                               ((in_bytes + 8 * n) / 1e9, (int(cap_bytes) + 8 * n + 16 * n) / 1e9)}
 
     if world == 1 and args.cpu_sample > 0:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)

@@ -21,11 +21,12 @@ _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 REFERENCE_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "reference_data")
 
 
-def splitmix64(seed, n, stream=0):
-    """n 64-bit values of the splitmix64 sequence started at `seed` (stream offsets the seed)."""
+def splitmix64(seed, n, stream=0, start=0):
+    """n 64-bit values of the splitmix64 sequence started at `seed` (stream offsets the seed), from element `start` on:
+    element i depends on (seed, stream, i) alone, so a slice of a sequence can be drawn without the elements before it."""
     with np.errstate(over="ignore"):
         z = (np.uint64(seed) + np.uint64(stream) * np.uint64(0xD1342543DE82EF95)
-             + (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)))
+             + (np.arange(start + 1, start + n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)))
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return z ^ (z >> np.uint64(31))
@@ -231,8 +232,8 @@ def _tag_counts(kind, n, seed):
     raise ValueError(kind)
 
 
-def _picks(total, pool_n, seed, zipf_s=None):
-    u = _uniform01(splitmix64(seed, total, stream=13))
+def _picks(total, pool_n, seed, zipf_s=None, start=0):
+    u = _uniform01(splitmix64(seed, total, stream=13, start=start))
     if zipf_s is None:
         return np.minimum((u * pool_n).astype(np.int64), pool_n - 1)
     w = 1.0 / np.power(np.arange(1, pool_n + 1, dtype=np.float64), zipf_s)
@@ -241,16 +242,26 @@ def _picks(total, pool_n, seed, zipf_s=None):
     return np.minimum(np.searchsorted(cdf, u), pool_n - 1).astype(np.int64)
 
 
-def make_corpus(name, n_files, seed=1234):
+def make_corpus(name, n_files, seed=1234, file_range=None):
     """One of the benchmark configurations (c1..c5; c3c: c3 with the alias chains inside the vocabulary; c2n: c2 without a
-    vocabulary file) as a Corpus."""
+    vocabulary file) as a Corpus.  file_range = (begin, end): only those files of the n_files-file corpus (byte for byte the
+    slice of the whole corpus; the tag draws before `begin` are skipped, not made), which is how one rank of a sharded run gets
+    its part of ONE corpus without building the rest."""
     name = name.lower()
+    lo, hi = (0, n_files) if file_range is None else (int(file_range[0]), int(file_range[1]))
+    if not (0 <= lo <= hi <= n_files):
+        raise ValueError("file_range outside the corpus")
+
+    def draw(kind, pool_n, zipf_s=None):
+        counts = _tag_counts(kind, n_files, seed)              # every file's tag count (cheap), so that the slice knows where its tags begin
+        first_tag = int(counts[:lo].sum())
+        counts = counts[lo:hi]
+        return counts, _picks(int(counts.sum()), pool_n, seed, zipf_s=zipf_s, start=first_tag)
     if name == "c1":
         with open(os.path.join(REFERENCE_DATA, "top_tags.txt"), "r", encoding="utf-8") as f:
             vocab = [t.strip() for t in f if t.strip()]
         pool = vocab
-        counts = _tag_counts("poisson30", n_files, seed)
-        picks = _picks(int(counts.sum()), len(pool), seed, zipf_s=1.0)
+        counts, picks = draw("poisson30", len(pool), zipf_s=1.0)
         cfg = dict(lexicon=os.path.join(REFERENCE_DATA, "rules", "lexicon.json"), actions=os.path.join(REFERENCE_DATA, "rules", "actions.json"),
                    required_facets=os.path.join(REFERENCE_DATA, "rules", "required_facets.json"),
                    profile=os.path.join(REFERENCE_DATA, "profiles", "sgrui.json"), vocabulary=os.path.join(REFERENCE_DATA, "top_tags.txt"),
@@ -259,8 +270,7 @@ def make_corpus(name, n_files, seed=1234):
         vocab = make_vocabulary(20000, seed=1)
         lex = make_lexicon(vocab, 20000, seed=2)
         pool = vocab + list(lex["aliases"].keys())[:2000]          # alias keys do occur in the input
-        counts = _tag_counts("poisson40", n_files, seed)
-        picks = _picks(int(counts.sum()), len(pool), seed, zipf_s=1.1 if name == "c4" else None)
+        counts, picks = draw("poisson40", len(pool), zipf_s=1.1 if name == "c4" else None)
         cfg = dict(lexicon=json.dumps(lex).encode(), vocabulary=("\n".join(vocab) + "\n").encode(), vocabulary_is_json=0,
                    minimal_subject_tags="1girl, solo")
         if name == "c2n":
@@ -270,8 +280,7 @@ def make_corpus(name, n_files, seed=1234):
         vocab = make_vocabulary(50000, seed=1)
         lex = make_lexicon(vocab, 100000, seed=2, chains=True)
         pool = vocab + list(lex["aliases"].keys())[:20000]
-        counts = _tag_counts("poisson40", n_files, seed)
-        picks = _picks(int(counts.sum()), len(pool), seed)
+        counts, picks = draw("poisson40", len(pool))
         # c3: the vocabulary file holds the plain tags only, so strict vocabulary (which a vocabulary file switches on,
         # Program.cs:999-1002) drops every chain member at ingest (Program.cs:601).  c3c: the chain and cycle members are
         # in the vocabulary file too, so a tag moves one alias hop at each NormalizeTag site and the chains are walked.
@@ -283,11 +292,12 @@ def make_corpus(name, n_files, seed=1234):
         lex = make_lexicon(vocab, 20000, seed=2)
         actions, facets = make_dense_rules(vocab)
         pool = vocab + list(lex["aliases"].keys())[:2000]
-        counts = _tag_counts("longtail", n_files, seed)
-        picks = _picks(int(counts.sum()), len(pool), seed, zipf_s=0.9)
+        counts, picks = draw("longtail", len(pool), zipf_s=0.9)
         cfg = dict(lexicon=json.dumps(lex).encode(), actions=json.dumps(actions).encode(), required_facets=json.dumps(facets).encode(),
                    vocabulary=("\n".join(vocab) + "\n").encode(), vocabulary_is_json=0, minimal_subject_tags="1girl, solo")
     else:
         raise ValueError("unknown corpus " + name)
+    if hi == lo:
+        return Corpus(name, np.zeros(0, np.uint8), np.zeros(1, np.uint64), cfg, pool)
     arena, offsets = build_lines(pool, counts, picks)
     return Corpus(name, arena, offsets, cfg, pool)

@@ -96,10 +96,11 @@ struct tp_ctx {
     std::vector<std::string> public_strings;         // the configuration's interned strings (what tp_get_string hands out pointers into)
     std::vector<std::string> learned;                // in the order they were learned
     std::unordered_map<std::string, uint32_t> learned_set;
-    DevBuf unk_keys, unk_ent, unk_count, unk_out;
+    DevBuf unk_keys, unk_ent, unk_text, unk_count, unk_out;
     bool learning = false;
     WorkBufs own;                    // grown with hipMalloc as runs need them
     WorkBufs fixed;                  // pieces of this device's static scratch array: tp_run_lines_device_noalloc works in these
+    bool fixed_bound = false;        //   (bound by that entry point's first call on the context)
     WorkBufs* w = &own;
     uint64_t* host_scalars = nullptr;   // pinned host words the runs read device scalars back into
     DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
@@ -120,7 +121,7 @@ struct tp_ctx {
         for (void* p : table_mem) (void)hipFree(p);
         own.release();
         if (host_scalars) (void)hipHostFree(host_scalars);
-        for (DevBuf* b : {&unk_keys, &unk_ent, &unk_count, &unk_out}) b->release();
+        for (DevBuf* b : {&unk_keys, &unk_ent, &unk_text, &unk_count, &unk_out}) b->release();
         for (DevBuf* b : {&dt_dev, &in_arena, &in_offsets, &in_tag_begin,
                           &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
                           &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits, &aud32})
@@ -600,6 +601,7 @@ void own_config(tp_ctx* c, const tp_config& cfg) {
 void attach_unknown_set(tp_ctx* c) {
     c->dt.unk_keys = c->learning ? c->unk_keys.as<unsigned long long>() : nullptr;
     c->dt.unk_ent = c->learning ? c->unk_ent.as<unsigned long long>() : nullptr;
+    c->dt.unk_text = c->learning ? c->unk_text.as<uint8_t>() : nullptr;
     c->dt.unk_count = c->learning ? c->unk_count.as<uint32_t>() : nullptr;
     c->dt.unk_mask = UNK_SLOTS - 1;
     HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));
@@ -667,7 +669,7 @@ int learn_unknown_strings(tp_ctx* c, hipStream_t s) {
     if (noted == 0) return TP_OK;
     uint32_t* d_out_count = c->unk_count.as<uint32_t>() + 1;
     HIP_OK(hipMemsetAsync(c->unk_count.p, 0, 8, s));
-    HIP_OK(launch_collect_unknown(c->unk_keys.as<unsigned long long>(), c->unk_ent.as<unsigned long long>(), UNK_SLOTS, c->unk_out.as<uint8_t>(), UNK_HARVEST, d_out_count, s));
+    HIP_OK(launch_collect_unknown(c->unk_keys.as<unsigned long long>(), c->unk_ent.as<unsigned long long>(), c->unk_text.as<uint8_t>(), UNK_SLOTS, c->unk_out.as<uint8_t>(), UNK_HARVEST, d_out_count, s));
     uint32_t got = 0;
     HIP_OK(hipMemcpyAsync(&got, d_out_count, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -731,7 +733,6 @@ tp_ctx* tp_create(const tp_config* cfg) {
         if (const char* b = std::getenv("TAGPIPE_NO_FAST")) c->no_fast = b[0] == '1';
         HIP_OK(hipHostMalloc((void**)&c->host_scalars, 64, hipHostMallocDefault));
         std::memset(c->host_scalars, 0, 64);
-        bind_fixed(c.get());
         own_config(c.get(), *cfg);
         load_tables(c.get(), nullptr);
         c->public_strings = c->ht.strings;
@@ -740,7 +741,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         c->learning = c->use_lean && !c->dt.drop_unknown;
         if (const char* b = std::getenv("TAGPIPE_NO_LEARN")) if (b[0] == '1') c->learning = false;
         if (c->learning) {
-            c->unk_keys.need((size_t)UNK_SLOTS * 8); c->unk_ent.need((size_t)UNK_SLOTS * 8); c->unk_count.need(64); c->unk_out.need((size_t)UNK_HARVEST * 40);
+            c->unk_keys.need((size_t)UNK_SLOTS * 8); c->unk_ent.need((size_t)UNK_SLOTS * 8); c->unk_text.need((size_t)UNK_SLOTS * 32); c->unk_count.need(64); c->unk_out.need((size_t)UNK_HARVEST * 40);
             HIP_OK(hipMemset(c->unk_keys.p, 0, (size_t)UNK_SLOTS * 8));
             HIP_OK(hipMemset(c->unk_count.p, 0, 64));
             attach_unknown_set(c.get());
@@ -955,6 +956,10 @@ int tp_run_lines_device_noalloc(tp_ctx* ctx, const tp_device_io* io, uint64_t* c
     if (io->n_files > TP_NOALLOC_MAX_FILES)
         return fail(TP_E_INVALID_ARG, "tp_run_lines_device_noalloc takes at most " + std::to_string((unsigned long long)TP_NOALLOC_MAX_FILES) + " files a call, got " +
                                       std::to_string((unsigned long long)io->n_files));
+    if (!ctx->fixed_bound) {                                       // first call on this context: find this GPU's static array (no allocation)
+        const int rc = guarded([&]() { HIP_OK(hipSetDevice(ctx->device)); bind_fixed(ctx); ctx->fixed_bound = true; return (int)TP_OK; });
+        if (rc != TP_OK) return rc;
+    }
     // the run works in the pieces of the static array instead of the context's own buffers, and within that workspace
     struct Swap {
         tp_ctx* c; WorkBufs* w; size_t budget;
@@ -979,6 +984,21 @@ int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* ou
         if (!out || capacity < text.size()) return text.empty() ? TP_OK : fail(TP_E_CAPACITY, "output buffer too small");
         std::memcpy(out, text.data(), text.size());
         return TP_OK;
+    });
+}
+
+const char* tp_error_needtag_text(void) { return "error; check later"; }   // Program.cs:353
+
+int tp_fallback_caption(const tp_ctx* ctx, uint8_t* out, uint64_t capacity, uint64_t* needed) {
+    if (!ctx || !needed) return fail(TP_E_INVALID_ARG, "null argument");
+    return guarded([&]() {
+        std::string text;                                          // string.Join(", ", fb) + Environment.NewLine, Program.cs:349-350
+        for (uint32_t k = 0; k < ctx->dt.n_fallback; ++k) { if (k) text += ", "; text += ctx->ht.strings[ctx->dt.fallback_ids[k]]; }
+        text.append((const char*)ctx->dt.newline, ctx->dt.newline_len);
+        *needed = text.size();
+        if (!out || capacity < text.size()) return fail(TP_E_CAPACITY, "output buffer too small");
+        std::memcpy(out, text.data(), text.size());
+        return (int)TP_OK;
     });
 }
 

@@ -321,10 +321,11 @@ struct DevTables {
     uint32_t n_public;           // ids below this are the configuration's strings (what the tag histogram has a count for); ids from here on are
                                  // strings learned from earlier input (tp_api.cpp): counted with the tags in no table
     // Tokens in no table that the lean stage meets while such tags are kept (no strict vocabulary) are noted here, once per
-    // string: a set of 64-bit hashes (0 = free) with the address and length of one occurrence each (address | length << 56).
-    // Null when nothing is to be noted.
+    // string: a set of 64-bit hashes (0 = free) with the string's length (unk_ent) and a copy of its bytes (unk_text, 32 per slot)
+    // beside each, so that nothing noted points into the caller's input once the run is over.  Null when nothing is to be noted.
     unsigned long long* unk_keys;
     unsigned long long* unk_ent;
+    uint8_t* unk_text;
     uint32_t* unk_count;
     uint32_t unk_mask;           // slots - 1
     const uint8_t* str_bytes;

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
                 w.sync();
                 if (w.lane() == 0) L.cpos[LEAN_CPOS_NOTE] = 0;
             }
+            if (w.lane() == 0) a.slot_of[f] = SLOT_NONE;             // not left to whatever an earlier run wrote there: the back half looks at it
             decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
         }
         w.sync();
@@ -1144,27 +1145,36 @@ hipError_t noalloc_scratch(int device, void** ptr, size_t* bytes) {
 }
 
 // The strings the lean stage noted (tp_lean.h, lean_note_unknown): every used slot's text goes to `out` and the slot is freed.
-__global__ __launch_bounds__(256) void k_collect_unknown(unsigned long long* keys, const unsigned long long* ent, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count) {
+__global__ __launch_bounds__(256) void k_collect_unknown(unsigned long long* keys, const unsigned long long* ent, const uint8_t* text, uint32_t slots, uint8_t* out, uint32_t out_cap,
+                                                         uint32_t* out_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= slots || keys[i] == 0) return;
     keys[i] = 0;
-    const unsigned long long e = ent[i];
-    const uint8_t* p = (const uint8_t*)(uintptr_t)(e & 0x00FFFFFFFFFFFFFFull);
-    const uint32_t n = (uint32_t)(e >> 56);
+    const uint32_t n = (uint32_t)ent[i];
+    const uint8_t* p = text + 32 * (size_t)i;                     // the copy lean_note_unknown made: nothing here points into a caller's input
     const uint32_t at = atomicAdd(out_count, 1u);
-    if (at >= out_cap || n == 0 || n > 32 || p == nullptr) return;
+    if (at >= out_cap || n == 0 || n > 32) return;
     uint8_t* o = out + (size_t)at * 40;
     for (uint32_t k = 0; k < 32; ++k) o[k] = k < n ? p[k] : 0;
     *(uint32_t*)(o + 32) = n;
     *(uint32_t*)(o + 36) = 0;
 }
-hipError_t launch_collect_unknown(unsigned long long* keys, const unsigned long long* ent, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count, hipStream_t s) {
-    hipLaunchKernelGGL(k_collect_unknown, dim3((slots + 255) / 256), dim3(256), 0, s, keys, ent, slots, out, out_cap, out_count);
+hipError_t launch_collect_unknown(unsigned long long* keys, const unsigned long long* ent, const uint8_t* text, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(k_collect_unknown, dim3((slots + 255) / 256), dim3(256), 0, s, keys, ent, text, slots, out, out_cap, out_count);
     return hipGetLastError();
 }
 
 uint32_t fast_fin_stride() { return FAST_FIN_MAX; }
 bool lean_ok(const DevTables& t) { return lean_tables_ok(t); }
+
+// A grid-size override from the environment (testing aid): a positive number, anything else leaves the default.
+static unsigned env_blocks(const char* name, unsigned dflt) {
+    const char* e = getenv(name);
+    if (!e) return dflt;
+    const long v = strtol(e, nullptr, 10);
+    return v >= 1 && v <= 0x7FFFFFFFl ? (unsigned)v : dflt;
+}
 
 hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between) {
     uint64_t n = a.file_end - a.file0;
@@ -1172,19 +1182,19 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
     uint64_t want = (n + FAST_WAVES_PER_BLOCK - 1) / FAST_WAVES_PER_BLOCK;
     // Wavefronts stride over the files.  Many more blocks than fit at once (measured best around 80 per CU): blocks that
     // finish early make room for others, which evens out the files' different costs.  Later stages usually find little to do.
-    static const unsigned max_blocks = [] { const char* e = getenv("TAGPIPE_FAST_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
+    static const unsigned max_blocks = env_blocks("TAGPIPE_FAST_BLOCKS", 256u * 80u);
     // Behind the lean stage (a.tables is set) the stages find few files as a rule: smaller grids, so that blocks which find
     // nothing to do are not what these launches cost.
-    static const unsigned after_lean1 = [] { const char* e = getenv("TAGPIPE_AFTER_LEAN_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 16u; }();
-    static const unsigned after_lean2 = [] { const char* e = getenv("TAGPIPE_AFTER_LEAN_BLOCKS2"); return e ? (unsigned)atoi(e) : 512u; }();
+    static const unsigned after_lean1 = env_blocks("TAGPIPE_AFTER_LEAN_BLOCKS", 256u * 16u);
+    static const unsigned after_lean2 = env_blocks("TAGPIPE_AFTER_LEAN_BLOCKS2", 512u);
     const bool after_lean = a.tables != nullptr && a.stage >= 1 && a.stage <= 3;
     const unsigned cap = after_lean ? (a.stage == 1 ? after_lean1 : after_lean2) : (a.stage == 1 ? max_blocks : 256u * 8u);
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     const bool tr = a.triage != 0;
     if (a.stage == 0) {
         // (measured on 1M c2 files, blocks: front / back ms: 1280: 0.89 / 1.47, 4096: 0.74 / 1.41, 20480: 0.71 / 1.33, 81920: 0.72 / 1.45)
-        static const unsigned lean_blocks_a = [] { const char* e = getenv("TAGPIPE_LEAN_A_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
-        static const unsigned lean_blocks_b = [] { const char* e = getenv("TAGPIPE_LEAN_B_BLOCKS"); return e ? (unsigned)atoi(e) : 256u * 80u; }();
+        static const unsigned lean_blocks_a = env_blocks("TAGPIPE_LEAN_A_BLOCKS", 256u * 80u);
+        static const unsigned lean_blocks_b = env_blocks("TAGPIPE_LEAN_B_BLOCKS", 256u * 80u);
         // about a dozen files per wavefront (shorter loops leave the wavefronts of a CU in different phases of their files; far
         // fewer files per wavefront and the per-block set-up and the per-wavefront hand-over of declined files begin to show)
         want = (n + 12 * LEAN_WAVES_PER_BLOCK - 1) / (12 * LEAN_WAVES_PER_BLOCK);
@@ -1233,13 +1243,13 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (a.fin32 && a.fast_ran) {                            // the wave-per-file kernel ran: its files first
         uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
-        static const unsigned per_cu = [] { const char* e = getenv("TAGPIPE_EMIT_BLOCKS_PER_CU"); return e ? (unsigned)atoi(e) : (unsigned)TP_EMIT_WAVES_PER_SIMD; }();
+        static const unsigned per_cu = env_blocks("TAGPIPE_EMIT_BLOCKS_PER_CU", (unsigned)TP_EMIT_WAVES_PER_SIMD);
         unsigned blocks = (unsigned)(want < 256 * per_cu ? want : 256 * per_cu);   // as many blocks (of four wavefronts) per CU as fit at once
         static const bool by_file = [] { const char* e = getenv("TAGPIPE_EMIT_BY_FILE"); return e && e[0] == '1'; }();   // testing aid: one file per wavefront
         if (by_file) hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
         else {
             want = ((n + RUN_FILES - 1) / RUN_FILES + EMIT_WAVES - 1) / EMIT_WAVES;
-            static const unsigned runs_per_cu = [] { const char* e = getenv("TAGPIPE_EMIT_BLOCKS_PER_CU"); return e ? (unsigned)atoi(e) : (unsigned)TP_EMIT_RUNS_WAVES_PER_SIMD; }();
+            static const unsigned runs_per_cu = env_blocks("TAGPIPE_EMIT_BLOCKS_PER_CU", (unsigned)TP_EMIT_RUNS_WAVES_PER_SIMD);
             blocks = (unsigned)(want < 256 * runs_per_cu ? want : 256 * runs_per_cu);
             hipLaunchKernelGGL(k_emit_runs, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
         }

@@ -10,6 +10,7 @@ namespace tp {
 
 constexpr uint32_t SLOT_FAST = 0xFFFFFFFFu;   // slot_of[file]: the file was finished by the wave-per-file kernel
 constexpr uint32_t SLOT_LEAN = 0xFFFFFFFEu;   // ... the lean stage's front half has left the file's candidates for its back half
+constexpr uint32_t SLOT_NONE = 0xFFFFFFFDu;   // ... no stage has finished the file yet (the lean stage's front half declined it)
 
 // Wave-per-file kernel over files [file0, file_end) (line ingest only).
 struct FastArgs {
@@ -129,9 +130,9 @@ uint64_t scan_tiles_needed(uint64_t n);
 hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_t s);
 hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s);
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s);
-// The strings noted in DevTables::unk_keys / unk_ent, as records of 40 bytes {32 bytes of text, length, 0} in `out` (at most
+// The strings noted in DevTables::unk_keys / unk_ent / unk_text, as records of 40 bytes {32 bytes of text, length, 0} in `out` (at most
 // out_cap of them; *out_count receives how many there were); the set is emptied.
-hipError_t launch_collect_unknown(unsigned long long* keys, const unsigned long long* ent, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count, hipStream_t s);
+hipError_t launch_collect_unknown(unsigned long long* keys, const unsigned long long* ent, const uint8_t* text, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count, hipStream_t s);
 uint32_t fast_fin_stride();
 bool lean_ok(const DevTables& t);   // the lean stage (tp_lean.h) can serve this configuration
 

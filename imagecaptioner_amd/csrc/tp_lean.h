@@ -177,8 +177,8 @@ TP_HD_FLAT bool lean_plain_unknown(const uint8_t* p, uint32_t n) {
 }
 
 // A token in no table that this stage has to decline because such tags are kept (no strict vocabulary): noted once per
-// string in DevTables::unk_keys (64-bit hash, 0 = free; linear probing) with where it stands, so that the host can add it
-// to the tables for later runs.  p: the token in the input (device memory that outlives the run), n <= 32 bytes.
+// string in DevTables::unk_keys (64-bit hash, 0 = free; linear probing) with a copy of its bytes, so that the host can add it
+// to the tables for later runs.  p: the token in the input, n <= 32 bytes; the input is not looked at again after the run.
 template <class TT>
 TP_HD_FLAT void lean_note_unknown(const TT& t, const uint8_t* p, uint32_t n) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -189,7 +189,9 @@ TP_HD_FLAT void lean_note_unknown(const TT& t, const uint8_t* p, uint32_t n) {
     for (uint32_t probe = 0; probe < 32; ++probe) {
         const unsigned long long old = atomicCAS(&t.unk_keys[slot], 0ull, h);
         if (old == 0ull) {
-            t.unk_ent[slot] = (unsigned long long)(uintptr_t)p | (unsigned long long)n << 56;
+            uint8_t* o = t.unk_text + 32 * (size_t)slot;
+            for (uint32_t k = 0; k < n; ++k) o[k] = p[k];
+            t.unk_ent[slot] = (unsigned long long)n;
             atomicAdd(t.unk_count, 1u);
             return;
         }

@@ -955,7 +955,7 @@ void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std
     std::memset(&sc, 0, sizeof sc);
     sc.n_strings = N;
     sc.n_public = n_public;
-    sc.unk_keys = nullptr; sc.unk_ent = nullptr; sc.unk_count = nullptr; sc.unk_mask = 0;
+    sc.unk_keys = nullptr; sc.unk_ent = nullptr; sc.unk_text = nullptr; sc.unk_count = nullptr; sc.unk_mask = 0;
     sc.ht_mask = slots - 1;
     sc.n_lits = n_lits;
     sc.lit_words = (n_lits + 31) / 32;

@@ -32,6 +32,39 @@ def allreduce_sum_(tensors, group=None):
     return tensors
 
 
+def shard_digest(captions, caption_offsets=None):
+    """(sha256 hex digest, byte count, file count) of one shard's caption bytes: what a rank hands to rank 0."""
+    import hashlib
+    import numpy as np
+    b = np.ascontiguousarray(captions, dtype=np.uint8)
+    n = 0 if caption_offsets is None else len(caption_offsets) - 1
+    return hashlib.sha256(b.tobytes()).hexdigest(), int(b.size), int(n)
+
+
+def check_shards_against_whole(shard_digests, whole_captions, whole_offsets, world):
+    """The ranks' shards, concatenated in rank order, are the single-GPU output: shard r's digest and size equal those of
+    bytes [offsets[begin_r], offsets[end_r]) of the whole run's captions (shard_range gives begin_r, end_r).  shard_digests:
+    shard_digest() of every rank, in rank order.  Returns None, or a message naming the first difference."""
+    import hashlib
+    import numpy as np
+    n = len(whole_offsets) - 1
+    if len(shard_digests) != world:
+        return "%d shard digests for %d ranks" % (len(shard_digests), world)
+    whole = np.ascontiguousarray(whole_captions, dtype=np.uint8)
+    for r, (digest, nbytes, nfiles) in enumerate(shard_digests):
+        b, e = shard_range(n, r, world)
+        lo, hi = int(whole_offsets[b]), int(whole_offsets[e])
+        if nfiles != e - b:
+            return "rank %d processed %d files, its shard has %d" % (r, nfiles, e - b)
+        if nbytes != hi - lo:
+            return "rank %d wrote %d caption bytes, the whole run has %d for its files" % (r, nbytes, hi - lo)
+        if hashlib.sha256(whole[lo:hi].tobytes()).hexdigest() != digest:
+            return "rank %d's captions differ from the whole run's captions of files %d..%d" % (r, b, e)
+    if int(whole_offsets[n]) != sum(d[1] for d in shard_digests):
+        return "the shards' bytes do not add up to the whole run's"
+    return None
+
+
 def free_port():
     """A TCP port on 127.0.0.1 that was free a moment ago (for MASTER_PORT)."""
     import socket

@@ -21,6 +21,7 @@ EXPORTS = (
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_run_lines_device_noalloc", "tp_format_top_tags", "tp_get_last_timing",
     "tp_triage_lines", "tp_run_merged", "tp_format_fired_rules", "tp_needtag_text", "tp_format_side_files",
     "tp_decode_joytag_replies", "tp_release_replies", "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows", "tp_review_csv_header", "tp_format_review_rows",
+    "tp_fallback_caption", "tp_error_needtag_text",
 )
 
 
@@ -84,6 +85,8 @@ def load_library():
     L.tp_review_csv_header.restype = C.c_char_p
     L.tp_format_review_rows.argtypes = [C.c_void_p, C.POINTER(tp_result), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p,
                                         C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.tp_fallback_caption.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.tp_error_needtag_text.restype = C.c_char_p
     _LIB = L
     return L
 
@@ -224,6 +227,19 @@ class TagPipe:
 
     def needtag_text(self):
         return self._L.tp_needtag_text()
+
+    def fallback_caption(self):
+        """tp_fallback_caption: the caption line the reference writes for an image whose processing failed (Program.cs:344-350)."""
+        need = C.c_uint64()
+        rc = self._L.tp_fallback_caption(self._h, None, 0, C.byref(need))
+        if rc not in (TP_OK, TP_E_CAPACITY):
+            self._check(rc)
+        buf = np.zeros(max(need.value, 1), dtype=np.uint8)
+        self._check(self._L.tp_fallback_caption(self._h, buf.ctypes.data, need.value, C.byref(need)))
+        return bytes(buf[:need.value])
+
+    def error_needtag_text(self):
+        return self._L.tp_error_needtag_text()
 
     def last_timing(self):
         t = tp_timing()

@@ -308,9 +308,10 @@ int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_b
 
 /*
  * tp_run_lines_device for callers that cannot allocate device memory while they
- * run (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc).  No counterpart in the reference.  Same arguments, outputs and
- * return codes, but the call makes no hipMalloc / hipFree / event creation:
+ * run (tight serving loops, harnesses that forbid hipMalloc).  No counterpart in
+ * the reference.  Same arguments, outputs and return codes, but the call makes no
+ * hipMalloc / hipFree / event creation (it does synchronise the stream, so it
+ * cannot itself be recorded into a HIP graph):
  * everything it needs besides the caller's buffers lives in one static array
  * of 16 MiB that each GPU the library runs on holds until the process ends.
  * Limits: at most TP_NOALLOC_MAX_FILES files a call (more: TP_E_INVALID_ARG);
@@ -320,8 +321,12 @@ int tp_run_lines_device(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_b
  * shares that GPU's array: calls that overlap in time on one GPU race, also
  * from different contexts or streams; the array keeps the last call's contents
  * and the call clears what it needs cleared.  The call does not compile tables
- * again (see tp_run_lines on tags in no table): what it meets is learned by
- * the next tp_run_lines / tp_run_lines_device call on the context.
+ * again (see tp_run_lines on tags in no table): what it meets is noted as a
+ * copy of the tag's bytes (never as a pointer into the caller's arena, which may
+ * be freed or reused as soon as the call returns) and learned by the next
+ * tp_run_lines / tp_run_lines_device call on the context.  A context whose GPU's
+ * array cannot be bound (device ordinal of 64 or more) reports TP_E_DEVICE here
+ * and works normally through every other entry point.
  */
 #define TP_NOALLOC_MAX_FILES 16384
 int tp_run_lines_device_noalloc(tp_ctx* ctx, const tp_device_io* io, uint64_t* caption_bytes);
@@ -343,6 +348,21 @@ int tp_triage_lines(tp_ctx* ctx, const uint8_t* arena, const uint64_t* offsets, 
  * full size.
  */
 int tp_format_top_tags(const tp_ctx* ctx, const uint64_t* histogram, uint8_t* out, uint64_t capacity, uint64_t* needed);
+
+/*
+ * The caption the reference writes for an image whose processing threw
+ * (Program.cs:344-350): string.Join(", ", SelectTags(ParseTagCandidatesFromLine(
+ * minimalFallback, null, 1.0, TagSource.OpenAI)).Tags) + the configured newline;
+ * the tags are joined as SelectTags returns them (no FormatCaptionSingleLine pass).
+ * The same text for every image of a run: the caller writes it for a file whose
+ * verdict carries TP_F_UNSUPPORTED (text this library does not process) or whose
+ * own stages before the call failed, when <image>.txt does not exist yet, and
+ * "error; check later" + newline to <image>.needtag under --keep-needtag
+ * (tp_error_needtag_text()).  Writes at most `capacity` bytes; *needed is the
+ * full size (TP_E_CAPACITY when capacity is smaller; nothing is written then).
+ */
+int tp_fallback_caption(const tp_ctx* ctx, uint8_t* out, uint64_t capacity, uint64_t* needed);
+const char* tp_error_needtag_text(void);
 
 /* Timing of the most recent run on this context (milliseconds, from HIP events on the run's stream). */
 typedef struct tp_timing {

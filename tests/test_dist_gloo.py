@@ -99,6 +99,35 @@ def test_launcher_two_ranks_join_and_sum(tmp_path):
     assert np.array_equal(caps, whole.captions)
 
 
+def test_strong_scaling_shards_of_one_corpus(tmp_path):
+    """`bench.py --scaling strong` on the CPU: two gloo ranks each build only their own range of ONE seeded corpus, and the check
+    bench.py runs on rank 0 (per-shard digests against the whole run, sizes, file counts) passes; the sums are the whole run's."""
+    import json
+    n_files = 203
+    p = _run_launcher(tmp_path, n_files, -1, "strong")
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert got["world"] == 2 and got["shard_check"] is None
+    c = make_corpus("c1", n_files, seed=11)
+    whole = Oracle(Config(**c.config_kwargs)).run_lines(c.arena, c.offsets)
+    assert got["hist"] == [whole.histogram[t] for t in sorted(whole.histogram)]
+    caps = np.concatenate([np.load(tmp_path / ("cap%d.npy" % r)) for r in range(2)])
+    assert np.array_equal(caps, whole.captions)
+
+
+def test_corpus_slices_are_the_whole_corpus_cut_up():
+    for name in ("c1", "c2", "c4", "c5"):
+        n = 777
+        whole = make_corpus(name, n, seed=21)
+        for world in (2, 3):
+            for r in range(world):
+                b, e = shard_range(n, r, world)
+                part = make_corpus(name, n, seed=21, file_range=(b, e))
+                lo, hi = int(whole.offsets[b]), int(whole.offsets[e])
+                assert np.array_equal(part.arena, whole.arena[lo:hi]) and np.array_equal(part.offsets, whole.offsets[b:e + 1] - whole.offsets[b])
+    assert make_corpus("c2", 10, seed=1, file_range=(4, 4)).n_files == 0
+
+
 def test_launcher_reports_a_failing_rank(tmp_path):
     p = _run_launcher(tmp_path, 16, 1)           # rank 1 exits with status 7 after the collective
     assert p.returncode == 7

@@ -664,6 +664,23 @@ def test_bench_two_ranks_share_this_gpu():
     assert line["n_gpus"] == 2 and line["config"]["files_per_gpu"] == 30000 and line["value"] > 0 and line["scaling"] == "weak"
 
 
+def test_bench_strong_scaling_two_ranks_share_this_gpu():
+    """`bench.py --gpus 2 --scaling strong`: ONE corpus (the committed golden size of c2) cut into two contiguous shards, both
+    ranks on this box's GPU, sums through gloo.  Rank 0 checks the shards against its own run over the whole corpus, the summed
+    histogram and counters against that run's, and the whole run's digest against tests/golden/corpus_digests.json."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-gpu", "--scaling", "strong", "--files", "1000",
+                        "--steps", "2", "--warmup", "1", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    chk = line["config"]["strong_scaling_check"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["collective"]["world_size_seen"] == 2
+    assert chk["files_in_all"] == 1000 and chk["shard_files"] == [500, 500] and chk["whole_run_checked"] and chk["golden_checked"]
+
+
 def test_strings_in_no_table_are_learned():
     """c2 without a vocabulary file: tags in no table are kept (Program.cs:1121-1133 with KnownTagDictionaryFound false), and a
     file that holds one takes the thread-per-file kernel.  The library notes such strings and compiles its tables again
@@ -690,3 +707,43 @@ def test_strings_in_no_table_are_learned():
     c2 = make_corpus("c2n", n, seed=999)
     got = p.run_lines(c2.arena, c2.offsets)
     assert_same_results(got, Oracle(cfg).run_lines(c2.arena, c2.offsets, threads=16), p.histogram_dict(got.histogram), "c2n, other files")
+
+
+def test_fallback_caption_is_the_failure_path_line():
+    """tp_fallback_caption = string.Join(", ", SelectTags(ParseTagCandidatesFromLine(minimalFallback, null, 1.0, OpenAI)).Tags)
+    + newline (Program.cs:349-350), against the oracle's SelectTags on its own minimalFallback; several configurations."""
+    for name in sorted(CONFIGS):
+        cfg = CONFIGS[name]()
+        p, o = pipe_for(cfg), Oracle(cfg)
+        nl = cfg.struct.newline or b"\n"
+        assert p.fallback_caption() == ", ".join(o.select_tags_from_line(o.minimal_fallback, 1.0)).encode("utf-8") + nl, name
+    assert pipe_for(CONFIGS["shipped"]()).error_needtag_text() == b"error; check later"      # Program.cs:353
+
+
+def test_noted_strings_do_not_point_into_a_freed_arena():
+    """Tags in no table that tp_run_lines_device_noalloc meets are noted as copies of their bytes: the caller frees (here:
+    overwrites, then drops) the arena, and the next allocating call still learns the right strings from what was noted."""
+    import torch
+    from imagecaptioner_amd.corpus import make_corpus
+    from test_zz_no_alloc import DeviceRun
+    n = 3000
+    c = make_corpus("c2n", n, seed=4244)
+    cfg = Config(**c.config_kwargs)
+    p = pipe_for(cfg)
+    r = DeviceRun(p, c).run(noalloc=True)
+    r.arena.fill_(0x41)                                       # what the notes used to point at is gone
+    del r
+    torch.cuda.empty_cache()
+    other = make_corpus("c2", 50, seed=5)                     # strict-free tables, another input: the call collects what was noted before
+    got = p.run_lines(other.arena, other.offsets)
+    assert got.counters["files"] == 50
+    got = p.run_lines(c.arena, c.offsets)                     # the noted strings are interned now: the wave kernels take the corpus
+    want = Oracle(cfg).run_lines(c.arena, c.offsets, threads=16)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "c2n after a freed arena")
+    assert p.last_timing()["general_files"] <= n // 100
+
+
+def test_hand_derived_known_answers():
+    """known_answers.py (coverage strings, facet choices, closure order, unknown-tag order, the 0.03 window) through the C ABI."""
+    import known_answers as ka
+    assert ka.check_known_answers(pipe_for, shipped_config) == 6
