@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -62,15 +63,73 @@ const T* upload(std::vector<void*>& owned, const std::vector<T>& v) {
     return (const T*)d;
 }
 
+// Host memory of the results the host-pointer entry points hand out: page-locked, so that the copies back from the device
+// run at the bus's rate (into pageable memory they take several times as long as the kernels and the bus together), and
+// pooled for the process, because locking a gigabyte of pages costs as much as copying it.  tp_release gives a result's
+// buffers back to the pool; the pool keeps a bounded number of them and frees the rest.  When the pages cannot be locked
+// the buffer is ordinary memory: slower, not wrong.
+struct PinBuf { void* p = nullptr; size_t cap = 0; bool pinned = false; };
+class PinPool {
+    std::mutex mu;
+    std::vector<PinBuf> idle;
+    size_t idle_bytes = 0;
+    static constexpr size_t MAX_IDLE = 32, MAX_IDLE_BYTES = (size_t)6 << 30;
+    static void drop(PinBuf& b) { if (b.p) { if (b.pinned) (void)hipHostFree(b.p); else std::free(b.p); } b = PinBuf{}; }
+public:
+    PinBuf take(size_t bytes) {
+        bytes = std::max<size_t>(bytes, 64);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].cap >= bytes && idle[i].cap <= 2 * bytes + (1u << 20) && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+            if (best != idle.size()) { PinBuf b = idle[best]; idle_bytes -= b.cap; idle.erase(idle.begin() + best); return b; }
+        }
+        PinBuf b;
+        b.cap = (bytes + bytes / 8 + 4095) & ~(size_t)4095;            // some slack: the next batch of about this size fits too
+        if (hipHostMalloc(&b.p, b.cap, hipHostMallocPortable) == hipSuccess && b.p) b.pinned = true;
+        else { (void)hipGetLastError(); b.p = std::malloc(b.cap); if (!b.p) throw std::bad_alloc(); }
+        return b;
+    }
+    void give(PinBuf b) {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (idle.size() >= MAX_IDLE || idle_bytes + b.cap > MAX_IDLE_BYTES) { drop(b); return; }
+        idle_bytes += b.cap;
+        idle.push_back(b);
+    }
+    ~PinPool() { for (PinBuf& b : idle) drop(b); }
+};
+PinPool& pin_pool() { static PinPool* pool = new PinPool(); return *pool; }   // never destroyed: results may outlive every context
+template <class T>
+class PinArr {
+    PinBuf b;
+    size_t n = 0;
+public:
+    PinArr() = default;
+    PinArr(const PinArr&) = delete;
+    PinArr& operator=(const PinArr&) = delete;
+    ~PinArr() { pin_pool().give(b); }
+    void resize(size_t count) {                                     // contents are not kept and not cleared: every user fills what it reads
+        if (count * sizeof(T) > b.cap) { pin_pool().give(b); b = PinBuf{}; b = pin_pool().take(count * sizeof(T)); }
+        n = count;
+    }
+    T* data() { return (T*)b.p; }
+    const T* data() const { return (const T*)b.p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return ((T*)b.p)[i]; }
+    const T& operator[](size_t i) const { return ((const T*)b.p)[i]; }
+};
 struct HostResult {
-    std::vector<uint8_t> captions;
-    std::vector<uint64_t> caption_offsets, histogram;
-    std::vector<tp_verdict> verdicts;
-    std::vector<uint32_t> fired;
-    std::vector<uint16_t> facet_choice;
-    std::vector<uint8_t> audit_text;        // audit mode only
-    std::vector<uint64_t> audit_offsets;
-    std::vector<uint32_t> review_bits;
+    PinArr<uint8_t> captions;
+    PinArr<uint64_t> caption_offsets, histogram;
+    PinArr<tp_verdict> verdicts;
+    PinArr<uint32_t> fired;
+    PinArr<uint16_t> facet_choice;
+    PinArr<uint8_t> audit_text;        // audit mode only
+    PinArr<uint64_t> audit_offsets;
+    PinArr<uint32_t> review_bits;
 };
 
 }  // namespace
@@ -503,21 +562,24 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     r->fired.resize(std::max<uint64_t>(n_files * t.fired_words, 1));
     r->facet_choice.resize(std::max<uint64_t>(n_files * t.n_facets, 1));
     tp_counters ctr{};
-    if (cap_bytes) HIP_OK(hipMemcpy(r->captions.data(), c->out_captions.p, cap_bytes, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(r->caption_offsets.data(), c->out_offsets.p, (n_files + 1) * 8, hipMemcpyDeviceToHost));
-    if (n_files) HIP_OK(hipMemcpy(r->verdicts.data(), c->out_verdicts.p, n_files * sizeof(tp_verdict), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(r->histogram.data(), c->out_hist.p, hist_n * 8, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(&ctr, c->out_counters.p, sizeof ctr, hipMemcpyDeviceToHost));
-    if (n_files * t.fired_words) HIP_OK(hipMemcpy(r->fired.data(), c->out_fired.p, n_files * t.fired_words * 4, hipMemcpyDeviceToHost));
-    if (n_files * t.n_facets) HIP_OK(hipMemcpy(r->facet_choice.data(), c->out_facets.p, n_files * t.n_facets * 2, hipMemcpyDeviceToHost));
+    // every copy back is queued on the stream and waited for once (the buffers are page-locked: the copies are DMA transfers)
+    if (cap_bytes) HIP_OK(hipMemcpyAsync(r->captions.data(), c->out_captions.p, cap_bytes, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(r->caption_offsets.data(), c->out_offsets.p, (n_files + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (n_files) HIP_OK(hipMemcpyAsync(r->verdicts.data(), c->out_verdicts.p, n_files * sizeof(tp_verdict), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(r->histogram.data(), c->out_hist.p, hist_n * 8, hipMemcpyDeviceToHost, s));
+    if (n_files * t.fired_words) HIP_OK(hipMemcpyAsync(r->fired.data(), c->out_fired.p, n_files * t.fired_words * 4, hipMemcpyDeviceToHost, s));
+    if (n_files * t.n_facets) HIP_OK(hipMemcpyAsync(r->facet_choice.data(), c->out_facets.p, n_files * t.n_facets * 2, hipMemcpyDeviceToHost, s));
     if (io.audit) {
         r->audit_text.resize(std::max<uint64_t>(audit_bytes, 1));
         r->audit_offsets.resize(n_files * AUDIT_COLS + 1);
-        if (audit_bytes) HIP_OK(hipMemcpy(r->audit_text.data(), c->out_audit.p, audit_bytes, hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(r->audit_offsets.data(), c->out_audit_offsets.p, (n_files * AUDIT_COLS + 1) * 8, hipMemcpyDeviceToHost));
+        if (audit_bytes) HIP_OK(hipMemcpyAsync(r->audit_text.data(), c->out_audit.p, audit_bytes, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(r->audit_offsets.data(), c->out_audit_offsets.p, (n_files * AUDIT_COLS + 1) * 8, hipMemcpyDeviceToHost, s));
         r->review_bits.resize(std::max<uint64_t>(n_files, 1));
-        if (n_files) HIP_OK(hipMemcpy(r->review_bits.data(), c->out_review_bits.p, n_files * 4, hipMemcpyDeviceToHost));
+        if (n_files) HIP_OK(hipMemcpyAsync(r->review_bits.data(), c->out_review_bits.p, n_files * 4, hipMemcpyDeviceToHost, s));
     }
+    HIP_OK(hipMemcpyAsync(&c->host_scalars[0], c->out_counters.p, sizeof ctr, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    std::memcpy(&ctr, &c->host_scalars[0], sizeof ctr);
     out->n_files = n_files;
     out->captions = r->captions.data();
     out->caption_offsets = r->caption_offsets.data();
