@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (RCCL refuses two ranks on one GPU: use --backend gloo)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --files per GPU; strong: --files in all, one corpus sharded by rank")
     ap.add_argument("--verify-files", type=int, default=2_000_000, help="strong scaling: rank 0 reruns the whole corpus on its own GPU to check the shards when the corpus has at most this many files")
+    ap.add_argument("--no-check", action="store_true", help="diagnostic builds whose outputs are wrong on purpose: skip the oracle check")
     ap.add_argument("--e2e-runs", type=int, default=2, help="1 GPU: timed calls of tp_run_lines (host buffers in, host results out) for the end-to-end rate; 0 = skip")
     args = ap.parse_args()
 
@@ -133,7 +134,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sel_ms, gen_ms, emit_ms, tot_ms, front_ms, back_ms, gen_files = [], [], [], [], [], [], 0
+    sel_ms, gen_ms, emit_ms, tot_ms, front_ms, back_ms, fused_ms, gen_files = [], [], [], [], [], [], [], 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -143,7 +144,7 @@ def main():
         cap_bytes = step()
         tm = pipe.last_timing()        # HIP events recorded by the library on the stream its kernels run on
         sel_ms.append(tm["select_ms"]); gen_ms.append(tm["general_ms"]); emit_ms.append(tm["emit_ms"]); tot_ms.append(tm["total_ms"])
-        front_ms.append(tm["lean_front_ms"]); back_ms.append(tm["lean_back_ms"])
+        front_ms.append(tm["lean_front_ms"]); back_ms.append(tm["lean_back_ms"]); fused_ms.append(tm["fused_ms"])
         gen_files = tm["general_files"]
     torch.cuda.synchronize()
     if world > 1:
@@ -223,7 +224,7 @@ def main():
     got_ver["n_evidence"] = 0
     want_ver["n_evidence"] = 0
     ok = bool(np.array_equal(got_off, want.caption_offsets) and np.array_equal(got_cap, want.captions) and got_ver.tobytes() == want_ver.tobytes())
-    if not ok:
+    if not ok and not args.no_check:
         raise SystemExit("bench.py: device captions differ from the oracle on the first %d files" % check_n)
 
     if rank != 0:
@@ -239,7 +240,7 @@ def main():
     # end (every kernel of the step, HIP events on the stream the library launches on).  The longest kernel is named beside it.
     mean = lambda v: float(np.mean(v))
     kernel_ms = {"k_lean_a": mean(front_ms), "k_lean_b": mean(back_ms), "later_wave_stages": mean(sel_ms) - mean(front_ms) - mean(back_ms),
-                 "k_pipeline": mean(gen_ms), "k_emit+k_hist": mean(emit_ms), "first_to_last_kernel": mean(tot_ms)}
+                 "k_lean_bx": mean(fused_ms), "k_pipeline": mean(gen_ms), "k_emit+k_hist": mean(emit_ms), "first_to_last_kernel": mean(tot_ms)}
     dominant = max((k for k in kernel_ms if k != "first_to_last_kernel"), key=lambda k: kernel_ms[k])
     step_ms = kernel_ms["first_to_last_kernel"]
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9
@@ -269,7 +270,7 @@ def main():
                                else "%s: %d tag files per GPU, %.0f input bytes/file" % (args.config, n, in_bytes / n),
                    "files_per_gpu": n, "input_bytes_per_file": in_bytes / n, "caption_bytes_per_file": cap_bytes / n,
                    "kernel_ms": kernel_ms,
-                   "files_in_general_kernel": int(gen_files),
+                   "files_in_general_kernel": int(gen_files), "fused_reruns": int(tm["fused_reruns"]),
                    "parallelism": ("files sharded by rank; histogram all-reduce (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal")) if world > 1 else "single GPU",
                    "collective": {"backend": (args.backend if world > 1 else None), "world_size_seen": (dist.get_world_size() if world > 1 else 1)},
                    "strong_scaling_check": strong_check,

@@ -141,7 +141,8 @@ class tp_device_io(C.Structure):
 
 class tp_timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("select_ms", C.c_float), ("general_ms", C.c_float), ("emit_ms", C.c_float),
-                ("other_ms", C.c_float), ("general_files", C.c_uint64), ("lean_front_ms", C.c_float), ("lean_back_ms", C.c_float)]
+                ("other_ms", C.c_float), ("general_files", C.c_uint64), ("lean_front_ms", C.c_float), ("lean_back_ms", C.c_float),
+                ("fused_ms", C.c_float), ("fused_reruns", C.c_uint64)]
 
 
 class tp_replies(C.Structure):

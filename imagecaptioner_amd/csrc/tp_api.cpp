@@ -136,9 +136,10 @@ struct HostResult {
 
 // What one run works in besides the caller's inputs and outputs.
 struct WorkBufs {
-    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, scalars, workspace;
+    DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, slow_list_b, tile_state, scalars, workspace;
     void release() {
-        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &scalars, &workspace})
+        for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &slow_list_b,
+                          &tile_state, &scalars, &workspace})
             b->release();
     }
 };
@@ -172,6 +173,9 @@ struct tp_ctx {
     size_t ws_budget = (size_t)64 << 30;
     bool no_fast = false;            // TAGPIPE_NO_FAST=1: every file takes the general kernel (testing aid)
     bool use_lean = false;           // the lean stage runs ahead of the wave stages (TAGPIPE_NO_LEAN=1 turns it off: testing aid)
+    bool no_fused = true;            // TAGPIPE_FUSED=1: the plain run's back half, caption offsets and caption bytes as ONE kernel (k_lean_bx).  Off by default:
+                                     // measured on c2 (1M files) the fused kernel takes 2.86 ms where k_lean_b + scan + k_emit_runs take 2.2 ms
+    uint64_t fused_reruns = 0;       // ranges the fused back half had to hand back to the separate kernels
     uint64_t last_slow = 0;
     uint32_t last_fpw = 64;          // files per wavefront of the last general-kernel run (the stride of its workspace rows)
 
@@ -218,9 +222,12 @@ struct RunState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> fast_ev, pipe_ev, emit_ev;
     struct Lean { hipEvent_t begin, mid, end; };
     std::vector<Lean> lean_ev;     // lean stage: front kernel between begin and mid, back kernel between mid and end
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> fused_ev;   // the fused back half (k_lean_bx)
 };
+constexpr size_t SCALARS_BYTES = 256;   // WorkBufs::scalars: [0, 64) totals, status and list counts; [64, 128) the fused back half's own batch counters;
+                                        // [128, 136) its ticket counter and the number of files it declined
 
-int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
+int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool allow_fused = true) {
     hipStream_t s = io.stream;
     const uint64_t n = f1 - f0;
     auto next_event = [&]() -> hipEvent_t { return st.timed ? c->event(st.ev++) : nullptr; };
@@ -232,6 +239,15 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     // audit mode over tag lines: the lean stage lists what it takes (interned ids, tp_lean.h), everything else takes the general kernel
     const bool audit_lean = io.audit && c->use_lean && c->dt.fast_ok && !io.tag_begin && io.mode == 0 && !c->no_fast;
     const bool use_fast = use_scored || audit_lean || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast && !io.audit);
+    // The plain run over tag lines (no detail arrays, no audit lists): the lean stage's back half, the caption offsets and the
+    // caption bytes are one kernel (k_lean_bx); the stages behind the front half run before it, so that every file's caption
+    // length is known or computed there.
+    const bool fused = allow_fused && use_fast && !use_scored && !audit_lean && c->use_lean && io.mode == 0 && !io.fired && !io.facet_choice && !c->no_fused;
+    uint8_t* const sc_bytes = (uint8_t*)c->w->scalars.p;
+    tp_counters* const d_bx_counters = (tp_counters*)(sc_bytes + 64);
+    uint32_t* const d_ticket = (uint32_t*)(sc_bytes + 128);
+    uint32_t* const d_back_count = d_ticket + 1;
+    FastArgs bxa{};
 
     c->w->cap_len.need(n * 4); c->w->n_final.need(n * 4); c->w->slot_of.need(n * 4);
     uint32_t* cap_len = c->w->cap_len.as<uint32_t>() - f0;      // indexed by absolute file number below
@@ -276,10 +292,13 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
             uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
             HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
             fa.stage = 0; fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
+            fa.front_only = fused ? 1 : 0;
             hipEvent_t pm = next_event(), pe = next_event();
             HIP_OK(launch_fast(c->dt, fa, s, pm));
             record(pe);
             if (st.timed) st.lean_ev.push_back({p0, pm, pe});
+            bxa = fa;
+            fa.front_only = 0;
             fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
         }
         fa.stage = 1; fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
@@ -331,9 +350,9 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
         if (ws_bytes > c->ws_budget && n > 64) {
             uint64_t mid = f0 + n / 2;
             c->last_slow -= n_slow;
-            int rc = run_range(c, io, f0, mid, st);
+            int rc = run_range(c, io, f0, mid, st, allow_fused);
             if (rc != TP_OK && rc != TP_E_CAPACITY) return rc;
-            return run_range(c, io, mid, f1, st);
+            return run_range(c, io, mid, f1, st, allow_fused);
         }
         c->w->workspace.need(ws_bytes);
         PipelineArgs pa{};
@@ -358,6 +377,75 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     } else {
         c->w->tile_sums.need(scan_tiles_needed(n) * 8);
     }
+    if (fused) {
+        // back half, caption offsets and caption bytes of the wave-kernel files in one kernel; once more when it had to decline
+        // files (the later stages finish them first) or when the caption buffer had to grow
+        c->w->tile_state.need(lean_bx_tiles(n) * 8);
+        c->w->slow_list_b.need(n * 4);
+        bxa.slow_list = c->w->slow_list_b.as<uint32_t>(); bxa.slow_count = d_back_count;
+        bxa.caption_offsets = io.caption_offsets; bxa.base_total = d_total + (st.chunk & 1); bxa.total_out = d_total + ((st.chunk + 1) & 1);
+        bxa.tile_state = c->w->tile_state.as<unsigned long long>(); bxa.ticket = d_ticket; bxa.bx_counters = io.counters ? d_bx_counters : nullptr;
+        bool declined_once = false;
+        uint64_t total = 0;
+        for (int pass = 0;; ++pass) {
+            bxa.captions = io.captions; bxa.caption_capacity = st.over_capacity ? 0 : io.caption_capacity;
+            HIP_OK(hipMemsetAsync(c->w->tile_state.p, 0, lean_bx_tiles(n) * 8, s));
+            HIP_OK(hipMemsetAsync(sc_bytes + 64, 0, 72, s));        // the kernel's own counters, ticket, declined count
+            hipEvent_t b0 = next_event(), b1 = next_event();
+            record(b0);
+            HIP_OK(launch_lean_bx(c->dt, bxa, s));
+            record(b1);
+            if (st.timed) st.fused_ev.emplace_back(b0, b1);
+            HIP_OK(hipMemcpyAsync(&c->host_scalars[3], bxa.total_out, 8, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(&c->host_scalars[5], d_back_count, 4, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            total = c->host_scalars[3];
+            const uint32_t n_back = (uint32_t)c->host_scalars[5];
+            if (n_back) {
+                // the later wave stages take what the back half declined; a file they decline too would need the general kernel a
+                // second time: the range then goes through the separate kernels from the start
+                uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);
+                bool give_up = declined_once || pass >= 3;
+                if (!give_up) {
+                    declined_once = true;
+                    HIP_OK(hipMemsetAsync(d_slow_count + 1, 0, 8, s));
+                    HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
+                    FastArgs fb = bxa;
+                    fb.front_only = 0; fb.triage = 0;
+                    fb.stage = 1; fb.item_list = c->w->slow_list_b.as<uint32_t>(); fb.item_count = d_back_count;
+                    fb.slow_list = c->w->slow_list1.as<uint32_t>(); fb.slow_count = d_slow_count + 1;
+                    HIP_OK(launch_fast(c->dt, fb, s));
+                    fb.stage = 2; fb.item_list = c->w->slow_list1.as<uint32_t>(); fb.item_count = d_slow_count + 1;
+                    fb.slow_list = c->w->slow_list2.as<uint32_t>(); fb.slow_count = d_slow_count + 2;
+                    HIP_OK(launch_fast(c->dt, fb, s));
+                    fb.stage = 3; fb.item_list = c->w->slow_list2.as<uint32_t>(); fb.item_count = d_slow_count + 2;
+                    fb.slow_list = c->w->slow_list0.as<uint32_t>(); fb.slow_count = d_slow_count0;
+                    HIP_OK(launch_fast(c->dt, fb, s));
+                    HIP_OK(hipMemcpyAsync(&c->host_scalars[5], d_slow_count0, 4, hipMemcpyDeviceToHost, s));
+                    HIP_OK(hipStreamSynchronize(s));
+                    give_up = (uint32_t)c->host_scalars[5] != 0;
+                }
+                if (give_up) {
+                    ++c->fused_reruns;
+                    c->last_slow -= n_slow;
+                    return run_range(c, io, f0, f1, st, false);
+                }
+                continue;
+            }
+            if (io.grow_captions && total > io.caption_capacity) {
+                c->out_captions.need(std::max<uint64_t>(total + total / 8, 16), true, s);
+                io.captions = c->out_captions.as<uint8_t>();
+                io.caption_capacity = c->out_captions.cap;
+                continue;
+            }
+            break;
+        }
+        st.total = total;
+        ++st.chunk;
+        if (st.total > io.caption_capacity) st.over_capacity = true;
+        if (st.over_capacity) return TP_E_CAPACITY;
+        if (io.counters) HIP_OK(launch_add_counters(io.counters, d_bx_counters, s));
+    } else {
     // caption offsets of the range, continuing the running total
     HIP_OK(launch_scan_u32(c->w->cap_len.as<uint32_t>(), n, io.caption_offsets + f0, c->w->tile_sums.as<uint64_t>(), d_total + (st.chunk & 1),
                            d_total + ((st.chunk + 1) & 1), s));
@@ -373,10 +461,11 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st) {
     }
     if (st.total > io.caption_capacity) st.over_capacity = true;
     if (st.over_capacity) return TP_E_CAPACITY;
+    }
     EmitArgs ea{};
     ea.file0 = f0; ea.file_end = f1;
     ea.wave_T = c->w->wave_T.as<uint32_t>(); ea.wave_LB = c->w->wave_LB.as<uint32_t>(); ea.wave_off = c->w->wave_off.as<uint64_t>(); ea.workspace = c->w->workspace.as<uint8_t>();
-    ea.fin32 = want_ids ? c->w->fin32.as<uint32_t>() : nullptr; ea.fast_ran = use_fast ? 1 : 0; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
+    ea.fin32 = want_ids ? c->w->fin32.as<uint32_t>() : nullptr; ea.fast_ran = use_fast ? 1 : 0; ea.wave_files_written = fused ? 1 : 0; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
     ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
     ea.histogram = io.histogram; ea.counters = io.counters; ea.fpw = fpw_used;
     hipEvent_t q0 = next_event(), q1 = next_event();
@@ -413,8 +502,8 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_byt
     const uint64_t n = io.n_files;
     c->timing = tp_timing{};
     c->last_slow = 0;
-    c->w->scalars.need(64);
-    HIP_OK(hipMemsetAsync(c->w->scalars.p, 0, 64, s));
+    c->w->scalars.need(SCALARS_BYTES);
+    HIP_OK(hipMemsetAsync(c->w->scalars.p, 0, SCALARS_BYTES, s));
     if (n == 0) {
         if (io.audit) HIP_OK(hipMemsetAsync(io.audit_offsets, 0, 8, s));
         if (audit_bytes) *audit_bytes = 0;
@@ -445,9 +534,11 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_byt
         HIP_OK(hipEventElapsedTime(&ms, p.begin, p.mid)); c->timing.lean_front_ms += ms;
         HIP_OK(hipEventElapsedTime(&ms, p.mid, p.end)); c->timing.lean_back_ms += ms;
     }
+    for (auto& p : st.fused_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.fused_ms += ms; }
     for (auto& p : st.pipe_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.general_ms += ms; }
     for (auto& p : st.emit_ev) { HIP_OK(hipEventElapsedTime(&ms, p.first, p.second)); c->timing.emit_ms += ms; }
-    c->timing.other_ms = c->timing.total_ms - c->timing.select_ms - c->timing.general_ms - c->timing.emit_ms;
+    c->timing.other_ms = c->timing.total_ms - c->timing.select_ms - c->timing.fused_ms - c->timing.general_ms - c->timing.emit_ms;
+    c->timing.fused_reruns = c->fused_reruns;
     c->timing.general_files = c->last_slow;
     if (caption_bytes) *caption_bytes = st.total;
     if (audit_bytes) *audit_bytes = st.audit_total;
@@ -470,8 +561,9 @@ void bind_fixed(tp_ctx* c) {
     };
     const size_t N = TP_NOALLOC_MAX_FILES;
     WorkBufs& w = c->fixed;
-    take(w.scalars, 64);
-    for (DevBuf* b : {&w.cap_len, &w.n_final, &w.slot_of, &w.slow_list, &w.slow_list0, &w.slow_list1, &w.slow_list2, &w.wave_T, &w.wave_LB}) take(*b, N * 4);
+    take(w.scalars, SCALARS_BYTES);
+    for (DevBuf* b : {&w.cap_len, &w.n_final, &w.slot_of, &w.slow_list, &w.slow_list0, &w.slow_list1, &w.slow_list2, &w.slow_list_b, &w.wave_T, &w.wave_LB}) take(*b, N * 4);
+    take(w.tile_state, lean_bx_tiles(N) * 8);
     take(w.wave_bytes, N * 8);
     take(w.wave_off, (N + 1) * 8);
     take(w.tile_sums, scan_tiles_needed(N) * 8);
@@ -793,6 +885,7 @@ tp_ctx* tp_create(const tp_config* cfg) {
         HIP_OK(hipSetDevice(c->device));
         if (const char* b = std::getenv("TAGPIPE_WORKSPACE_BYTES")) { unsigned long long v = std::strtoull(b, nullptr, 10); if (v >= (1ull << 20)) c->ws_budget = (size_t)v; }
         if (const char* b = std::getenv("TAGPIPE_NO_FAST")) c->no_fast = b[0] == '1';
+        if (const char* b = std::getenv("TAGPIPE_FUSED")) c->no_fused = b[0] != '1';
         HIP_OK(hipHostMalloc((void**)&c->host_scalars, 64, hipHostMallocDefault));
         std::memset(c->host_scalars, 0, 64);
         own_config(c.get(), *cfg);

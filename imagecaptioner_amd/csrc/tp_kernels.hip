@@ -312,7 +312,7 @@ __device__ __forceinline__ void lean_b_body(const FastArgs& a) {
             FastOut out;
             LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
             if (DETAIL && a.aud32) { aud.row = a.aud32 + i * AUD_STRIDE; aud.cnt = a.audit_cnt + i * AUDIT_COLS; aud.len = a.audit_len + i * AUDIT_COLS; aud.rbits = a.review_bits + i; }
-            const bool done = lean_back<DETAIL>(w, t, L, shared, rc_lds, w.lane() < n0 ? id0 : NO_ID, n0, out, a.fin32 + i * FAST_FIN_MAX,
+            const bool done = lean_back<DETAIL, true>(w, t, L, shared, rc_lds, w.lane() < n0 ? id0 : NO_ID, n0, out, a.fin32 + i * FAST_FIN_MAX,
                                         a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, records_free, aud);
             if (done) {
                 if (w.lane() == 0) {
@@ -813,17 +813,116 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
 // The same files, several to a wavefront.  The captions of consecutive files are consecutive in the output, so a run of
 // wave-kernel files is one list of tags in which the last tag of each file is followed by the line end instead of ", ".
 // A wavefront takes a group of RUN_FILES consecutive files: as one run when all of them are wave-kernel files and the run
-// fits (RUN_BLOCKS lane blocks of tags, RUN_STAGE caption bytes), else file by file.  Lanes 0 .. RUN_FILES load the
-// group's sizes, kinds and offsets (one instruction each for the whole group, one group ahead); every lane block of the
-// run then loads its tags' ids, then their 32-byte caption records (strings up to 31 bytes inline), and only then the
-// text is put together in LDS at the output's 16-byte phase and stored 16 bytes per lane.  Per file this takes about
-// two thirds of the instructions of one file per wavefront (c2's 73 tags fill 1.14 of that kernel's two lane blocks) and
-// a third of its dependent memory round trips.
+// fits (RUN_BLOCKS lane blocks of tags, RUN_STAGE caption bytes), else file by file.  Every lane block of the run loads its
+// tags' ids, then their 32-byte caption records (strings up to 31 bytes inline), and only then the text is put together in
+// LDS at the output's 16-byte phase and stored 16 bytes per lane.  Per file this takes about two thirds of the
+// instructions of one file per wavefront (c2's 73 tags fill 1.14 of that kernel's two lane blocks) and a third of its
+// dependent memory round trips.
 constexpr int RUN_FILES = 4;
 constexpr int RUN_BLOCKS = 5;
 constexpr uint32_t RUN_TAGS = 64 * RUN_BLOCKS;
 constexpr uint32_t RUN_STAGE = 6144;
 static_assert(RUN_STAGE >= FAST_CAPTION_MAX && RUN_TAGS >= FAST_FIN_MAX, "a single file always fits a run");
+
+// One group of up to RUN_FILES consecutive files: rows = the first file's row of tag ids (the others follow at FAST_FIN_MAX
+// words each); bit j of fastmask: file j is a wave-kernel file (the others are written elsewhere); n_[j] its tag count;
+// off_[j] .. off_[j + 1] its place in `captions`.  stage: RUN_STAGE + 48 bytes of LDS of this wavefront's own.
+template <class TT>
+__device__ __forceinline__ void emit_group(const TT& t, const uint32_t* rows, uint8_t* captions, uint8_t* stage, uint32_t lane, uint32_t nfile, uint32_t fastmask,
+                                           const uint32_t (&n_)[RUN_FILES], const uint64_t (&off_)[RUN_FILES + 1]) {
+    uint32_t tags_all = 0;
+    for (int j = 0; j < RUN_FILES; ++j) tags_all += ((fastmask >> j) & 1u) ? n_[j] : 0u;
+    const bool whole = fastmask == (1u << nfile) - 1u && tags_all <= RUN_TAGS && off_[nfile] - off_[0] <= (uint64_t)RUN_STAGE;
+    // the runs of the group: [0, nfile) as a whole, or every wave-kernel file by itself
+    for (uint32_t lo = 0; lo < nfile; lo = whole ? nfile : lo + 1) {
+        const uint32_t hi = whole ? nfile : lo + 1;
+        if (!whole && !((fastmask >> lo) & 1u)) continue;
+        uint32_t nn[RUN_FILES];
+        for (int j = 0; j < RUN_FILES; ++j) nn[j] = ((uint32_t)j >= lo && (uint32_t)j < hi) ? n_[j] : 0u;
+        const uint32_t c1 = nn[0], c2 = c1 + nn[1], c3 = c2 + nn[2], T = c3 + nn[3];
+        static_assert(RUN_FILES == 4, "the cumulative counts above are written out for four files");
+        uint64_t out0 = off_[0], out1 = off_[RUN_FILES];
+        for (int j = 1; j < RUN_FILES; ++j) { if ((uint32_t)j == lo) out0 = off_[j]; if ((uint32_t)j == hi) out1 = off_[j]; }
+        const uint32_t total = (uint32_t)(out1 - out0);
+        if (T == 0 || total == 0) continue;
+        const uint32_t head = (uint32_t)((uintptr_t)(captions + out0) & 15);
+
+        // which file and which of its tags a lane holds in each lane block; the ids, then the records
+        uint32_t id[RUN_BLOCKS];                                   // bit 31: the last tag of its file
+        TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
+            const uint32_t gi = 64u * b + lane;
+            const uint32_t j = (uint32_t)(gi >= c1) + (uint32_t)(gi >= c2) + (uint32_t)(gi >= c3);
+            const uint32_t cj = j == 0 ? 0u : j == 1 ? c1 : j == 2 ? c2 : c3, nj = j == 0 ? nn[0] : j == 1 ? nn[1] : j == 2 ? nn[2] : nn[3];
+            const uint32_t kb = gi - cj;
+            id[b] = 0;
+            if (64u * b < T && gi < T) {
+                const uint32_t v = rows[(size_t)j * FAST_FIN_MAX + kb];
+                id[b] = (v < t.n_strings ? v : 0) | (uint32_t)(kb + 1 == nj) << 31;
+            }
+        }
+        uint4 r0[RUN_BLOCKS], r1[RUN_BLOCKS];
+        TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
+            r0[b] = make_uint4(0, 0, 0, 0); r1[b] = r0[b];
+            if (64u * b < T) {
+                const uint4* rp = (const uint4*)(t.emit_rec32 + 8 * (size_t)(id[b] & 0x7FFFFFFFu));
+                r0[b] = rp[0]; r1[b] = rp[1];
+            }
+        }
+        uint32_t at = head;                                        // where the lane block's text begins in the staging area
+        TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
+            if (64u * b >= T) break;
+            const bool live = 64u * b + lane < T;
+            const uint32_t lenb = r1[b].w >> 24;
+            const bool in_rec = lenb != 0xFFu;
+            const uint32_t n = live ? (in_rec ? lenb : r0[b].y) : 0u;
+            const bool last = (id[b] >> 31) != 0;
+            const uint32_t seg = live ? n + (last ? t.newline_len : 2u) : 0u;
+            const uint32_t incl = wave_scan_incl(seg);
+            uint8_t* dst = stage + at + incl - seg;
+            uint64_t v[4];
+            v[0] = r0[b].x | (uint64_t)r0[b].y << 32; v[1] = r0[b].z | (uint64_t)r0[b].w << 32;
+            v[2] = r1[b].x | (uint64_t)r1[b].y << 32; v[3] = r1[b].z | (uint64_t)(r1[b].w & 0xFFFFFFu) << 32;
+            const uint8_t* sp = t.str_bytes + (in_rec ? 0u : r0[b].x);
+            if (!in_rec && n) {                                    // longer than the record: its first 32 bytes at once (the string arena has slack behind its end)
+                __builtin_memcpy(&v[0], sp, 16);
+                __builtin_memcpy(&v[2], sp + 16, 16);
+            }
+            const uint32_t n32 = n < 32 ? n : 32, nfull = n32 >> 3;
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < nfull) __builtin_memcpy(dst + 8 * k, &v[k], 8);
+            if (n32 & 7) {                                           // the last, partial word in pieces of 4, 2 and 1 bytes
+                uint64_t x = nfull == 0 ? v[0] : (nfull == 1 ? v[1] : (nfull == 2 ? v[2] : v[3]));
+                uint32_t o = 8 * nfull;
+                if (n32 & 4) { uint32_t y = (uint32_t)x; __builtin_memcpy(dst + o, &y, 4); x >>= 32; o += 4; }
+                if (n32 & 2) { uint16_t y = (uint16_t)x; __builtin_memcpy(dst + o, &y, 2); x >>= 16; o += 2; }
+                if (n32 & 1) dst[o] = (uint8_t)x;
+            }
+            for (uint32_t done = 32; done < n; ++done) dst[done] = sp[done];
+            if (live) {
+                if (last) { for (uint32_t q = 0; q < t.newline_len; ++q) dst[n + q] = t.newline[q]; }
+                else { dst[n] = ','; dst[n + 1] = ' '; }
+            }
+            at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staging area is this wave's own: no wait for global traffic
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint8_t* gbase = captions + out0 - head;                      // 16-byte aligned
+        const uint32_t end = head + total, nchunks = (end + 15) >> 4;
+        for (uint32_t c = lane; c < nchunks; c += 64) {
+            if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
+        }
+        if (lane < 32) {                                              // the partial first and last pieces, one byte per lane
+            const uint32_t c = lane < 16 ? 0u : nchunks - 1;
+            const uint32_t off = 16 * c + (lane & 15);
+            const bool partial = !(16 * c >= head && 16 * c + 16 <= end) && (lane < 16 || nchunks > 1);
+            if (partial && off >= head && off < end) gbase[off] = stage[off];
+        }
+        __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next run's are written
+    }
+}
+
+// Lanes 0 .. RUN_FILES load the group's sizes, kinds and offsets (one instruction each for the whole group, one group ahead).
 #ifndef TP_EMIT_RUNS_WAVES_PER_SIMD
 #define TP_EMIT_RUNS_WAVES_PER_SIMD 4      // 128 registers: the records of five lane blocks stay in registers (measured: 0.79 ms against 0.82 at five waves with spills)
 #endif
@@ -868,107 +967,7 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         uint64_t off_[RUN_FILES + 1];
         for (int j = 0; j < RUN_FILES; ++j) n_[j] = lane_of(m0.n, j);
         for (int j = 0; j <= RUN_FILES; ++j) off_[j] = lane_of((uint32_t)m0.off, j) | (uint64_t)lane_of((uint32_t)(m0.off >> 32), j) << 32;
-        uint32_t tags_all = 0;
-        for (int j = 0; j < RUN_FILES; ++j) tags_all += ((fastmask >> j) & 1u) ? n_[j] : 0u;
-        const bool whole = fastmask == (1u << nfile) - 1u && tags_all <= RUN_TAGS && off_[nfile] - off_[0] <= (uint64_t)RUN_STAGE;
-        // the runs of the group: [0, nfile) as a whole, or every wave-kernel file by itself
-        for (uint32_t lo = 0; lo < nfile; lo = whole ? nfile : lo + 1) {
-            const uint32_t hi = whole ? nfile : lo + 1;
-            if (!whole && !((fastmask >> lo) & 1u)) continue;
-            uint32_t nn[RUN_FILES];
-            for (int j = 0; j < RUN_FILES; ++j) nn[j] = ((uint32_t)j >= lo && (uint32_t)j < hi) ? n_[j] : 0u;
-            const uint32_t c1 = nn[0], c2 = c1 + nn[1], c3 = c2 + nn[2], T = c3 + nn[3];
-            static_assert(RUN_FILES == 4, "the cumulative counts above are written out for four files");
-            uint64_t out0 = off_[0], out1 = off_[RUN_FILES];
-            for (int j = 1; j < RUN_FILES; ++j) { if ((uint32_t)j == lo) out0 = off_[j]; if ((uint32_t)j == hi) out1 = off_[j]; }
-            const uint32_t total = (uint32_t)(out1 - out0);
-            if (T == 0 || total == 0) continue;
-            const uint32_t head = (uint32_t)((uintptr_t)(a.captions + out0) & 15);
-
-            // which file and which of its tags a lane holds in each lane block; the ids, then the records
-            uint32_t id[RUN_BLOCKS];                                   // bit 31: the last tag of its file
-            TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
-                const uint32_t gi = 64u * b + lane;
-                const uint32_t j = (uint32_t)(gi >= c1) + (uint32_t)(gi >= c2) + (uint32_t)(gi >= c3);
-                const uint32_t cj = j == 0 ? 0u : j == 1 ? c1 : j == 2 ? c2 : c3, nj = j == 0 ? nn[0] : j == 1 ? nn[1] : j == 2 ? nn[2] : nn[3];
-                const uint32_t kb = gi - cj;
-                id[b] = 0;
-                if (64u * b < T && gi < T) {
-#ifdef RUNS_X_NOIDS
-                    const uint32_t v = (uint32_t)(row0 + j + kb) & 1023u;
-#else
-                    const uint32_t v = a.fin32[(row0 + j) * FAST_FIN_MAX + kb];
-#endif
-                    id[b] = (v < t.n_strings ? v : 0) | (uint32_t)(kb + 1 == nj) << 31;
-                }
-            }
-            uint4 r0[RUN_BLOCKS], r1[RUN_BLOCKS];
-            TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
-                r0[b] = make_uint4(0, 0, 0, 0); r1[b] = r0[b];
-                if (64u * b < T) {
-#ifdef RUNS_X_NOGATHER
-                    r0[b] = make_uint4(id[b], id[b] * 3u, id[b] * 5u, 7u); r1[b] = make_uint4(0, 0, 0, 12u << 24);
-#else
-                    const uint4* rp = (const uint4*)(t.emit_rec32 + 8 * (size_t)(id[b] & 0x7FFFFFFFu));
-                    r0[b] = rp[0]; r1[b] = rp[1];
-#endif
-                }
-            }
-            uint32_t at = head;                                        // where the lane block's text begins in the staging area
-            TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
-                if (64u * b >= T) break;
-                const bool live = 64u * b + lane < T;
-                const uint32_t lenb = r1[b].w >> 24;
-                const bool in_rec = lenb != 0xFFu;
-                const uint32_t n = live ? (in_rec ? lenb : r0[b].y) : 0u;
-                const bool last = (id[b] >> 31) != 0;
-                const uint32_t seg = live ? n + (last ? t.newline_len : 2u) : 0u;
-                const uint32_t incl = wave_scan_incl(seg);
-                uint8_t* dst = stage + at + incl - seg;
-                uint64_t v[4];
-                v[0] = r0[b].x | (uint64_t)r0[b].y << 32; v[1] = r0[b].z | (uint64_t)r0[b].w << 32;
-                v[2] = r1[b].x | (uint64_t)r1[b].y << 32; v[3] = r1[b].z | (uint64_t)(r1[b].w & 0xFFFFFFu) << 32;
-                const uint8_t* sp = t.str_bytes + (in_rec ? 0u : r0[b].x);
-                if (!in_rec && n) {                                    // longer than the record: its first 32 bytes at once (the string arena has slack behind its end)
-                    __builtin_memcpy(&v[0], sp, 16);
-                    __builtin_memcpy(&v[2], sp + 16, 16);
-                }
-                const uint32_t n32 = n < 32 ? n : 32, nfull = n32 >> 3;
-                for (uint32_t k = 0; k < 4; ++k)
-                    if (k < nfull) __builtin_memcpy(dst + 8 * k, &v[k], 8);
-                if (n32 & 7) {                                           // the last, partial word in pieces of 4, 2 and 1 bytes
-                    uint64_t x = nfull == 0 ? v[0] : (nfull == 1 ? v[1] : (nfull == 2 ? v[2] : v[3]));
-                    uint32_t o = 8 * nfull;
-                    if (n32 & 4) { uint32_t y = (uint32_t)x; __builtin_memcpy(dst + o, &y, 4); x >>= 32; o += 4; }
-                    if (n32 & 2) { uint16_t y = (uint16_t)x; __builtin_memcpy(dst + o, &y, 2); x >>= 16; o += 2; }
-                    if (n32 & 1) dst[o] = (uint8_t)x;
-                }
-                for (uint32_t done = 32; done < n; ++done) dst[done] = sp[done];
-                if (live) {
-                    if (last) { for (uint32_t q = 0; q < t.newline_len; ++q) dst[n + q] = t.newline[q]; }
-                    else { dst[n] = ','; dst[n + 1] = ' '; }
-                }
-                at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the staging area is this wave's own: no wait for global traffic
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint8_t* gbase = a.captions + out0 - head;                    // 16-byte aligned
-            const uint32_t end = head + total, nchunks = (end + 15) >> 4;
-#ifdef RUNS_X_NOSTORE
-            if (total == 0xFFFFFFFFu)
-#endif
-            for (uint32_t c = lane; c < nchunks; c += 64) {
-                if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
-            }
-            if (lane < 32) {                                              // the partial first and last pieces, one byte per lane
-                const uint32_t c = lane < 16 ? 0u : nchunks - 1;
-                const uint32_t off = 16 * c + (lane & 15);
-                const bool partial = !(16 * c >= head && 16 * c + 16 <= end) && (lane < 16 || nchunks > 1);
-                if (partial && off >= head && off < end) gbase[off] = stage[off];
-            }
-            __builtin_amdgcn_wave_barrier();                              // the staging bytes are read before the next run's are written
-        }
+        emit_group(t, a.fin32 + row0 * FAST_FIN_MAX, a.captions, stage, lane, nfile, fastmask, n_, off_);
     }
     if (a.counters) {                                                     // added up per block in LDS, then one global atomic per block and counter
         if (threadIdx.x < 8) blk_cnt[threadIdx.x] = 0;
@@ -977,6 +976,254 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         __syncthreads();
         if (threadIdx.x < 8 && blk_cnt[threadIdx.x]) atomicAdd((unsigned long long*)a.counters + threadIdx.x, blk_cnt[threadIdx.x]);
     }
+}
+
+// The back half, the caption offsets and the caption bytes in one kernel (the plain run: no detail arrays, no audit lists).
+// Files are handed out in tiles of BX_TILE consecutive files, in the order blocks ask for them (a ticket counter), BX_FILES
+// consecutive files to each of the block's wavefronts.  A wavefront first runs the back half for those of its files the
+// front half passed (final tag ids to the file's row of the id array, as k_lean_b leaves them: the histogram kernel counts
+// them there, and the rows are in the L2 cache when the same wavefront reads them again for the text); files an earlier
+// stage has finished bring their sizes.  The block adds up its files' caption bytes and publishes the sum in the tile's state
+// word (flag AGG).  Where the tile's captions begin is the sum over all tiles before it: a decoupled look-back over the state
+// words, nearest tile first, adding up aggregates until a tile is met whose inclusive prefix is known (flag PRE), after which
+// the tile's own inclusive prefix is published.  A tile waits for nothing but state words of tiles handed out before it, which
+// their blocks publish without waiting for anyone.  The look-back of a tile is put off until the block has done the back
+// halves of its NEXT tile: by then the tiles just before it have long published their sums, so the walk finds every word it
+// needs at the first try (tiles that run side by side all finish their back halves at about the same time; looking back
+// right away, each would wait for its neighbours and walk through up to a thousand of them while its block idles).
+// Then every wavefront writes its files' caption offsets and their text, RUN_FILES files to a run as k_emit_runs does.
+// What this saves over k_lean_b + scan + k_emit_runs: the latency-bound text phase runs beside other wavefronts' back
+// halves, which are bound by instruction issue; the sizes, kinds and offsets are not loaded again; three scan kernels go.
+// A file the back half declines is put on a.slow_list and counted in *a.slow_count with length 0: the host then finishes such
+// files with the later stages and runs this kernel again (files finished here are then files "an earlier stage has finished").
+#ifndef BX_RUNS_N
+#define BX_RUNS_N 2
+#endif
+constexpr int BX_RUNS = BX_RUNS_N;
+constexpr int BX_FILES = BX_RUNS * RUN_FILES;                 // files per wavefront and tile
+constexpr int BX_TILE = BX_FILES * LEAN_WAVES_PER_BLOCK;      // files per tile
+constexpr unsigned long long BX_AGG = 1ull << 62, BX_PRE = 2ull << 62, BX_VAL = (1ull << 62) - 1;
+constexpr int BX_WINDOWS = 4;                                  // state words per lane and look-back step
+#ifndef TP_LEAN_BX_WAVES_PER_SIMD
+#define TP_LEAN_BX_WAVES_PER_SIMD 4
+#endif
+union alignas(16) BxWaveLds {
+    LeanLds lean;                                               // while the wavefront's back halves run
+    uint8_t stage[RUN_STAGE + 48];                              // while its captions are put together
+};
+struct BxMeta { uint32_t n, len, fl, fast; };                  // one file: tags, caption bytes, verdict flags, whether its caption is written here
+
+// The caption bytes of all files before tile `tile` (> 0) of this launch.
+__device__ __forceinline__ unsigned long long bx_look_back(const unsigned long long* state, uint64_t tile, uint32_t lane) {
+    long long look = (long long)tile - 1;
+    unsigned long long part = 0;
+    for (;;) {
+        unsigned long long v[BX_WINDOWS];
+        TP_UNROLL for (int q = 0; q < BX_WINDOWS; ++q) {
+            const long long idx = look - 64 * q - (long long)lane;   // lane 0 of window 0: the nearest tile
+            v[q] = BX_PRE;                                          // before the first tile: nothing, and nothing further back
+            if (idx >= 0) v[q] = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int q = 0;
+        bool done = false, again = false;
+        for (; q < BX_WINDOWS; ++q) {
+            const uint64_t m_pre = __ballot((v[q] >> 62) == 2 ? 1 : 0), m_none = __ballot((v[q] >> 62) == 0 ? 1 : 0);
+            const uint32_t first_pre = m_pre ? (uint32_t)__builtin_ctzll(m_pre) : 64u;
+            const uint64_t upto = first_pre >= 63u ? ~0ull : ((1ull << (first_pre + 1)) - 1ull);   // the lanes whose values count
+            if (m_none & upto) { again = true; break; }           // a tile in between has not published yet: this window once more
+            if ((upto >> lane) & 1ull) part += v[q] & BX_VAL;
+            if (first_pre < 64u) { done = true; break; }
+        }
+        if (done) break;
+        look -= 64 * q;
+        if (again) __builtin_amdgcn_s_sleep(4);
+    }
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+    return part;
+}
+
+__global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_BX_WAVES_PER_SIMD))) void k_lean_bx(FastArgs a) {
+    __shared__ BxWaveLds lds[LEAN_WAVES_PER_BLOCK];
+    __shared__ LeanShared shared;
+    __shared__ DeclineBuf dbuf[LEAN_WAVES_PER_BLOCK];
+    __shared__ uint32_t wave_total[2][LEAN_WAVES_PER_BLOCK];   // by tile parity: a tile's sums are read while the next tile's are made
+    __shared__ BxMeta meta[2][LEAN_WAVES_PER_BLOCK][BX_FILES];
+    __shared__ uint32_t tile_s;
+    __shared__ unsigned long long blk_cnt[8];
+    extern __shared__ uint32_t rc_lds[];                        // the rule cache, t.rc_words words (dynamic LDS)
+    ConstTables& t = *(ConstTables*)(uintptr_t)a.tables;
+    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
+    lean_shared_init(t, shared, threadIdx.x, blockDim.x);
+    if (threadIdx.x < 8) blk_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t n_declined = 0;
+    const uint32_t wv = wave_in_block();
+    LeanLds& L = lds[wv].lean;
+    DevWave w;
+    const uint32_t lane = w.lane();
+    const uint64_t n_items = a.file_end - a.file0;
+    const uint64_t n_tiles = (n_items + BX_TILE - 1) / BX_TILE;
+    auto lane_of = [](uint32_t v, uint32_t j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)j)); };
+
+    // what the wavefront knows of a file before its turn: kind, sizes, and - for a file of the front half - its candidates' ids
+    struct Peek { uint32_t slot, n, len, id; };
+    auto peek = [&](uint64_t i, Peek& p) {
+        p.slot = SLOT_NONE; p.n = 0; p.len = 0; p.id = NO_ID;
+        if (i < n_items) {
+            const uint64_t f = a.file0 + i;
+            p.slot = a.slot_of[f];
+            p.n = a.n_final[f];
+            if (p.slot == SLOT_LEAN) p.id = a.fin32[i * FAST_FIN_MAX + lane];      // entries behind the count are never used
+            else if (p.slot != SLOT_NONE) p.len = a.cap_len[f];
+        }
+    };
+    auto fetch_records = [&](const Peek& p) {                    // p is the same in every lane but for id
+        if (p.slot == SLOT_LEAN && lane < p.n) {
+            const uint32_t* src = t.crec + 8 * (size_t)p.id;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)&L.cr[0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4), (__attribute__((address_space(3))) void*)&L.cr[1][0], 16, 0, 0);
+        }
+    };
+
+    bool pend = false;                                           // the tile before: back halves done, sums published, text still to write
+    uint64_t pend_tile = 0;
+    for (uint32_t it = 0;; ++it) {
+#ifdef BX_X_STATIC
+        const uint64_t tile = blockIdx.x + (uint64_t)it * gridDim.x;
+#else
+        if (threadIdx.x == 0) tile_s = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        const uint64_t tile = tile_s;
+#endif
+        const bool have = tile < n_tiles;
+        if (!have && !pend) break;
+        const uint32_t par = it & 1u;
+        if (have) {
+            // ---- the wavefront's files of this tile: back halves, sizes ---------------------------------------------------------------
+            const uint64_t i0 = tile * BX_TILE + (uint64_t)wv * BX_FILES;    // the wavefront's first file, relative to file0
+            uint32_t tile_len = 0;
+            Peek p0, p1;
+            peek(i0, p0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fetch_records(p0);
+            for (uint32_t j = 0; j < (uint32_t)BX_FILES; ++j) {
+                const uint64_t i = i0 + j;
+                const uint64_t f = a.file0 + i;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this file's records are in L.cr
+                if (j + 1 < (uint32_t)BX_FILES) peek(i + 1, p1); else { p1.slot = SLOT_NONE; p1.n = 0; p1.len = 0; p1.id = NO_ID; }
+                bool fetched = false;
+                auto records_free = [&]() {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // what this file read out of L.cr has arrived, and the next file's ids
+                    fetch_records(p1);
+                    fetched = true;
+                };
+                BxMeta m{0, 0, 0, 0};
+                if (p0.slot == SLOT_LEAN) {
+                    FastOut out;
+                    const bool done = lean_back<false, true>(w, t, L, shared, rc_lds, lane < p0.n ? p0.id : NO_ID, p0.n, out, a.fin32 + i * FAST_FIN_MAX, nullptr, nullptr, records_free);
+                    if (done) {
+                        m.n = out.n_final; m.len = out.caption_len; m.fl = out.verdict.flags; m.fast = 1;
+                        if (lane == 0) {
+                            a.verdicts[f] = out.verdict;
+                            a.n_final[f] = m.n;
+                            a.cap_len[f] = m.len;
+                            a.slot_of[f] = SLOT_FAST;
+                        }
+                    } else {
+                        if (lane == 0) a.slot_of[f] = SLOT_NONE;
+                        decline_push(dbuf[wv], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
+                    }
+                    w.sync();
+                } else if (p0.slot == SLOT_FAST) {
+                    m.n = p0.n; m.len = p0.len; m.fast = 1;
+                    m.fl = a.verdicts[f].flags;
+                } else {
+                    m.len = p0.len;                               // a file of the general kernel: its caption is written from its workspace later
+                }
+                if (!fetched) records_free();
+                if (lane == 0) meta[par][wv][j] = m;
+                tile_len += m.len;
+                p0 = p1;
+            }
+            if (lane == 0) wave_total[par][wv] = tile_len;
+        }
+#ifndef BX_X_NOBAR
+        __syncthreads();
+#endif
+        if (have && wv == 0 && lane == 0) {                      // the tile's sum; the first tile knows its prefix already
+            unsigned long long total = 0;
+            for (int k = 0; k < LEAN_WAVES_PER_BLOCK; ++k) total += wave_total[par][k];
+            __hip_atomic_store(&a.tile_state[tile], tile == 0 ? (BX_PRE | (*a.base_total + total)) : (BX_AGG | total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pend) {
+            // ---- the tile before: where its captions begin, then offsets and text of the wavefront's files ------------------------------
+            const uint32_t pp = par ^ 1u;
+#ifdef BX_X_NOLOOK
+            unsigned long long base = *a.base_total + pend_tile * 1000;
+#else
+            unsigned long long base = pend_tile == 0 ? *a.base_total : bx_look_back(a.tile_state, pend_tile, lane);
+#endif
+            if (wv == 0 && lane == 0 && pend_tile != 0) {
+                unsigned long long total = 0;
+                for (int k = 0; k < LEAN_WAVES_PER_BLOCK; ++k) total += wave_total[pp][k];
+                __hip_atomic_store(&a.tile_state[pend_tile], BX_PRE | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (uint32_t k = 0; k < wv; ++k) base += wave_total[pp][k];
+            const uint64_t i0 = pend_tile * BX_TILE + (uint64_t)wv * BX_FILES;
+            BxMeta m{0, 0, 0, 0};
+            if (lane < (uint32_t)BX_FILES) m = meta[pp][wv][lane];
+            const uint32_t incl = w.scan_incl(m.len);
+            const unsigned long long off = base + (incl - m.len);
+            if (lane < (uint32_t)BX_FILES && i0 + lane < n_items) {
+                a.caption_offsets[a.file0 + i0 + lane] = off;
+                if (i0 + lane + 1 == n_items) { a.caption_offsets[a.file_end] = off + m.len; *a.total_out = off + m.len; }
+                if (m.fast && a.bx_counters) {
+                    const uint32_t fl = m.fl;
+                    atomicAdd(&blk_cnt[0], 1ull);
+                    if (fl & TP_F_LOW) atomicAdd(&blk_cnt[1], 1ull);
+                    if (fl & TP_F_ELIGIBLE) atomicAdd(&blk_cnt[2], 1ull);
+                    if (fl & TP_F_FOOTJOB) atomicAdd(&blk_cnt[3], 1ull);
+                    if (fl & TP_F_FALLBACK) atomicAdd(&blk_cnt[4], 1ull);
+                    if (fl & TP_F_LINE_REJECTED) atomicAdd(&blk_cnt[5], 1ull);
+                    if (fl & TP_F_UNSUPPORTED) atomicAdd(&blk_cnt[6], 1ull);
+                    if (fl & TP_F_SAFE_REJECT) atomicAdd(&blk_cnt[7], 1ull);
+                }
+            }
+            const uint32_t fastbits = (uint32_t)w.ballot(m.fast != 0);
+            for (uint32_t r = 0; r < (uint32_t)BX_RUNS; ++r) {
+                const uint64_t row0 = i0 + (uint64_t)RUN_FILES * r;
+                if (row0 >= n_items) break;
+                const uint64_t left = n_items - row0;
+                const uint32_t nfile = left < (uint64_t)RUN_FILES ? (uint32_t)left : (uint32_t)RUN_FILES;
+                const uint32_t fastmask = (fastbits >> (RUN_FILES * r)) & ((1u << nfile) - 1u);
+                if (fastmask == 0) continue;
+                uint32_t n_[RUN_FILES];
+                uint64_t off_[RUN_FILES + 1];
+                for (uint32_t q = 0; q < (uint32_t)RUN_FILES; ++q) {
+                    n_[q] = lane_of(m.n, RUN_FILES * r + q);
+                    off_[q] = lane_of((uint32_t)off, RUN_FILES * r + q) | (uint64_t)lane_of((uint32_t)(off >> 32), RUN_FILES * r + q) << 32;
+                }
+                off_[RUN_FILES] = off_[RUN_FILES - 1] + lane_of(m.len, RUN_FILES * r + RUN_FILES - 1);
+                for (uint32_t q = nfile; q < (uint32_t)RUN_FILES; ++q) { n_[q] = 0; off_[q + 1] = off_[nfile]; }     // (files behind the range's end)
+                if (off_[nfile] > a.caption_capacity) continue;   // no room: the host learns the total and reports it
+#ifdef BX_X_NOEMIT
+                if (a.caption_capacity == 12345)
+#endif
+                emit_group(t, a.fin32 + row0 * FAST_FIN_MAX, a.captions, lds[wv].stage, lane, nfile, fastmask, n_, off_);
+            }
+            w.sync();
+        }
+        pend = have;
+        pend_tile = tile;
+    }
+    decline_flush(dbuf[wv], n_declined, a.slow_list, a.slow_count);
+    if (a.bx_counters) {
+        __syncthreads();
+        if (threadIdx.x < 8 && blk_cnt[threadIdx.x]) atomicAdd((unsigned long long*)a.bx_counters + threadIdx.x, blk_cnt[threadIdx.x]);
+    }
+}
+__global__ __launch_bounds__(64) void k_add_counters(tp_counters* dst, const tp_counters* src) {
+    if (threadIdx.x < 8) { const unsigned long long v = ((const unsigned long long*)src)[threadIdx.x]; if (v) atomicAdd((unsigned long long*)dst + threadIdx.x, v); }
 }
 
 // Tag histogram of the wave-kernel files: ids id0 .. id0 + HIST_IDS are counted in LDS (a tag occurs at most once per file,
@@ -1201,6 +1448,7 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
         if (want < 256u * 5u) want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK < 256u * 5u ? (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK : 256u * 5u;
         hipLaunchKernelGGL(k_lean_a, dim3((unsigned)(want < lean_blocks_a ? want : lean_blocks_a)), dim3(64 * LEAN_WAVES_PER_BLOCK), 0, s, a);
         if (between) { hipError_t e = hipEventRecord(between, s); if (e != hipSuccess) return e; }
+        if (a.front_only) return hipGetLastError();               // the fused back half follows later (launch_lean_bx)
         const dim3 grid_b((unsigned)(want < lean_blocks_b ? want : lean_blocks_b));
         if (a.fired || a.facet_choice || a.aud32) hipLaunchKernelGGL(k_lean_b_detail, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
         else hipLaunchKernelGGL(k_lean_b, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
@@ -1208,6 +1456,21 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
     else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < (after_lean ? after_lean2 : 4096u) ? n : (after_lean ? after_lean2 : 4096u))), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    return hipGetLastError();
+}
+uint64_t lean_bx_tiles(uint64_t n_files) { return (n_files + BX_TILE - 1) / BX_TILE; }
+hipError_t launch_lean_bx(const DevTables& t, const FastArgs& a, hipStream_t s) {
+    const uint64_t n = a.file_end - a.file0;
+    if (n == 0) return hipSuccess;
+    const uint64_t tiles = lean_bx_tiles(n);
+    // as many blocks as fit at once take tiles until none is left (a block that starts late simply finds fewer)
+    static const unsigned per_cu = env_blocks("TAGPIPE_LEAN_BX_BLOCKS_PER_CU", (unsigned)TP_LEAN_BX_WAVES_PER_SIMD);
+    const uint64_t cap = 256ull * per_cu;
+    hipLaunchKernelGGL(k_lean_bx, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
+    return hipGetLastError();
+}
+hipError_t launch_add_counters(tp_counters* dst, const tp_counters* src, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(64), 0, s, dst, src);
     return hipGetLastError();
 }
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,
@@ -1241,7 +1504,7 @@ hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s) {
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
-    if (a.fin32 && a.fast_ran) {                            // the wave-per-file kernel ran: its files first
+    if (a.fin32 && a.fast_ran && !a.wave_files_written) {   // the wave-per-file kernel ran: its files first
         uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
         static const unsigned per_cu = env_blocks("TAGPIPE_EMIT_BLOCKS_PER_CU", (unsigned)TP_EMIT_WAVES_PER_SIMD);
         unsigned blocks = (unsigned)(want < 256 * per_cu ? want : 256 * per_cu);   // as many blocks (of four wavefronts) per CU as fit at once

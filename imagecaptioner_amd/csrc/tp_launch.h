@@ -33,6 +33,7 @@ struct FastArgs {
     const uint64_t* secondary_begin;   // two replies per file to merge: first tag of the secondary reply (else null)
     int secondary_cap;
     int triage;                   // 1: existing-caption triage: stop after the candidates, verdict flags carry TP_F_TRIAGE_BAD
+    int front_only;               // stage 0: launch the front half alone
     int stage;                    // 0: the lean stage (tp_lean.h); 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)
     uint32_t* fired;
     uint16_t* facet_choice;
@@ -43,6 +44,15 @@ struct FastArgs {
     uint32_t* audit_cnt;          // AUDIT_COLS per file, indexed by file - file0
     uint32_t* audit_len;
     uint32_t* review_bits;        // indexed by file - file0
+    // the fused back half (k_lean_bx: back half, caption offsets by look-back over tiles of files, caption bytes); null / 0 otherwise
+    uint64_t* caption_offsets;    // indexed by file; the kernel writes entries file0 .. file_end
+    uint8_t* captions;
+    uint64_t caption_capacity;    // a tile whose captions would end behind this writes none (the total is still counted)
+    const uint64_t* base_total;   // caption bytes of the files before file0 (device memory)
+    uint64_t* total_out;          // receives *base_total + the range's caption bytes
+    unsigned long long* tile_state;   // one word per tile, zero before the launch
+    uint32_t* ticket;             // zero before the launch: tiles are handed out in the order blocks ask for them
+    tp_counters* bx_counters;     // accumulated (may be null)
 };
 
 // General kernel: items are files file0 + i, or slow_list[i] when a list is given.  Item i uses lane i & 63 of
@@ -103,6 +113,7 @@ struct EmitArgs {
     uint32_t* fin32;              // FAST_FIN_MAX tag ids per file, indexed by file - file0: written by the wave-per-file kernels for their files and by
                                   // the general emit kernel for the others (what the histogram kernel counts); null when neither is wanted
     int fast_ran;                 // the wave-per-file kernels ran over the range
+    int wave_files_written;       // ... and the fused back half has written their captions and counted them: only the histogram is left to do for them
     const uint32_t* item_list;    // the files of the general kernel, relative to file0 (null: all files of the range)
     uint64_t n_items;             // how many of them
     const uint32_t* slot_of;
@@ -133,6 +144,11 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s);
 // The strings noted in DevTables::unk_keys / unk_ent / unk_text, as records of 40 bytes {32 bytes of text, length, 0} in `out` (at most
 // out_cap of them; *out_count receives how many there were); the set is emptied.
 hipError_t launch_collect_unknown(unsigned long long* keys, const unsigned long long* ent, const uint8_t* text, uint32_t slots, uint8_t* out, uint32_t out_cap, uint32_t* out_count, hipStream_t s);
+// The fused back half over [file0, file_end): a.tables, the lean front half's outputs and the fields above must be set.
+hipError_t launch_lean_bx(const DevTables& t, const FastArgs& a, hipStream_t s);
+uint64_t lean_bx_tiles(uint64_t n_files);                      // words of FastArgs::tile_state a range of n_files files needs
+// dst[k] += src[k] for the eight batch counters (both device memory)
+hipError_t launch_add_counters(tp_counters* dst, const tp_counters* src, hipStream_t s);
 uint32_t fast_fin_stride();
 bool lean_ok(const DevTables& t);   // the lean stage (tp_lean.h) can serve this configuration
 

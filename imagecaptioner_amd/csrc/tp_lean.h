@@ -578,6 +578,9 @@ TP_HD_FLAT bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared&
     const bool act = (fb & 1u) != 0;
     const uint64_t m_act = w.ballot(act);
     n_cand = popc64(m_act);
+    // fewer than three selected tags mean the minimal fallback line (Program.cs:297-298): every candidate AddOne accepts ends up
+    // selected (the last sweep takes what the buckets left, Program.cs:677-680), so their number says it here already
+    if (t.n_prefix + popc64(w.ballot(act && !(f & FL_BLANK) && (f & FL_VALID) && !(f & FL_DROP) && !(f & FL_PREFIX))) < 3u) return LEAN_NO(7);
     if (act) row[w.rank(m_act)] = id;
     w.tick(19);
     return true;
@@ -596,7 +599,8 @@ TP_HD_FLAT bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared&
 struct LeanAudit { uint32_t* row; uint32_t* cnt; uint32_t* len; uint32_t* rbits; };
 // DETAIL false (the plain run's build of the kernel): aud is taken as null whatever is passed, and with fired a file with a
 // seed whose closure has more than two members is declined (the evidence set is counted, not listed).
-template <bool DETAIL = true, class W, class TT, class RF>
+// FIX: files whose action tags NormalizeTag changes are taken (lean_caption_fix); without it they are declined.
+template <bool DETAIL = true, bool FIX = DETAIL, class W, class TT, class RF>
 TP_HD_FLAT bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, const uint32_t* rc, uint32_t id, uint32_t n_cand, FastOut& out, uint32_t* fin32,
                      uint32_t* fired_or_null, uint16_t* facet_choice_or_null, RF&& records_free, const LeanAudit aud_or_null = LeanAudit{nullptr, nullptr, nullptr, nullptr}) {
     uint32_t* const fired = fired_or_null;
@@ -765,7 +769,7 @@ TP_HD_FLAT bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, co
         frules_possible = t.frules_vacuous || w.ballot(lit_f) != 0;
         const bool rules_possible = w.ballot(lit_r) != 0;           // the evidence holds a literal some action rule tests positively: look closer
         if (rules_possible) {
-            n_act = lean_actions<DETAIL>(w, t, L, rc, fired, chg);
+            n_act = lean_actions<FIX>(w, t, L, rc, fired, chg);
             if (n_act == LEAN_DEAD) return LEAN_NO(11);
         } else if (fired && lane < t.fired_words) fired[lane] = 0;
     }
@@ -970,7 +974,7 @@ TP_HD_FLAT bool lean_back(W& w, const TT& t, LeanLds& L, const LeanShared& S, co
     v.n_unknown = (uint16_t)unknown;
     v.n_dropped = (uint16_t)n_dropped;
     uint32_t n_cap = nf, cap_bytes = bytes;                         // the caption's list is the final list, unless NormalizeTag changes one of its tags
-    if constexpr (DETAIL) {
+    if constexpr (FIX) {
         if (chg != 0) {
             const LeanCap c = lean_caption_fix(w, t, L, fin32, fb, nr + grown1 + grown2, n_act, chg, nf, aud.row);
             if (c.n == LEAN_DEAD) return LEAN_NO(16);

@@ -245,7 +245,8 @@ class TagPipe:
         t = tp_timing()
         self._check(self._L.tp_get_last_timing(self._h, C.byref(t)))
         return {"total_ms": t.total_ms, "select_ms": t.select_ms, "general_ms": t.general_ms, "emit_ms": t.emit_ms, "other_ms": t.other_ms,
-                "general_files": int(t.general_files), "lean_front_ms": t.lean_front_ms, "lean_back_ms": t.lean_back_ms}
+                "general_files": int(t.general_files), "lean_front_ms": t.lean_front_ms, "lean_back_ms": t.lean_back_ms,
+                "fused_ms": t.fused_ms, "fused_reruns": int(t.fused_reruns)}
 
     # ---- host-buffer runs -----------------------------------------------------------------------
     def audit_header(self):

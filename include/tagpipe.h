@@ -374,6 +374,9 @@ typedef struct tp_timing {
     uint64_t general_files; /* how many files took the thread-per-file kernel */
     float lean_front_ms; /* part of select_ms: k_lean_a (scan of the line, table lookup of every tag, Distinct) */
     float lean_back_ms;  /* part of select_ms: k_lean_b (selection, implied tags, rules, facets, the final tag ids) */
+    float fused_ms;      /* k_lean_bx, the plain run's fused kernel: k_lean_b's work, the caption offsets and the caption bytes of the
+                            wave-per-file kernels' files (not part of select_ms or emit_ms; lean_back_ms is 0 then) */
+    uint64_t fused_reruns; /* ranges (since tp_create) that k_lean_bx handed back to the separate kernels */
 } tp_timing;
 /*
  * firedRules of every file as AppendAudit joins them (Program.cs:334, 966:

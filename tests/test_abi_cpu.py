@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_abi.tp_verdict) == 16
     assert C.sizeof(_abi.tp_counters) == 64
     assert C.sizeof(_abi.tp_source) == 24
-    assert C.sizeof(_abi.tp_timing) == 40
+    assert C.sizeof(_abi.tp_timing) == 56
     assert C.sizeof(_abi.tp_device_io) == 12 * 8
     # compile a probe with the real header and compare sizes / a few offsets
     import subprocess, tempfile, textwrap
@@ -40,8 +40,8 @@ def test_struct_layouts_match_header():
         #include <stddef.h>
         #include "tagpipe.h"
         int main(void) {
-            printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(tp_config), sizeof(tp_result), sizeof(tp_table_info), offsetof(tp_config, trigger),
-                   offsetof(tp_config, line_weight), offsetof(tp_result, histogram), offsetof(tp_result, opaque));
+            printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(tp_config), sizeof(tp_result), sizeof(tp_table_info), offsetof(tp_config, trigger),
+                   offsetof(tp_config, line_weight), offsetof(tp_result, histogram), offsetof(tp_result, opaque), sizeof(tp_timing), offsetof(tp_timing, fused_reruns));
             return 0;
         }""")
     with tempfile.TemporaryDirectory() as d:
@@ -49,7 +49,8 @@ def test_struct_layouts_match_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "p"), os.path.join(d, "p.c")])
         out = subprocess.check_output([os.path.join(d, "p")]).decode().split()
     got = [C.sizeof(_abi.tp_config), C.sizeof(_abi.tp_result), C.sizeof(_abi.tp_table_info), _abi.tp_config.trigger.offset,
-           _abi.tp_config.line_weight.offset, _abi.tp_result.histogram.offset, _abi.tp_result.opaque.offset]
+           _abi.tp_config.line_weight.offset, _abi.tp_result.histogram.offset, _abi.tp_result.opaque.offset, C.sizeof(_abi.tp_timing),
+           _abi.tp_timing.fused_reruns.offset]
     assert [int(x) for x in out] == got
 
 
