@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -729,6 +730,57 @@ void compute_fallback(tp_ctx* c) {
 
 }  // namespace
 
+namespace {
+// Rows of a log file for files [0, n): row_for(i, row) appends file i's row (without the newline; nothing for a file that has
+// none) and returns false on an error it has reported with fail().  The files are cut into contiguous chunks, one per host
+// thread; every thread puts its chunk's rows together, then the chunks are copied to their places in `out`, again in parallel.
+// Conventions of the tp_format_* calls: out_offsets has n + 1 entries, *needed receives the size, TP_E_CAPACITY when it
+// does not fit (nothing is written then).
+template <class RowFor>
+int format_rows_parallel(uint64_t n, const std::string& nl, RowFor&& row_for, uint8_t* out, uint64_t capacity, uint64_t* out_offsets, uint64_t* needed) {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("TAGPIPE_FORMAT_THREADS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 256) hw = (unsigned)v; }
+    const uint64_t want = n / 2048 + 1;
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1, 32), want));
+    std::vector<std::string> text(T);
+    std::vector<int> ok(T, 1);
+    std::vector<std::string> err(T);
+    auto lo_of = [&](unsigned k) { return n * k / T; };
+    auto work = [&](unsigned k) {
+        std::string row;
+        std::string& rows = text[k];
+        for (uint64_t i = lo_of(k); i < lo_of(k + 1); ++i) {
+            out_offsets[i] = rows.size();                          // relative to the chunk for now
+            row.clear();
+            if (!row_for(i, row)) { ok[k] = 0; err[k] = g_error; return; }
+            if (!row.empty()) { rows += row; rows += nl; }
+        }
+    };
+    auto run_all = [&](auto&& fn) {
+        if (T == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < T; ++k) th.emplace_back([&fn, k]() { fn(k); });
+        fn(0u);
+        for (auto& x : th) x.join();
+    };
+    run_all(work);
+    for (unsigned k = 0; k < T; ++k) if (!ok[k]) return fail(TP_E_INVALID_ARG, err[k]);
+    std::vector<uint64_t> base(T + 1, 0);
+    for (unsigned k = 0; k < T; ++k) base[k + 1] = base[k] + text[k].size();
+    const uint64_t total = base[T];
+    const bool fits = total == 0 || (out && capacity >= total);
+    run_all([&](unsigned k) {
+        for (uint64_t i = lo_of(k); i < lo_of(k + 1); ++i) out_offsets[i] += base[k];
+        if (fits && !text[k].empty()) std::memcpy(out + base[k], text[k].data(), text[k].size());
+    });
+    out_offsets[n] = total;
+    *needed = total;
+    if (!fits) return fail(TP_E_CAPACITY, "output buffer too small");
+    return TP_OK;
+}
+}  // namespace
+
+
 extern "C" {
 
 const char* tp_last_error(void) { return g_error.c_str(); }
@@ -1266,25 +1318,22 @@ int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t*
     const uint32_t n_rules = ctx->dt.n_rules, n_facets = ctx->dt.n_facets, fw = ctx->dt.fired_words;
     const std::string nl((const char*)ctx->dt.newline, ctx->dt.newline_len);
     return guarded([&]() {
-        std::string rows, row, field;
-        auto csv = [&](const char* p, size_t n) {                // Csv(), Program.cs:976-981: quotes doubled, always quoted
-            row.push_back('"');
-            for (size_t k = 0; k < n; ++k) { if (p[k] == '"') row.push_back('"'); row.push_back(p[k]); }
-            row.push_back('"');
-        };
-        auto csv_s = [&](const std::string& x) { csv(x.data(), x.size()); };
         static const char* const kCats[6] = {"identity", "hair", "eyes", "outfit", "pose_action", "background_scene"};   // Program.cs:1067-1074
-        for (uint64_t i = 0; i < n_files; ++i) {
-            out_offsets[i] = rows.size();
+        auto row_for = [&](uint64_t i, std::string& row) -> bool {
+            auto csv = [&](const char* p, size_t n) {            // Csv(), Program.cs:976-981: quotes doubled, always quoted
+                row.push_back('"');
+                for (size_t k = 0; k < n; ++k) { if (p[k] == '"') row.push_back('"'); row.push_back(p[k]); }
+                row.push_back('"');
+            };
+            auto csv_s = [&](const std::string& x) { csv(x.data(), x.size()); };
+            std::string field;
             const tp_verdict& v = res->verdicts[i];
-            if (v.flags & TP_F_UNSUPPORTED) continue;             // the device code did not process the file: no row
-            row.clear();
+            if (v.flags & TP_F_UNSUPPORTED) return true;          // the device code did not process the file: no row
             csv((const char*)names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i]));
             const uint64_t* ao = r->audit_offsets.data() + i * AUDIT_COLS;
             row.push_back(','); csv((const char*)r->audit_text.data() + ao[AUDIT_KEPT], (size_t)(ao[AUDIT_KEPT + 1] - ao[AUDIT_KEPT]));
             row.push_back(','); csv((const char*)r->audit_text.data() + ao[AUDIT_EVIDENCE], (size_t)(ao[AUDIT_EVIDENCE + 1] - ao[AUDIT_EVIDENCE]));
             // firedRules, Program.cs:741, 748, 764, 772
-            field.clear();
             auto put = [&](const std::string& x) { if (!field.empty()) field.push_back(';'); field += x; };
             const uint32_t* fb = r->fired.data() + i * fw;
             auto bit = [&](uint32_t b) { return (fb[b >> 5] >> (b & 31)) & 1u; };
@@ -1304,7 +1353,7 @@ int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t*
             row.push_back(','); csv((const char*)r->audit_text.data() + ao[AUDIT_DROPPED], (size_t)(ao[AUDIT_DROPPED + 1] - ao[AUDIT_DROPPED]));
             field.clear();                                        // rejectReason ?? "", Program.cs:329, 944
             if (v.flags & TP_F_SAFE_REJECT) {
-                if (v.safe_hit < 0 || (size_t)v.safe_hit >= h.safe_tags.size()) return fail(TP_E_INVALID_ARG, "verdict with a safe-mode hit out of range");
+                if (v.safe_hit < 0 || (size_t)v.safe_hit >= h.safe_tags.size()) { fail(TP_E_INVALID_ARG, "verdict with a safe-mode hit out of range"); return false; }
                 field = "safe_mode:" + h.safe_tags[v.safe_hit];
             }
             row.push_back(','); csv_s(field);
@@ -1324,15 +1373,9 @@ int tp_format_audit_rows(const tp_ctx* ctx, const tp_result* res, const uint8_t*
             }
             row.push_back(','); csv_s(missing.empty() ? std::string("coverage_satisfied") : std::string("openai_disabled_or_missing_api_key"));
             row.push_back(','); csv_s("pass0_joy missing=" + missing + " required_missing=" + required + " details=" + details + " tags=" + std::to_string(v.n_selected));
-            rows += row;
-            rows += nl;
-        }
-        out_offsets[n_files] = rows.size();
-        *needed = rows.size();
-        if (rows.empty()) return (int)TP_OK;
-        if (!out || capacity < rows.size()) return fail(TP_E_CAPACITY, "output buffer too small");
-        std::memcpy(out, rows.data(), rows.size());
-        return (int)TP_OK;
+            return true;
+        };
+        return format_rows_parallel(n_files, nl, row_for, out, capacity, out_offsets, needed);
     });
 }
 
@@ -1407,14 +1450,12 @@ int tp_format_review_rows(const tp_ctx* ctx, const tp_result* res, int format, c
     const HostTables& h = ctx->ht;
     const std::string nl((const char*)ctx->dt.newline, ctx->dt.newline_len);
     return guarded([&]() {
-        std::string rows, row;
         static const char* const kCats[6] = {"identity", "hair", "eyes", "outfit", "pose_action", "background_scene"};
         auto join = [](const std::vector<std::string>& v) { std::string o; for (size_t k = 0; k < v.size(); ++k) { if (k) o += ';'; o += v[k]; } return o; };
-        auto csv = [&](const std::string& x) { row += '"'; for (char ch : x) { if (ch == '"') row += '"'; row += ch; } row += '"'; };   // Program.cs:976-981
-        for (uint64_t i = 0; i < n_files; ++i) {
-            out_offsets[i] = rows.size();
+        auto row_for = [&](uint64_t i, std::string& row) -> bool {
+            auto csv = [&](const std::string& x) { row += '"'; for (char ch : x) { if (ch == '"') row += '"'; row += ch; } row += '"'; };   // Program.cs:976-981
             const tp_verdict& v = res->verdicts[i];
-            if (v.flags & TP_F_UNSUPPORTED) continue;
+            if (v.flags & TP_F_UNSUPPORTED) return true;
             const uint32_t rb = r->review_bits[i];
             // BuildReviewRecord, Program.cs:826-868
             std::vector<std::string> banned, reasons;
@@ -1442,13 +1483,12 @@ int tp_format_review_rows(const tp_ctx* ctx, const tp_result* res, int format, c
             }
             const std::string stop = missing.empty() ? "coverage_satisfied" : "openai_disabled_or_missing_api_key";
             const bool has_coverage_log = !missing.empty();                                  // Program.cs:844 with a one-entry trace
-            if (reasons.empty() && banned.empty() && unknown.empty() && !has_coverage_log) continue;   // Program.cs:845: no record
+            if (reasons.empty() && banned.empty() && unknown.empty() && !has_coverage_log) return true;   // Program.cs:845: no record
             const std::vector<std::string> trace = {"pass0_joy missing=" + missing + " required_missing=" + required + " details=" + details + " tags=" +
                                                     std::to_string(v.n_selected)};
             const std::string image((const char*)image_paths + image_offsets[i], (size_t)(image_offsets[i + 1] - image_offsets[i]));
             const std::string caption((const char*)caption_paths + caption_offsets[i], (size_t)(caption_offsets[i + 1] - caption_offsets[i]));
             const std::string vocab = vocab_file ? vocab_file : "";
-            row.clear();
             if (format == TP_REVIEW_JSONL) {                                                 // JsonSerializer.Serialize(record), Program.cs:874, 415-431
                 row += "{\"ImagePath\":"; json_string(image, row);
                 row += ",\"CaptionPath\":"; json_string(caption, row);
@@ -1472,15 +1512,9 @@ int tp_format_review_rows(const tp_ctx* ctx, const tp_result* res, int format, c
                 csv(join(unknown)); row += ','; csv(h.known_found ? "true" : "false"); row += ','; csv(std::to_string(h.n_known)); row += ','; csv(vocab); row += ',';
                 csv(stop); row += ','; csv(join(trace));
             }
-            rows += row;
-            rows += nl;
-        }
-        out_offsets[n_files] = rows.size();
-        *needed = rows.size();
-        if (rows.empty()) return (int)TP_OK;
-        if (!out || capacity < rows.size()) return fail(TP_E_CAPACITY, "output buffer too small");
-        std::memcpy(out, rows.data(), rows.size());
-        return (int)TP_OK;
+            return true;
+        };
+        return format_rows_parallel(n_files, nl, row_for, out, capacity, out_offsets, needed);
     });
 }
 
