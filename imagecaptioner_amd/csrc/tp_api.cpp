@@ -278,11 +278,22 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
             c->aud32.need(n * AUD_STRIDE * 4); c->audit_cnt.need(n * AUDIT_COLS * 4); c->audit_len.need(n * AUDIT_COLS * 4);
             fa.aud32 = c->aud32.as<uint32_t>(); fa.audit_cnt = c->audit_cnt.as<uint32_t>(); fa.audit_len = c->audit_len.as<uint32_t>(); fa.review_bits = io.review_bits + f0;
             fa.item_list = nullptr; fa.item_count = nullptr;
-            fa.stage = 0; fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.tables = c->dt_dev.as<DevTables>();
+            c->w->slow_list0.need(n * 4);
+            uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
+            HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
+            fa.stage = 0; fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
             hipEvent_t pm = next_event(), pe = next_event();
             HIP_OK(launch_fast(c->dt, fa, s, pm));
             record(pe);
             if (st.timed) st.lean_ev.push_back({p0, pm, pe});
+            // what the lean stage declines: the general wave stages in audit mode (one token per lane, then two); the long-file
+            // stage keeps no lists, so what the second declines is the general kernel's
+            fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+            fa.stage = 1; fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
+            HIP_OK(launch_fast(c->dt, fa, s));
+            fa.stage = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
+            fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
+            HIP_OK(launch_fast(c->dt, fa, s));
         } else {
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
         // through the long-file stage, and what is left to the general kernel.  Later stages learn their item counts on the device.

@@ -393,8 +393,10 @@ struct DevTables {
     const uint32_t* step_off;    // n_strings + 1: what one ExpandImpliedTags visit of the string appends, in order:
     const uint32_t* step_ids;    //   NormalizeTag(it), then the implied tags of that (Program.cs:1164-1175); empty when nothing can change
     const uint32_t* reach_off;   // n_strings + 1: every other string the closure of {it} holds, as pairs
-    const uint32_t* reach_ent;   //   {id, literal index (24 bits, 0xFFFFFF = none) | FL_NFEET-ness << 24 | FL_NPENIS-ness << 25}
+    const uint32_t* reach_ent;   //   {id, literal index (24 bits, 0xFFFFFF = none) | FL_NFEET-ness << 24 | FL_NPENIS-ness << 25 | round << 26}, in the order
+                                 //   ExpandImpliedTags appends them to {it} (round = the loop round that does, from 1)
     uint32_t closure_tables;     // 0 when the reach table would be too large: files that need a closure take the general kernel
+    uint32_t reach_levels_ok;    // every reach entry's round fits the six bits its info word has for it
     uint32_t fast_ok;            // the configuration fits the wave-per-file kernel at all
     uint32_t n_prefix; uint32_t prefix_ids[MAX_TOTAL_TAGS];      // result list after the AddOne calls of Program.cs:664-668
     uint32_t n_fb_final; uint32_t fb_final[MAX_FALLBACK];        // normalizedFinalSet of the fallback selection (Program.cs:298, 303)

@@ -81,6 +81,11 @@ struct FastOut {
     uint32_t n_final;
     uint32_t caption_len;
 };
+// Audit mode: where a wave stage leaves a file's other lists as interned ids (row: AUD_STRIDE words laid out by the AUD_*
+// constants of tp_common.h - the evidence set in insertion order, the dropped candidates with their reason, the first TOP_TAGS
+// candidates, the final list when the caption's list differs from it), their entry counts and text lengths per column (cnt,
+// len: AUDIT_COLS entries each) and the review record's bits; what the general kernel reports in the same arrays for its files.
+struct LeanAudit { uint32_t* row; uint32_t* cnt; uint32_t* len; uint32_t* rbits; };
 
 TP_HD uint32_t popc64(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -654,9 +659,9 @@ struct TailIn {
     bool settled, rejected;
     uint32_t (*kid)[64];
 };
-template <int NF, class W, class Ev>
+template <int NF, bool AUD = false, class W, class Ev>
 TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, BackLds& L, const uint32_t* rc, const TailIn& in_, Ev& evidence, FastOut& out, uint32_t* fin32,
-                                                   uint32_t* fired, uint16_t* facet_choice) {
+                                                   uint32_t* fired, uint16_t* facet_choice, const LeanAudit aud = LeanAudit{nullptr, nullptr, nullptr, nullptr}) {
     constexpr uint32_t FIN_MAX = 64u * NF;
     const uint32_t lane = w.lane();
     const uint32_t nr = in_.nr, n = in_.n, n_selected = in_.n_selected, n_dropped = in_.n_dropped;
@@ -958,7 +963,7 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
     w.tick(10);
     TP_STOP(10, own0 ^ own1 ^ nf)
     // ---- S12: verdicts on the final list (Program.cs:319, 329), GetUnknownTags (:817-824), FormatCaptionSingleLine (:971-974) ---
-    uint32_t c[2] = {EMPTY_ID, EMPTY_ID}, clen[2] = {0, 0};
+    uint32_t c[2] = {EMPTY_ID, EMPTY_ID}, clen[2] = {0, 0}, idlen[2] = {0, 0};
     bool cnb[2] = {false, false}, cknown[2] = {false, false};
     bool face = false, outfit = false, changed = false;
     uint32_t safe_idx[2] = {0, 0};
@@ -972,9 +977,11 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
             fl = cfl = in ? L.fattr[idx] : (uint32_t)FL_BLANK;
             c[blk] = in ? id : EMPTY_ID;
             clen[blk] = in ? L.flen[idx] : 0;
+            idlen[blk] = clen[blk];
         } else {
             Rec rr = t.rec[in ? id : EMPTY_ID];
             fl = rr.flags;
+            idlen[blk] = in ? rr.len : 0;
             c[blk] = rr.next;
             Rec rn = rr;
             if (in && c[blk] != id) { rn = t.rec[c[blk]]; changed = true; }
@@ -1016,6 +1023,22 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
     if (keepc[0]) fin32[w.rank(mc0)] = c[0];
     if (keepc[1]) fin32[popc64(mc0) + w.rank(mc1)] = c[1];
     if (ev_feet && ev_penis) { flags |= TP_F_ELIGIBLE; if (footjob) flags |= TP_F_FOOTJOB; }
+    if constexpr (AUD) {
+        // keptTags = the final list as it stands (Program.cs:334); the caption's list (fin32) differs from it when NormalizeTag changes
+        // a tag or makes one blank (Program.cs:972); GetUnknownTags walks the caption's list (Program.cs:817-821)
+        const bool differs = w.ballot(changed) != 0;
+        const uint32_t kbytes = w.sum(idlen[0] + idlen[1]);
+        const uint32_t ubytes = t.known_active ? w.sum((keepc[0] && !cknown[0] ? clen[0] : 0u) + (keepc[1] && !cknown[1] ? clen[1] : 0u)) : 0u;
+        if (differs) {
+            if (lane < nf) aud.row[AUD_KEPT + lane] = own0;
+            if (lane + 64 < nf) aud.row[AUD_KEPT + lane + 64] = own1;
+        }
+        if (lane == 0) {
+            aud.row[AUD_FLAGS] = differs ? 1u : 0u;
+            aud.cnt[AUDIT_KEPT] = nf; aud.len[AUDIT_KEPT] = kbytes + (nf ? nf - 1 : 0u);
+            aud.cnt[AUDIT_UNKNOWN] = nc; aud.len[AUDIT_UNKNOWN] = ubytes + (unknown ? unknown - 1 : 0u);
+        }
+    }
 
     w.tick(11);
     tp_verdict& v = out.verdict;
@@ -1042,9 +1065,10 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
 // scored candidates on the lanes in the order SelectTags sorts them into (ScoredFront below); text / len / cls / triage
 // are not used then.
 struct LineFront { static constexpr bool scored = false; };
-template <int NT, int NF, class W, class Front = LineFront>
+template <int NT, int NF, class W, class Front = LineFront, bool AUD = false>
 TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice, bool triage = false, Front* front = nullptr) {
+                     uint32_t* fired, uint16_t* facet_choice, bool triage = false, Front* front = nullptr, const LeanAudit aud = LeanAudit{nullptr, nullptr, nullptr, nullptr}) {
+    static_assert(!(AUD && Front::scored), "the audit lists are kept for tag lines only");
     static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
     const uint32_t lane = w.lane();
     int nblk = 1;
@@ -1162,6 +1186,34 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     }
 
     if constexpr (Front::scored) n_dropped += front->extra_dropped;
+    if constexpr (AUD) {
+        // DroppedTagsWithReason in candidate order (Program.cs:630-631, 682), the first TOP_TAGS raw candidates (Program.cs:860), and
+        // what BuildReviewRecord finds among the normalised raw candidates (Program.cs:827-837)
+        if (n_dropped > AUD_TOP - AUD_DROPPED) return false;        // no room in the row
+        const uint64_t mb0 = w.ballot(first2[0] && bad2[0]), mb1 = nblk > 1 ? w.ballot(first2[1] && bad2[1]) : 0;
+        uint32_t dbytes = 0, tbytes = 0, rb = 0;
+        bool banned = false;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+            if (first2[blk] && bad2[blk]) {
+                const uint32_t pos = blk ? popc64(mb0) + w.rank(mb1) : w.rank(mb0);
+                aud.row[AUD_DROPPED + pos] = t2[blk] | ((r2[blk].flags & FL_VALID) ? 0x80000000u : 0u);
+                dbytes += r2[blk].len + AUDIT_REASON_LEN;
+            }
+            if (act[blk] && ci[blk] < (uint32_t)TOP_TAGS) { aud.row[AUD_TOP + ci[blk]] = h1[blk]; tbytes += r1[blk].len; }
+            if (nonblank2[blk]) { rb |= (r2[blk].flags & (FL_SUBJ_MALE | FL_SUBJ_GIRL | FL_SUBJ_MULTI)) >> 10; banned = banned || (r2[blk].flags & FL_BANNED) != 0; }
+        }
+        uint32_t rbits = w.or_all(rb);
+        if (w.ballot(banned) != 0)
+            for (int k = 0; k < N_BANNED; ++k)
+                if (w.ballot((nonblank2[0] && t2[0] == t.banned_ids[k]) || (nonblank2[1] && t2[1] == t.banned_ids[k])) != 0) rbits |= 1u << k;
+        dbytes = w.sum(dbytes); tbytes = w.sum(tbytes);
+        const uint32_t ntop = n < (uint32_t)TOP_TAGS ? n : (uint32_t)TOP_TAGS;
+        if (lane == 0) {
+            aud.cnt[AUDIT_DROPPED] = n_dropped; aud.len[AUDIT_DROPPED] = dbytes + (n_dropped ? n_dropped - 1 : 0u);
+            aud.cnt[AUDIT_TOP] = ntop; aud.len[AUDIT_TOP] = tbytes + (ntop ? ntop - 1 : 0u);
+            *aud.rbits = rbits;
+        }
+    }
     w.tick(4);
     TP_STOP(4, t2[0] ^ t2[1] ^ r2[0].flags ^ r2[1].flags ^ r2[0].next ^ (uint32_t)uniq[0] ^ (uint32_t)uniq[1] ^ (uint32_t)ev_seed[0] ^ (uint32_t)ev_seed[1] ^ (uint32_t)style_cap ^ n_dropped)
     // ---- S6: SelectTags second half (Program.cs:661-699) -----------------------------------------------------------------
@@ -1267,6 +1319,93 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         uint64_t m_far = 0;                                        // seeds whose closure reaches beyond their own two steps
         TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) m_far |= w.ballot(ev_seed[blk] && (r2[blk].flags & FL_EDGE) && !(r2[blk].flags & FL_REACH2));
         const bool count = fired != nullptr;                       // the size of the evidence set is a detail output: it takes the set to count
+        if constexpr (AUD) {
+            // The evidence set as a list in the reference's insertion order (BuildEvidenceTags, then ExpandImpliedTags' rounds:
+            // Program.cs:721-729, 1160-1179): the seeds in candidate order; then, round by round, what the round appends - for
+            // every member the round before appended, in their order, what a visit of it appends.  Every seed brings the list of
+            // its own closure in that order with the round of each entry (DevTables::reach_ent, or its record's two steps); a
+            // round's additions over all seeds are ordered by seed, then by place in the seed's list; a string counts where it
+            // comes first.  So every entry goes into the set under the key (round, seed, place), the lowest key of a string
+            // wins, and a winner's position is the number of winners with lower keys.
+            constexpr uint32_t EV_CAP = AUD_DROPPED - AUD_EVIDENCE;
+            if (m_far && (!t.closure_tables || !t.reach_levels_ok)) return false;
+            set_clear(w, L);
+            const uint64_t ms0 = w.ballot(ev_seed[0]), ms1 = nblk > 1 ? w.ballot(ev_seed[1]) : 0;
+            uint32_t total = popc64(ms0) + popc64(ms1);
+            if (total > EV_CAP) return false;
+            uint32_t ebytes = 0;
+            bool full = false;
+            uint32_t ne[2] = {0, 0}, e0[2] = {0, 0};                // entries of the seed's list, and where the list starts
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                if (ev_seed[blk]) {
+                    bool created;
+                    const uint32_t pos = blk ? popc64(ms0) + w.rank(ms1) : w.rank(ms0);
+                    if (set_put(w, L, t2[blk], pos, created) == NO_ID) full = true;
+                    aud.row[AUD_EVIDENCE + pos] = t2[blk];
+                    ebytes += r2[blk].len;
+                    if (r2[blk].flags & FL_EDGE) {
+                        if (r2[blk].flags & FL_REACH2) ne[blk] = r2[blk].step_cnt;
+                        else { e0[blk] = t.reach_off[t2[blk]]; ne[blk] = t.reach_off[t2[blk] + 1] - e0[blk]; }
+                        if (ne[blk] > 0xFFFFu) full = true;
+                    }
+                }
+            }
+            w.sync();
+            auto entry = [&](int blk, uint32_t k, uint32_t& id, uint32_t& info) {
+                if (r2[blk].flags & FL_REACH2) { id = k ? r2[blk].step1 : r2[blk].step0; info = ((k ? r2[blk].s1_info : r2[blk].s0_info) & 0x3FFFFFFu) | 1u << 26; }
+                else { id = t.reach_ent[2 * (size_t)(e0[blk] + k)]; info = t.reach_ent[2 * (size_t)(e0[blk] + k) + 1]; }
+            };
+            auto key_of = [&](int blk, uint32_t k, uint32_t info) { return (info >> 26) << 24 | ci[blk] << 16 | k; };
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                for (uint32_t k = 0; k < ne[blk] && !full; ++k) {
+                    uint32_t id, info;
+                    entry(blk, k, id, info);
+                    bool created;
+                    if (set_put(w, L, id, key_of(blk, k, info), created) == NO_ID) full = true;
+                    const uint32_t li = info & 0xFFFFFFu;
+                    if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                    ev_feet |= (info >> 24) & 1u;
+                    ev_penis |= (info >> 25) & 1u;
+                }
+            }
+            if (w.ballot(full)) return false;
+            w.sync();
+            uint32_t cur[2] = {0, 0};
+            for (uint32_t lev = 1; lev < 64; ++lev) {
+                if (!w.ballot(cur[0] < ne[0] || cur[1] < ne[1])) break;
+                uint32_t wins[2] = {0, 0};
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                    for (uint32_t k = cur[blk]; k < ne[blk]; ++k) {
+                        uint32_t id, info;
+                        entry(blk, k, id, info);
+                        if ((info >> 26) != lev) break;
+                        const uint32_t slot = set_find(L, id);
+                        wins[blk] += (uint32_t)(slot != NO_ID && L.set_min[slot] == key_of(blk, k, info));
+                    }
+                }
+                const uint32_t incl0 = w.scan_incl(wins[0]), tot0 = w.bcast(incl0, 63);
+                uint32_t incl1 = 0, tot1 = 0;
+                if (nblk > 1) { incl1 = w.scan_incl(wins[1]); tot1 = w.bcast(incl1, 63); }
+                if (total + tot0 + tot1 > EV_CAP) return false;
+                uint32_t at[2] = {total + incl0 - wins[0], total + tot0 + incl1 - wins[1]};
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                    uint32_t k = cur[blk];
+                    for (; k < ne[blk]; ++k) {
+                        uint32_t id, info;
+                        entry(blk, k, id, info);
+                        if ((info >> 26) != lev) break;
+                        const uint32_t slot = set_find(L, id);
+                        if (slot != NO_ID && L.set_min[slot] == key_of(blk, k, info)) { aud.row[AUD_EVIDENCE + at[blk]++] = id; ebytes += t.attr2[2 * (size_t)id + 1]; }
+                    }
+                    cur[blk] = k;
+                }
+                total += tot0 + tot1;
+            }
+            if (w.ballot(cur[0] < ne[0] || cur[1] < ne[1])) return false;
+            n_evidence = total;
+            ebytes = w.sum(ebytes);
+            if (lane == 0) { aud.cnt[AUDIT_EVIDENCE] = total; aud.len[AUDIT_EVIDENCE] = ebytes + (total ? total - 1 : 0u); }
+        } else
         if (!m_edge) {
             n_evidence = popc64(w.ballot(ev_seed[0])) + (nblk > 1 ? popc64(w.ballot(ev_seed[1])) : 0);
         } else if (!count && !m_far) {
@@ -1319,7 +1458,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
             if (n_evidence > FAST_SET_SLOTS * 3 / 4) return false;
         }
         if constexpr (Front::scored) n_evidence += front->extra_evidence;
-        if (!count) n_evidence = 0xFFFF;
+        if (!count && !AUD) n_evidence = 0xFFFF;
         ev_feet = w.ballot(ev_feet) != 0;
         ev_penis = w.ballot(ev_penis) != 0;
         w.sync();
@@ -1331,7 +1470,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     ti.nr = nr; ti.n = n; ti.n_selected = n_selected; ti.n_dropped = n_dropped;
     if constexpr (Front::scored) ti.n = front->n_candidates;
     ti.settled = settled; ti.rejected = rejected; ti.kid = kid;
-    return fast_tail<NF>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice);
+    return fast_tail<NF, AUD>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice, aud);
 }
 
 // ================================================================================================================

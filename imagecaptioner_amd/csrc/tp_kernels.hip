@@ -138,7 +138,8 @@ __device__ inline void decline_push(DeclineBuf& b, uint32_t& n, uint32_t item, u
 // serves the files the first declined (a.item_list, a.item_count entries on the device) with 128 tokens.  Files both decline
 // go to a.slow_list for the general kernel.
 // TR: existing-caption triage (a compile-time choice, so that the caption kernels carry none of it).
-template <int NT, bool TR>
+// AUD: audit mode - the file's other lists go to its row of a.aud32 (LeanAudit in tp_fast.h), as the lean stage leaves them.
+template <int NT, bool TR, bool AUD = false>
 __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a) {
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
     __shared__ uint8_t cls[256];                                // byte classes of the line scan
@@ -161,8 +162,10 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
         bool done = false;
         FastOut out;
         if (len64 <= FAST_LINE_MAX) {
-            done = fast_file<NT, 2>(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
-                                 a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR);
+            LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
+            if (AUD) { const uint64_t r = f - a.file0; aud.row = a.aud32 + r * AUD_STRIDE; aud.cnt = a.audit_cnt + r * AUDIT_COLS; aud.len = a.audit_len + r * AUDIT_COLS; aud.rbits = a.review_bits + r; }
+            done = fast_file<NT, 2, DevWave, LineFront, AUD>(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
+                                                             a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR, nullptr, aud);
         }
         if (done) {
             if (w.lane() == 0) {
@@ -190,6 +193,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2(DevTables t, FastArgs a) { fast_body<2, false>(t, a); }
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast_triage(DevTables t, FastArgs a) { fast_body<1, true>(t, a); }
 __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2_triage(DevTables t, FastArgs a) { fast_body<2, true>(t, a); }
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast_audit(DevTables t, FastArgs a) { fast_body<1, false, true>(t, a); }
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_fast2_audit(DevTables t, FastArgs a) { fast_body<2, false, true>(t, a); }
 
 // The lean stage (tp_lean.h) over the whole range, as two kernels: the front half (line scan, token lookup, Distinct) leaves
 // each file's candidates - interned ids - in the file's row of the id array and marks the file SLOT_LEAN; the back half takes
@@ -1453,9 +1458,10 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
         if (a.fired || a.facet_choice || a.aud32) hipLaunchKernelGGL(k_lean_b_detail, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
         else hipLaunchKernelGGL(k_lean_b, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
     } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    else if (a.stage == 3 && a.aud32) return hipErrorInvalidValue;   // the long-file stage keeps no audit lists: the caller hands its files to the general kernel
     else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < (after_lean ? after_lean2 : 4096u) ? n : (after_lean ? after_lean2 : 4096u))), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
-    else if (a.stage == 2) hipLaunchKernelGGL(tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
-    else hipLaunchKernelGGL(tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    else if (a.stage == 2) hipLaunchKernelGGL(a.aud32 ? k_fast2_audit : tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    else hipLaunchKernelGGL(a.aud32 ? k_fast_audit : tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     return hipGetLastError();
 }
 uint64_t lean_bx_tiles(uint64_t n_files) { return (n_files + BX_TILE - 1) / BX_TILE; }

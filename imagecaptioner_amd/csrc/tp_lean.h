@@ -596,7 +596,6 @@ TP_HD_FLAT bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared&
 // candidates with their reason, the first TOP_TAGS candidates (AUD_* in tp_common.h) - with their entry counts, text
 // lengths and the review record's bits, as the general kernel reports them in audit mode (tp_pipeline.h); the kept tags
 // and the caption tags outside the vocabulary are read from fin32 by whoever writes the text.
-struct LeanAudit { uint32_t* row; uint32_t* cnt; uint32_t* len; uint32_t* rbits; };
 // DETAIL false (the plain run's build of the kernel): aud is taken as null whatever is passed, and with fired a file with a
 // seed whose closure has more than two members is declined (the evidence set is counted, not listed).
 // FIX: files whose action tags NormalizeTag changes are taken (lean_caption_fix); without it they are declined.

@@ -1057,24 +1057,30 @@ void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std
     out.reach_ent.clear();
     sc.closure_tables = 1;
     {
-        std::vector<uint32_t> seen(N, NO_ID), stack;
+        // Breadth first, in the order ExpandImpliedTags would grow the set {it}: round r appends, for every member that round r - 1
+        // appended (in their order), what one visit of it appends (Program.cs:1160-1179).  An entry's round sits in bits 26..31 of
+        // its info word, so that the lists of several seeds can be merged into the reference's insertion order.
+        std::vector<uint32_t> seen(N, NO_ID), queue, level;
+        sc.reach_levels_ok = 1;
         for (uint32_t i = 0; i < N && sc.closure_tables; ++i) {
             out.reach_off[i] = (uint32_t)(out.reach_ent.size() / 2);
             if (!(out.flags[i] & FL_EDGE)) continue;
-            stack.assign(1, i);
+            queue.assign(1, i);
+            level.assign(1, 0);
             seen[i] = i;
-            while (!stack.empty()) {
-                uint32_t x = stack.back();
-                stack.pop_back();
+            for (size_t q = 0; q < queue.size(); ++q) {
+                const uint32_t x = queue[q], lv = level[q] + 1;
                 if (!(out.flags[x] & FL_EDGE)) continue;
                 for (uint32_t m = out.step_off[x]; m < out.step_off[x + 1]; ++m) {
                     uint32_t y = out.step_ids[m];
                     if (seen[y] == i) continue;
                     seen[y] = i;
-                    stack.push_back(y);
+                    queue.push_back(y);
+                    level.push_back(lv);
+                    if (lv > 63) sc.reach_levels_ok = 0;
                     uint32_t li = out.lit[y] == NO_ID ? 0xFFFFFFu : out.lit[y];
                     out.reach_ent.push_back(y);
-                    out.reach_ent.push_back(li | ((out.flags[y] & FL_NFEET) ? 1u << 24 : 0) | ((out.flags[y] & FL_NPENIS) ? 1u << 25 : 0));
+                    out.reach_ent.push_back(li | ((out.flags[y] & FL_NFEET) ? 1u << 24 : 0) | ((out.flags[y] & FL_NPENIS) ? 1u << 25 : 0) | (std::min(lv, 63u) << 26));
                 }
             }
             if (out.reach_ent.size() > (size_t)(64u << 20)) sc.closure_tables = 0;

@@ -304,6 +304,28 @@ def test_audit_row_known_answer():
                                 b"coverage_stop_reason,coverage_trace")
 
 
+@pytest.mark.parametrize("name,n", [("c3c", 4000), ("c1", 4000), ("c4", 3000)])
+def test_audit_mode_stays_in_the_wave_stages(name, n):
+    """Audit mode beyond the lean stage: a file it declines (c3c: every file holds a tag that moves one alias hop per NormalizeTag
+    site; c1: spellings the lean stage does not take) gets its lists from the general wave stages, in the reference's insertion
+    order (evidence: seeds, then what each ExpandImpliedTags round appends), so hardly any file needs the thread-per-file kernel."""
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus(name, n, seed=515)
+    cfg = Config(**c.config_kwargs)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    audit = _review_args(n)
+    got, want = p.run_lines(c.arena, c.offsets, audit=audit), o.run_lines(c.arena, c.offsets, threads=16, detail=True, audit=audit)
+    general = p.last_timing()["general_files"]
+    print("%s in audit mode: %d of %d files in the general kernel" % (name, general, n))
+    assert general <= n // 100
+    _check_audit(got, want)
+    _check_review(got, want)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name + " audit")
+    if name == "c3c":
+        deep = sum(1 for i in range(n) if got.audit_lists[i][1].count(b";") > got.audit_lists[i][0].count(b";"))
+        assert deep > n // 4          # evidence lists longer than the final lists: closures of several rounds were listed
+
+
 @pytest.mark.parametrize("name", ["shipped", "novocab_w07_crlf", "c3", "c5"])
 def test_audit_rows_lines(name):
     if name in ("c3", "c5"):
