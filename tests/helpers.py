@@ -277,6 +277,33 @@ class HostSim:
         raw = text.tobytes()
         return [tuple(raw[int(offs3[5 * i + c]):int(offs3[5 * i + c + 1])] for c in range(5)) for i in range(n)], ver
 
+    def run_audit_wave(self, arena, offsets):
+        """The audit lists as the wave stages leave them (lean stage, then the general wave stage): (lists, verdicts, stage_of);
+        lists[i] = the five columns as bytes (';'-joined, the review record's two newline-separated); stage_of[i] = 0 for a file
+        none of them takes (its lists are then empty: the thread-per-file kernel's file)."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        offs5 = np.zeros(5 * n + 1, dtype=np.uint64)
+        ver = np.zeros(n, dtype=VERDICT_DTYPE)
+        self.review_bits = np.zeros(n, dtype=np.uint32)
+        stage_of = np.zeros(n, dtype=np.uint8)
+        cap = 1 << 20
+        fn = self._L.sim_run_audit_wave
+        fn.restype = C.c_longlong
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        while True:
+            text = np.zeros(cap, dtype=np.uint8)
+            rc = fn(self._h, arena.ctypes.data, offsets.ctypes.data, n, text.ctypes.data, cap, offs5.ctypes.data, ver.ctypes.data, self.review_bits.ctypes.data,
+                    stage_of.ctypes.data)
+            if rc == -1:
+                cap *= 4
+                continue
+            assert rc >= 0, "audit list sizes reported by a wave stage differ from the text of its ids: " + self._L.sim_last_error().decode()
+            break
+        raw = text.tobytes()
+        return [tuple(raw[int(offs5[5 * i + c]):int(offs5[5 * i + c + 1])] for c in range(5)) for i in range(n)], ver, stage_of
+
     def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
         arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
         tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)

@@ -509,6 +509,90 @@ long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, 
     return (long long)all.size();
 }
 
+// The wave stages in audit mode on an emulated wavefront: the lean stage (front half, then the back half's detail build), then
+// the general wave stage with one and with two tokens per lane.  Per file: which stage took it (0 none: the general kernel's
+// file, 1 lean, 2 / 3 the general wave stage), its verdict and review bits, and the five columns of list text put together from
+// the interned ids the stage left in the file's audit row - as k_emit_audit does for such a file.  offs5 has 5 n + 1 entries;
+// returns the text size, -1 when cap is too small, -2 when a column's length differs from what the stage reported.
+long long sim_run_audit_wave(void* h, const uint8_t* arena_in, const uint64_t* offsets, uint64_t n, uint8_t* text, uint64_t cap, uint64_t* offs5, tp_verdict* verdicts,
+                             uint32_t* review_bits, uint8_t* stage_of) {
+    g_err.clear();
+    const Sim& s = *(Sim*)h;
+    const DevTables& t = s.dt;
+    std::vector<uint8_t> padded((size_t)offsets[n] + 128, 0);
+    uint8_t* arena = padded.data() + 64;
+    std::memcpy(arena, arena_in, (size_t)offsets[n]);
+    std::vector<uint8_t> all;
+    std::vector<uint32_t> fired(std::max<size_t>(t.fired_words, 1));
+    std::vector<uint16_t> facets(std::max<size_t>(t.n_facets, 1));
+    emu::Shared sh;
+    offs5[0] = 0;
+    bool mismatch = false;
+    for (uint64_t f = 0; f < n; ++f) {
+        const uint8_t* line = arena + offsets[f];
+        const uint32_t len = (uint32_t)(offsets[f + 1] - offsets[f]);
+        std::vector<uint32_t> fin32(FAST_FIN_MAX, 0xDEADBEEF), row(AUD_STRIDE, 0xDEADBEEF);
+        uint32_t cnt[AUDIT_COLS] = {0}, alen[AUDIT_COLS] = {0}, rbits = 0;
+        const LeanAudit aud{row.data(), cnt, alen, &rbits};
+        bool done[64];
+        FastOut outs[64];
+        int stage = 0;
+        if (lean_tables_ok(t) && len <= LEAN_LINE_MAX) {
+            static LeanFrontLds flds;
+            static LeanLds llds;
+            static LeanShared lshared;
+            std::memset((void*)&flds, 0xCD, sizeof flds);
+            std::memset((void*)&llds, 0xCD, sizeof llds);
+            lean_shared_init(t, lshared, 0, 1);
+            std::vector<uint32_t> cand(64, 0xDEADBEEF);
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                uint32_t piece[4];
+                lean_fetch(w, line, len, piece);
+                done[lane] = lean_file(w, t, flds, llds, lshared, t.rc, line, len, piece, cand.data(), outs[lane], fin32.data(), fired.data(), t.n_facets ? facets.data() : nullptr, aud);
+            });
+            if (done[0]) stage = 1;
+        }
+        for (int nt = 1; nt <= 2 && !stage && t.fast_ok && len <= FAST_LINE_MAX; ++nt) {
+            static FastLds lds;
+            std::memset(&lds, 0xCD, sizeof lds);
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                done[lane] = nt == 1 ? fast_file<1, 2, emu::Wave, LineFront, true>(w, t, lds, t.rc, cls_table(), line, len, outs[lane], fin32.data(), fired.data(),
+                                                                                   t.n_facets ? facets.data() : nullptr, false, nullptr, aud)
+                                     : fast_file<2, 2, emu::Wave, LineFront, true>(w, t, lds, t.rc, cls_table(), line, len, outs[lane], fin32.data(), fired.data(),
+                                                                                   t.n_facets ? facets.data() : nullptr, false, nullptr, aud);
+            });
+            for (int l = 1; l < 64; ++l) if (done[l] != done[0]) g_err = "lanes disagree on the audit-mode verdict";
+            if (done[0]) stage = 1 + nt;
+        }
+        stage_of[f] = (uint8_t)stage;
+        verdicts[f] = stage ? outs[0].verdict : tp_verdict{};
+        review_bits[f] = stage ? rbits : 0;
+        for (int c = 0; c < AUDIT_COLS; ++c) {
+            const size_t before = all.size();
+            bool first = true;
+            for (uint32_t k = 0; stage && k < cnt[c]; ++k) {
+                const uint32_t v = c == AUDIT_UNKNOWN ? fin32[k] : c == AUDIT_KEPT ? (row[AUD_FLAGS] ? row[AUD_KEPT + k] : fin32[k]) : c == AUDIT_EVIDENCE ? row[AUD_EVIDENCE + k]
+                                   : c == AUDIT_DROPPED ? row[AUD_DROPPED + k] : row[AUD_TOP + k];
+                const uint32_t id = v & 0x7FFFFFFFu;
+                if (id >= t.n_strings) { g_err = "audit row entry is not an interned id"; return -2; }
+                if (c == AUDIT_UNKNOWN && !(t.known_active && !(t.flags[id] & FL_KNOWN))) continue;
+                if (!first) all.push_back(c >= AUDIT_TOP ? '\n' : ';');
+                first = false;
+                all.insert(all.end(), str_ptr(t, id), str_ptr(t, id) + str_len(t, id));
+                if (c == AUDIT_DROPPED) { const char* r = (v >> 31) ? ":policy_drop" : ":invalid_tag"; all.insert(all.end(), r, r + AUDIT_REASON_LEN); }
+            }
+            if (stage && all.size() - before != alen[c]) mismatch = true;
+            offs5[f * AUDIT_COLS + c + 1] = all.size();
+        }
+    }
+    if (mismatch) return -2;
+    if (all.size() > cap) return -1;
+    if (!all.empty()) std::memcpy(text, all.data(), all.size());
+    return (long long)all.size();
+}
+
 void sim_lean_declines(unsigned long long* out32, int reset) {
     for (int k = 0; k < 32; ++k) { out32[k] = g_lean_declines[k]; if (reset) g_lean_declines[k] = 0; }
 }

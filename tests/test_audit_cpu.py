@@ -293,3 +293,37 @@ def test_tagger_reply_tags_outside_ascii():
     arena, toffs = pack_lines(["1girl", "µm", "smile"])
     r = sim.run_scored(arena, toffs, np.array([0, 3], dtype=np.uint64), np.array([0.9, 0.8, 0.7]), np.zeros(3, np.uint8))
     assert r.verdicts["flags"][0] & 0x20
+
+
+@pytest.mark.parametrize("name,n", [("c3c", 300), ("c2", 300), ("c1", 300), ("c5", 200), ("edge", 0)])
+def test_audit_lists_of_the_wave_stages(name, n):
+    """Audit mode in the wave stages (the kernels' code on an emulated wavefront): the lists a stage leaves as interned ids - final
+    tags, evidence in insertion order, dropped tags with reason, top tagger tags, unknown caption tags - and the review bits equal
+    the oracle's for every file a stage takes, and the stages take nearly every file (c3c: the general wave stage lists closures of
+    several ExpandImpliedTags rounds; c5: files of more than 128 tags are the thread-per-file kernel's)."""
+    from helpers import EDGE_LINES, Config, check_review_facts
+    from test_pipeline_logic_cpu import fuzz_lines
+    if name == "edge":
+        cfg = shipped_config()
+        arena, offsets = pack_lines(EDGE_LINES + fuzz_lines(17, 400))
+    else:
+        from imagecaptioner_amd.corpus import make_corpus
+        c = make_corpus(name, n, seed=616)
+        cfg = Config(**c.config_kwargs)
+        arena, offsets = c.arena, c.offsets
+    m = len(offsets) - 1
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    want = orc.run_lines(arena, offsets, detail=True, audit=review_args(m))
+    lists, ver, stage = sim.run_audit_wave(arena, offsets)
+    exp = oracle_audit_lists(want)
+    taken = [i for i in range(m) if stage[i]]
+    assert len(taken) >= (m * 9 // 10 if name not in ("edge", "c5") else m // 2), (len(taken), m)
+    if name in ("c3c", "c1"):
+        assert sum(1 for i in taken if stage[i] >= 2) > (m // 3 if name == "c3c" else 5)      # the general wave stage had work to do
+    for i in taken:
+        assert lists[i][:3] == exp[i], (i, lists[i][:3], exp[i])
+        assert ver[i].tobytes() == want.verdicts[i].tobytes(), i
+    sub = lambda seq: [seq[i] for i in taken]
+    class Sub:                                                       # the oracle's records of the files a stage took
+        review_jsonl = sub(want.review_jsonl)
+    check_review_facts(sub(lists), sim.review_bits[taken], ver[taken], Sub)
