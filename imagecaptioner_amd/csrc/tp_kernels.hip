@@ -832,12 +832,15 @@ static_assert(RUN_STAGE >= FAST_CAPTION_MAX && RUN_TAGS >= FAST_FIN_MAX, "a sing
 // One group of up to RUN_FILES consecutive files: rows = the first file's row of tag ids (the others follow at FAST_FIN_MAX
 // words each); bit j of fastmask: file j is a wave-kernel file (the others are written elsewhere); n_[j] its tag count;
 // off_[j] .. off_[j + 1] its place in `captions`.  stage: RUN_STAGE + 48 bytes of LDS of this wavefront's own.
-template <class TT>
+// HIST: every tag id of the group is also counted in `bins` (LDS, two 16-bit counters a word, ids below n_public) and the
+// learned strings among them in n_learned; STAGE_CAP is the staging area's size.
+template <bool HIST = false, uint32_t STAGE_CAP = RUN_STAGE, class TT>
 __device__ __forceinline__ void emit_group(const TT& t, const uint32_t* rows, uint8_t* captions, uint8_t* stage, uint32_t lane, uint32_t nfile, uint32_t fastmask,
-                                           const uint32_t (&n_)[RUN_FILES], const uint64_t (&off_)[RUN_FILES + 1]) {
+                                           const uint32_t (&n_)[RUN_FILES], const uint64_t (&off_)[RUN_FILES + 1], uint32_t* bins = nullptr, uint32_t* n_learned = nullptr) {
+    static_assert(STAGE_CAP >= FAST_CAPTION_MAX, "a single file always fits the staging area");
     uint32_t tags_all = 0;
     for (int j = 0; j < RUN_FILES; ++j) tags_all += ((fastmask >> j) & 1u) ? n_[j] : 0u;
-    const bool whole = fastmask == (1u << nfile) - 1u && tags_all <= RUN_TAGS && off_[nfile] - off_[0] <= (uint64_t)RUN_STAGE;
+    const bool whole = fastmask == (1u << nfile) - 1u && tags_all <= RUN_TAGS && off_[nfile] - off_[0] <= (uint64_t)STAGE_CAP;
     // the runs of the group: [0, nfile) as a whole, or every wave-kernel file by itself
     for (uint32_t lo = 0; lo < nfile; lo = whole ? nfile : lo + 1) {
         const uint32_t hi = whole ? nfile : lo + 1;
@@ -863,6 +866,15 @@ __device__ __forceinline__ void emit_group(const TT& t, const uint32_t* rows, ui
             if (64u * b < T && gi < T) {
                 const uint32_t v = rows[(size_t)j * FAST_FIN_MAX + kb];
                 id[b] = (v < t.n_strings ? v : 0) | (uint32_t)(kb + 1 == nj) << 31;
+            }
+        }
+        if constexpr (HIST) {                                       // a tag occurs once in a file: the 16-bit counters hold as many files as the launch gives a block
+            TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
+                if (64u * b < T && 64u * b + lane < T) {
+                    const uint32_t v = id[b] & 0x7FFFFFFFu;
+                    if (v < t.n_public) atomicAdd(&bins[v >> 1], 1u << (16 * (v & 1)));
+                    else *n_learned += 1;                           // (v < n_strings: a learned string, counted with the tags in no table)
+                }
             }
         }
         uint4 r0[RUN_BLOCKS], r1[RUN_BLOCKS];
@@ -931,9 +943,25 @@ __device__ __forceinline__ void emit_group(const TT& t, const uint32_t* rows, ui
 #ifndef TP_EMIT_RUNS_WAVES_PER_SIMD
 #define TP_EMIT_RUNS_WAVES_PER_SIMD 4      // 128 registers: the records of five lane blocks stay in registers (measured: 0.79 ms against 0.82 at five waves with spills)
 #endif
-__global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu(TP_EMIT_RUNS_WAVES_PER_SIMD))) void k_emit_runs(DevTables t, EmitArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[EMIT_WAVES][RUN_STAGE + 48];
+// k_emit_runs_hist: the same with the tag histogram of these files counted on the way (the ids are in registers), one block
+// of 16 wavefronts per CU: its LDS holds the staging areas and 16-bit counters for HISTX_IDS ids, so the launch takes it when
+// the tables have no more strings than that and a block sees fewer than 65536 files; k_hist then only counts the general
+// kernel's files.
+constexpr int EMITH_WAVES = 16;
+constexpr uint32_t HISTX_IDS = 32768;
+constexpr uint32_t RUNH_STAGE = 6064;                           // 16 x (6064 + 48) + 64 KB of counters = 160 KB less 512 bytes
+template <bool HIST, int WAVES, uint32_t STAGE_CAP>
+__device__ __forceinline__ void emit_runs_body(const DevTables& t, const EmitArgs& a) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[WAVES][STAGE_CAP + 48];
     __shared__ unsigned long long blk_cnt[8];
+    __shared__ uint32_t bins[HIST ? HISTX_IDS / 2 : 1];
+    __shared__ uint32_t learned;
+    if constexpr (HIST) {
+        for (uint32_t i = threadIdx.x; i < HISTX_IDS / 2; i += blockDim.x) bins[i] = 0;
+        if (threadIdx.x == 0) learned = 0;
+        __syncthreads();
+    }
+    uint32_t n_learned = 0;
     const uint32_t lane = threadIdx.x & 63;
     uint8_t* stage = stage_all[wave_in_block()];
     const uint64_t wave_global = wave_index();
@@ -972,7 +1000,17 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         uint64_t off_[RUN_FILES + 1];
         for (int j = 0; j < RUN_FILES; ++j) n_[j] = lane_of(m0.n, j);
         for (int j = 0; j <= RUN_FILES; ++j) off_[j] = lane_of((uint32_t)m0.off, j) | (uint64_t)lane_of((uint32_t)(m0.off >> 32), j) << 32;
-        emit_group(t, a.fin32 + row0 * FAST_FIN_MAX, a.captions, stage, lane, nfile, fastmask, n_, off_);
+        emit_group<HIST, STAGE_CAP>(t, a.fin32 + row0 * FAST_FIN_MAX, a.captions, stage, lane, nfile, fastmask, n_, off_, bins, &n_learned);
+    }
+    if constexpr (HIST) {
+        if (n_learned) atomicAdd(&learned, n_learned);
+        __syncthreads();
+        if (threadIdx.x == 0 && learned) atomicAdd((unsigned long long*)&a.histogram[t.n_public], (unsigned long long)learned);
+        for (uint32_t i = threadIdx.x; i < (t.n_public + 1) / 2; i += blockDim.x) {
+            const uint32_t v = bins[i];
+            if (v & 0xFFFFu) atomicAdd((unsigned long long*)&a.histogram[2 * i], (unsigned long long)(v & 0xFFFFu));
+            if (v >> 16) atomicAdd((unsigned long long*)&a.histogram[2 * i + 1], (unsigned long long)(v >> 16));
+        }
     }
     if (a.counters) {                                                     // added up per block in LDS, then one global atomic per block and counter
         if (threadIdx.x < 8) blk_cnt[threadIdx.x] = 0;
@@ -982,6 +1020,10 @@ __global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu
         if (threadIdx.x < 8 && blk_cnt[threadIdx.x]) atomicAdd((unsigned long long*)a.counters + threadIdx.x, blk_cnt[threadIdx.x]);
     }
 }
+__global__ __launch_bounds__(64 * EMIT_WAVES) __attribute__((amdgpu_waves_per_eu(TP_EMIT_RUNS_WAVES_PER_SIMD))) void k_emit_runs(DevTables t, EmitArgs a) {
+    emit_runs_body<false, EMIT_WAVES, RUN_STAGE>(t, a);
+}
+__global__ __launch_bounds__(64 * EMITH_WAVES) void k_emit_runs_hist(DevTables t, EmitArgs a) { emit_runs_body<true, EMITH_WAVES, RUNH_STAGE>(t, a); }
 
 // The back half, the caption offsets and the caption bytes in one kernel (the plain run: no detail arrays, no audit lists).
 // Files are handed out in tiles of BX_TILE consecutive files, in the order blocks ask for them (a ticket counter), BX_FILES
@@ -1234,7 +1276,8 @@ __global__ __launch_bounds__(64) void k_add_counters(tp_counters* dst, const tp_
 // Tag histogram of the wave-kernel files: ids id0 .. id0 + HIST_IDS are counted in LDS (a tag occurs at most once per file,
 // so a block's 16-bit counters cannot overflow before HIST_FILES_PER_FLUSH files), then added to the global histogram.
 // Wider id ranges take further launches.  One wavefront per file.
-// general != 0: the files of the general kernel whose ids its emit kernel left in the same rows are counted too.
+// general != 0: the files of the general kernel whose ids its emit kernel left in the same rows are counted too; 2: only those
+// (the caption writer has counted the wave kernels' files).
 __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t id0, int general) {
     __shared__ uint32_t bins[HIST_IDS / 2];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
@@ -1257,7 +1300,8 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
                 nf[k] = 0;
                 if (g < c1) {
                     const uint32_t n = a.n_final[g];
-                    if (a.slot_of[g] == SLOT_FAST || (general && n <= FAST_FIN_MAX)) nf[k] = n;
+                    const bool fast = a.slot_of[g] == SLOT_FAST;
+                    if ((fast && general != 2) || (!fast && general && n <= FAST_FIN_MAX)) nf[k] = n;
                 }
             }
         };
@@ -1273,7 +1317,12 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
             }
             auto count = [&](uint32_t id, bool live) {
                 const uint32_t k = id - id0;
-                if (live && k < span) atomicAdd(&bins[k >> 1], 1u << (16 * (k & 1)));
+#ifdef HIST_X_NOATOM
+                if (live && k == span + 12345)
+#else
+                if (live && k < span)
+#endif
+                    atomicAdd(&bins[k >> 1], 1u << (16 * (k & 1)));
                 n_learned += (uint32_t)(live && id0 == 0 && id >= t.n_public && id < t.n_strings);
             };
             TP_UNROLL for (int k = 0; k < NF; ++k) { count(x[k].x, 2 * lane < nf[k]); count(x[k].y, 2 * lane + 1 < nf[k]); }
@@ -1282,6 +1331,9 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
         if (n_learned) atomicAdd(&learned, n_learned);
         __syncthreads();
         if (threadIdx.x == 0 && learned) { atomicAdd((unsigned long long*)&a.histogram[t.n_public], (unsigned long long)learned); learned = 0; }
+#ifdef HIST_X_NOFLUSH
+        if (span == 12345)
+#endif
         for (uint32_t i = threadIdx.x; i < (span + 1) / 2; i += blockDim.x) {
             const uint32_t v = bins[i];
             if (v & 0xFFFFu) atomicAdd((unsigned long long*)&a.histogram[id0 + 2 * i], (unsigned long long)(v & 0xFFFFu));
@@ -1510,6 +1562,7 @@ hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s) {
 hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
+    bool wave_files_counted = false;
     if (a.fin32 && a.fast_ran && !a.wave_files_written) {   // the wave-per-file kernel ran: its files first
         uint64_t want = (n + EMIT_WAVES - 1) / EMIT_WAVES;
         static const unsigned per_cu = env_blocks("TAGPIPE_EMIT_BLOCKS_PER_CU", (unsigned)TP_EMIT_WAVES_PER_SIMD);
@@ -1520,7 +1573,14 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
             want = ((n + RUN_FILES - 1) / RUN_FILES + EMIT_WAVES - 1) / EMIT_WAVES;
             static const unsigned runs_per_cu = env_blocks("TAGPIPE_EMIT_BLOCKS_PER_CU", (unsigned)TP_EMIT_RUNS_WAVES_PER_SIMD);
             blocks = (unsigned)(want < 256 * runs_per_cu ? want : 256 * runs_per_cu);
-            hipLaunchKernelGGL(k_emit_runs, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
+            static const bool no_hist = [] { const char* e = getenv("TAGPIPE_EMIT_HIST"); return e && e[0] == '0'; }();   // testing aid: the separate histogram kernel
+            const uint64_t hwant = ((n + RUN_FILES - 1) / RUN_FILES + EMITH_WAVES - 1) / EMITH_WAVES;
+            const unsigned hblocks = (unsigned)(hwant < 256 ? hwant : 256);
+            if (!no_hist && a.histogram && t.n_public <= HISTX_IDS && n >= 4096 && n / hblocks + RUN_FILES * EMITH_WAVES < 65536) {
+                hipLaunchKernelGGL(k_emit_runs_hist, dim3(hblocks), dim3(64 * EMITH_WAVES), 0, s, t, a);
+                wave_files_counted = true;
+            } else
+                hipLaunchKernelGGL(k_emit_runs, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1533,8 +1593,9 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
     if (a.fin32 && a.histogram) {                           // after both emit kernels: the general one leaves its files' tag ids in the same rows
         uint64_t hb = (n + 1023) / 1024;                      // a block is worth launching for a thousand files
         unsigned hblocks = (unsigned)(hb < 256 ? hb : 256);   // one per CU: the counters take most of its LDS
-        const int general = a.n_items ? 1 : 0;
-        for (uint32_t id0 = 0; id0 < t.n_public; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0, general);
+        const int general = a.n_items ? (wave_files_counted ? 2 : 1) : 0;
+        if (!(wave_files_counted && !a.n_items))
+            for (uint32_t id0 = 0; id0 < t.n_public; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0, general);
     }
     return hipGetLastError();
 }
