@@ -164,7 +164,7 @@ struct tp_ctx {
     bool fixed_bound = false;        //   (bound by that entry point's first call on the context)
     WorkBufs* w = &own;
     uint64_t* host_scalars = nullptr;   // pinned host words the runs read device scalars back into
-    DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary;           // host-pointer entry points stage their inputs here
+    DevBuf in_arena, in_offsets, in_tag_begin, in_scores, in_sources, in_secondary, in_reply_flags;           // host-pointer entry points stage their inputs here
     DevBuf out_captions, out_offsets, out_verdicts, out_hist, out_counters, out_fired, out_facets;
     DevBuf audit_cnt, audit_len, out_audit, out_audit_offsets, out_review_bits, aud32;
     std::unordered_map<std::string, uint32_t> string_ids;   // text of every interned string -> id (made on first use by tp_decode_joytag_replies)
@@ -187,7 +187,7 @@ struct tp_ctx {
         if (host_scalars) (void)hipHostFree(host_scalars);
         for (DevBuf* b : {&unk_keys, &unk_ent, &unk_text, &unk_count, &unk_out}) b->release();
         for (DevBuf* b : {&dt_dev, &in_arena, &in_offsets, &in_tag_begin,
-                          &in_scores, &in_sources, &in_secondary, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
+                          &in_scores, &in_sources, &in_secondary, &in_reply_flags, &out_captions, &out_offsets, &out_verdicts, &out_hist, &out_counters, &out_fired, &out_facets,
                           &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits, &aud32})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -203,6 +203,7 @@ namespace {
 struct RunIo {
     const uint8_t* arena; const uint64_t* offsets; const uint64_t* tag_begin; const double* scores; const uint8_t* sources;
     const uint64_t* secondary_begin; int secondary_cap;
+    const uint8_t* reply_flags;                                         // scored ingest: tp_replies::has_score per file on the device, or null
     uint64_t n_files;
     uint8_t* captions; uint64_t caption_capacity; bool grow_captions;   // grow_captions: captions live in ctx->out_captions and may be reallocated
     uint64_t* caption_offsets; tp_verdict* verdicts; uint64_t* histogram; tp_counters* counters; uint32_t* fired; uint16_t* facet_choice;
@@ -369,7 +370,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         c->w->workspace.need(ws_bytes);
         PipelineArgs pa{};
         pa.arena = io.arena; pa.offsets = io.offsets; pa.tag_begin = io.tag_begin; pa.scores = io.scores; pa.sources = io.sources;
-        pa.secondary_begin = io.secondary_begin; pa.secondary_cap = io.secondary_cap;
+        pa.secondary_begin = io.secondary_begin; pa.secondary_cap = io.secondary_cap; pa.reply_flags = io.reply_flags;
         pa.item_list = item_list; pa.file0 = f0; pa.n_items = n_slow; pa.fpw = fpw;
         fpw_used = fpw;
         c->last_fpw = fpw;
@@ -603,7 +604,7 @@ int guarded(F&& body) {
 // Host-pointer run shared by tp_run_lines and tp_run_scored.
 int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64_t* offsets, uint64_t n_offsets, const uint64_t* tag_begin,
              const double* scores, const uint8_t* sources, uint64_t n_tags, uint64_t n_files, tp_result* out,
-             const uint64_t* secondary_begin = nullptr, int secondary_cap = 0) {
+             const uint64_t* secondary_begin = nullptr, int secondary_cap = 0, const uint8_t* reply_flags = nullptr) {
     HIP_OK(hipSetDevice(c->device));
     hipStream_t s = nullptr;
     const DevTables& t = c->dt;
@@ -623,6 +624,10 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
             c->in_secondary.need(std::max<uint64_t>(n_files, 1) * 8);
             if (n_files) HIP_OK(hipMemcpyAsync(c->in_secondary.p, secondary_begin, n_files * 8, hipMemcpyHostToDevice, s));
         }
+        if (reply_flags) {
+            c->in_reply_flags.need(std::max<uint64_t>(n_files, 1));
+            if (n_files) HIP_OK(hipMemcpyAsync(c->in_reply_flags.p, reply_flags, n_files, hipMemcpyHostToDevice, s));
+        }
     }
     const size_t hist_n = (size_t)t.n_public + 1;
     c->out_offsets.need((n_files + 1) * 8);
@@ -641,6 +646,7 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     io.scores = tag_begin ? c->in_scores.as<double>() : nullptr;
     io.sources = tag_begin ? c->in_sources.as<uint8_t>() : nullptr;
     io.secondary_begin = secondary_begin ? c->in_secondary.as<uint64_t>() : nullptr; io.secondary_cap = secondary_cap;
+    io.reply_flags = tag_begin && reply_flags ? c->in_reply_flags.as<uint8_t>() : nullptr;
     io.n_files = n_files;
     io.captions = c->out_captions.as<uint8_t>(); io.caption_capacity = c->out_captions.cap; io.grow_captions = true;
     io.caption_offsets = c->out_offsets.as<uint64_t>(); io.verdicts = c->out_verdicts.as<tp_verdict>();
@@ -1090,6 +1096,37 @@ int tp_run_scored(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets
     }
     if (tag_offsets[n_tags] && !arena) return fail(TP_E_INVALID_ARG, "null argument");
     return guarded([&]() { return run_host(ctx, arena, tag_offsets[n_tags], tag_offsets, n_tags + 1, tag_begin, scores, sources, n_tags, n_files, out); });
+}
+
+// tp_run_replies: one reply per file (secondary_begin null: tp_run_scored's checks and run) or two (tp_run_merged's), with the
+// replies' HasScore flags handed on.
+static int run_scored_checked(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin,
+                              const double* scores, const uint8_t* sources, int secondary_cap, const uint8_t* reply_flags, uint64_t n_files, tp_result* out) {
+    for (uint64_t i = 0; i < n_files; ++i) {
+        if (tag_begin[i + 1] < tag_begin[i]) return fail(TP_E_INVALID_ARG, "tag_begin must be non-decreasing");
+        if (secondary_begin && (secondary_begin[i] < tag_begin[i] || secondary_begin[i] > tag_begin[i + 1])) return fail(TP_E_INVALID_ARG, "secondary_begin must lie within the file's tags");
+    }
+    const uint64_t n_tags = tag_begin[n_files];
+    if (n_tags && (!scores || (!secondary_begin && !sources))) return fail(TP_E_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n_tags; ++i) {
+        if (tag_offsets[i + 1] < tag_offsets[i]) return fail(TP_E_INVALID_ARG, "tag_offsets must be non-decreasing");
+        if (!(scores[i] == scores[i]) || scores[i] - scores[i] != 0.0) return fail(TP_E_INVALID_ARG, "scores must be finite");
+    }
+    const uint64_t arena_bytes = tag_offsets[n_tags];
+    if (arena_bytes && !arena) return fail(TP_E_INVALID_ARG, "null argument");
+    static const uint64_t none = 0;
+    return guarded([&]() {
+        return run_host(ctx, arena, arena_bytes, tag_offsets, n_tags + 1, tag_begin, scores, secondary_begin ? nullptr : sources, n_tags, n_files, out,
+                        secondary_begin ? (n_files ? secondary_begin : &none) : nullptr, secondary_cap, reply_flags);
+    });
+}
+
+static int run_scored_checked(tp_ctx* ctx, const uint8_t* arena, const uint64_t* tag_offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin,
+                              const double* scores, const uint8_t* sources, int secondary_cap, const uint8_t* reply_flags, uint64_t n_files, tp_result* out);
+
+int tp_run_replies(tp_ctx* ctx, const tp_replies* r, int secondary_cap, tp_result* out) {
+    if (!ctx || !r || !out || !r->tag_offsets || !r->tag_begin || (r->n_files && !r->has_score)) return fail(TP_E_INVALID_ARG, "null argument");
+    return run_scored_checked(ctx, r->arena, r->tag_offsets, r->tag_begin, r->secondary_begin, r->scores, r->sources, secondary_cap, r->has_score, r->n_files, out);
 }
 
 namespace {

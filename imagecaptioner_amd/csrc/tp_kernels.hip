@@ -553,11 +553,12 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
         in.arena = a.arena; in.tag_offsets = a.offsets; in.tag_lo = a.tag_begin[f]; in.tag_hi = a.tag_begin[f + 1];
         in.scores = a.scores; in.sources = a.sources;
         in.merged = a.secondary_begin != nullptr; in.tag_mid = in.merged ? a.secondary_begin[f] : in.tag_hi; in.secondary_cap = a.secondary_cap;
+        in.keep_order = a.reply_flags != nullptr && !(a.reply_flags[f] & 1u);
     } else {
         uint64_t o = a.offsets[f];
         in.text = a.arena + o; in.len = (uint32_t)(a.offsets[f + 1] - o);
         in.arena = nullptr; in.tag_offsets = nullptr; in.tag_lo = in.tag_hi = 0; in.scores = nullptr; in.sources = nullptr;
-        in.merged = false; in.tag_mid = 0; in.secondary_cap = 0;
+        in.merged = false; in.tag_mid = 0; in.secondary_cap = 0; in.keep_order = false;
     }
     FileOut out;
     process_file(t, in, ws, out, a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, a.mode);

@@ -65,6 +65,7 @@ struct PipelineArgs {
     const uint8_t* sources;
     const uint64_t* secondary_begin;   // scored ingest of two tagger replies: first secondary tag of every file (else null)
     int secondary_cap;
+    const uint8_t* reply_flags;   // scored ingest: per file, bit 0 = the (primary) reply was sorted by ParseJoyTags (null: every reply was)
     const uint32_t* item_list;    // may be null
     uint64_t file0;
     uint64_t n_items;

@@ -110,6 +110,10 @@ struct FileIn {
     bool merged;
     uint64_t tag_mid;
     int secondary_cap;
+    // the (primary) reply stays in the order it came in: no element of it carried a score, so ParseJoyTags did not sort it
+    // (Program.cs:487).  What follows the list's order downstream: the evidence set's and the dropped tags' insertion order
+    // (Program.cs:627-631, 723-727) and which of several entries on one whole sort key comes first.
+    bool keep_order;
 };
 struct FileOut {
     tp_verdict verdict;
@@ -748,7 +752,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
     } else {
         // ---------------- scored ingest, shaped like ParseJoyTags (Program.cs:473-487) ----------------
         // One tagger reply: tags [lo, hi) become entries g0 .. of the candidate arrays, ordered by (score descending, order ascending).
-        auto ingest = [&](uint64_t lo, uint64_t hi, uint32_t g0, int fixed_source) -> uint32_t {
+        auto ingest = [&](uint64_t lo, uint64_t hi, uint32_t g0, int fixed_source, bool keep) -> uint32_t {
             uint32_t order = 0, m = 0;
             for (uint64_t k = lo; k < hi; ++k) {
                 const uint8_t* s = in.arena + in.tag_offsets[k];
@@ -762,7 +766,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
                 // insertion by (score descending, order ascending): OrderByDescending(Score).ThenBy(Order), Program.cs:487
                 double sc = in.scores[k];
                 uint32_t pos = g0 + m;
-                while (pos > g0 && ws.score[pos - 1] < sc) {
+                while (!keep && pos > g0 && ws.score[pos - 1] < sc) {
                     ws.hnd[pos] = ws.hnd[pos - 1]; ws.score[pos] = ws.score[pos - 1]; ws.order[pos] = ws.order[pos - 1]; ws.src[pos] = ws.src[pos - 1];
                     --pos;
                 }
@@ -771,10 +775,10 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
             }
             return m;
         };
-        if (!in.merged) n = ingest(in.tag_lo, in.tag_hi, 0, -1);
+        if (!in.merged) n = ingest(in.tag_lo, in.tag_hi, 0, -1, in.keep_order);
         else {
-            const uint32_t np = ingest(in.tag_lo, in.tag_mid, 0, TP_SRC_PRIMARY_JOY);
-            const uint32_t ns = unsupported ? 0 : ingest(in.tag_mid, in.tag_hi, np, TP_SRC_SECONDARY_JOY);
+            const uint32_t np = ingest(in.tag_lo, in.tag_mid, 0, TP_SRC_PRIMARY_JOY, in.keep_order);
+            const uint32_t ns = unsupported ? 0 : ingest(in.tag_mid, in.tag_hi, np, TP_SRC_SECONDARY_JOY, false);   // LimitSecondaryTags sorts it in any case (Program.cs:805)
             if (!unsupported) {
                 // MergeCandidateTags (Program.cs:442-461) over the primary reply followed by what LimitSecondaryTags
                 // (Program.cs:801-815) lets through of the secondary one.  The map's values sit in insertion order in

@@ -1508,9 +1508,10 @@ void decode_joytag_reply(const HostTables& ht, const std::unordered_map<std::str
         return;
     }
     // With HasScore the list is sorted by (score descending, order) (Program.cs:487), which is what the scored ingest does with any
-    // list.  Without it the list stays as it is: that is the same thing only when the scores do not rise along it.
+    // list.  Without it the list stays as it is: that is the same thing only when the scores do not rise along it; the status
+    // tells the caller when they do (tp_run_replies keeps such a list's order, tp_run_scored / tp_run_merged would sort it).
     if (!has_score)
-        for (size_t k = 1; k < items.size(); ++k) if (items[k].score > items[k - 1].score) { status = TP_REPLY_ORDER; return; }
+        for (size_t k = 1; k < items.size(); ++k) if (items[k].score > items[k - 1].score) { status = TP_REPLY_ORDER; break; }
     for (const Item& it : items) {
         const std::string b = to_utf8(it.tag);
         out.arena.insert(out.arena.end(), b.begin(), b.end());

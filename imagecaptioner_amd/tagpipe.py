@@ -20,7 +20,7 @@ EXPORTS = (
     "tp_config_init", "tp_create", "tp_destroy", "tp_last_error", "tp_get_table_info", "tp_get_string", "tp_get_name",
     "tp_run_lines", "tp_run_scored", "tp_release", "tp_run_lines_device", "tp_run_lines_device_noalloc", "tp_format_top_tags", "tp_get_last_timing",
     "tp_triage_lines", "tp_run_merged", "tp_format_fired_rules", "tp_needtag_text", "tp_format_side_files",
-    "tp_decode_joytag_replies", "tp_release_replies", "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows", "tp_review_csv_header", "tp_format_review_rows",
+    "tp_decode_joytag_replies", "tp_release_replies", "tp_run_replies", "tp_set_audit", "tp_get_audit", "tp_audit_header", "tp_format_audit_rows", "tp_review_csv_header", "tp_format_review_rows",
     "tp_fallback_caption", "tp_error_needtag_text",
 )
 
@@ -72,6 +72,7 @@ def load_library():
     L.tp_decode_joytag_replies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(tp_replies)]
     L.tp_release_replies.argtypes = [C.POINTER(tp_replies)]
     L.tp_release_replies.restype = None
+    L.tp_run_replies.argtypes = [C.c_void_p, C.POINTER(tp_replies), C.c_int, C.POINTER(tp_result)]
     L.tp_run_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(tp_result)]
     L.tp_format_fired_rules.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     L.tp_needtag_text.restype = C.c_char_p
@@ -434,6 +435,30 @@ class TagPipe:
         finally:
             self._L.tp_release_replies(C.byref(r))
         return out
+
+    def run_replies(self, decoded, secondary_cap=15, audit=None):
+        """tp_run_replies on what decode_joytag_replies returned: one reply per file or two, each kept in the order
+        ParseJoyTags leaves it in (sorted only when an element carried a score, Program.cs:487)."""
+        keep = {k: np.ascontiguousarray(decoded[k], dtype=dt) for k, dt in (("arena", np.uint8), ("tag_offsets", np.uint64), ("tag_begin", np.uint64),
+                                                                             ("scores", np.float64), ("sources", np.uint8), ("has_score", np.uint8))}
+        sec = None if decoded.get("secondary_begin") is None else np.ascontiguousarray(decoded["secondary_begin"], dtype=np.uint64)
+        ptr = lambda a, ct: C.cast(a.ctypes.data, C.POINTER(ct)) if a is not None and a.size else None
+        r = tp_replies()
+        r.n_files = len(keep["tag_begin"]) - 1
+        r.n_tags = int(keep["tag_begin"][-1])
+        r.arena = ptr(keep["arena"], C.c_uint8); r.tag_offsets = ptr(keep["tag_offsets"], C.c_uint64); r.tag_begin = ptr(keep["tag_begin"], C.c_uint64)
+        if sec is not None and not sec.size:
+            sec = np.zeros(1, np.uint64)                       # never a null pointer: null means "one reply per file"
+        r.secondary_begin = None if sec is None else C.cast(sec.ctypes.data, C.POINTER(C.c_uint64))
+        r.scores = ptr(keep["scores"], C.c_double); r.sources = ptr(keep["sources"], C.c_uint8)
+        r.status = None; r.has_score = ptr(keep["has_score"], C.c_uint8); r.opaque = None
+        res = tp_result()
+        self._check(self._L.tp_set_audit(self._h, int(audit is not None)))
+        try:
+            self._check(self._L.tp_run_replies(self._h, C.byref(r), int(secondary_cap), C.byref(res)))
+        finally:
+            self._L.tp_set_audit(self._h, 0)
+        return self._collect(res, audit)
 
     # ---- device-resident run ---------------------------------------------------------------------
     def run_lines_device(self, io: tp_device_io, noalloc=False):

@@ -254,8 +254,11 @@ void tp_release(tp_ctx* ctx, tp_result* res);
 #define TP_REPLY_OK       0
 #define TP_REPLY_NO_TAGS  1  /* well-formed JSON without a "tags" array: an empty list, as in the reference (Program.cs:502-503) */
 #define TP_REPLY_ORDER    2  /* no element carries a score, and the default scores rise somewhere along the list (string and score-less
-                                object elements mixed): ParseJoyTags keeps such a list unsorted (Program.cs:487), the scored ingest would
-                                sort it; the reply is returned empty and is the caller's to handle */
+                                object elements mixed): ParseJoyTags keeps such a list unsorted (Program.cs:487).  The tags are returned
+                                in the reply's order; tp_run_replies keeps that order (has_score says which replies were sorted),
+                                tp_run_scored / tp_run_merged sort every list, which gives the same captions, verdicts, counters and
+                                fired rules (SelectTags sorts by score itself, Program.cs:651-655) but lists the evidence and the
+                                dropped tags of the audit row in sorted instead of reply order */
 #define TP_REPLY_FAILED   3  /* the reference throws on it (JSON that does not parse, a root that is not an object, a "score" or
                                 "confidence" that is not a number): the image fails there; returned empty */
 typedef struct tp_replies {
@@ -273,6 +276,16 @@ typedef struct tp_replies {
 int tp_decode_joytag_replies(tp_ctx* ctx, const uint8_t* primary, const uint64_t* primary_offsets, const uint8_t* secondary,
                              const uint64_t* secondary_offsets, uint64_t n_files, tp_replies* out);
 void tp_release_replies(tp_replies* replies);
+/*
+ * The decoded replies through the pipeline: what Program.cs:214-224 does with CallJoyTagAsync's lists.  Without secondary
+ * replies (replies->secondary_begin NULL) every file's list goes to SelectTags as ParseJoyTags left it: sorted by (score
+ * descending, order) when an element carried a score, in the reply's own order otherwise (Program.cs:487; has_score bit 0).
+ * With secondary replies the two lists are merged as tp_run_merged does (secondary_cap = --secondary-new-tags-cap), the
+ * primary one again in ParseJoyTags' order.  Files whose status is TP_REPLY_FAILED hold no tags: the reference fails such
+ * an image before the pipeline, and the caller does the same with what comes back for them.  `replies` may be the struct
+ * tp_decode_joytag_replies filled or one the caller built with the same layout (host pointers).
+ */
+int tp_run_replies(tp_ctx* ctx, const tp_replies* replies, int secondary_cap, tp_result* out);
 
 /*
  * Device-resident variant of tp_run_lines for callers that already hold the

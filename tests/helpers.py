@@ -62,6 +62,8 @@ def sim_lib():
         L.sim_run_audit.restype = C.c_longlong
         L.sim_run_audit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sim_run_audit_flags.restype = C.c_longlong
+        L.sim_run_audit_flags.argtypes = L.sim_run_audit.argtypes + [C.c_void_p]
         _SIM = L
     return _SIM
 
@@ -252,13 +254,15 @@ class HostSim:
             raise RuntimeError(self._L.sim_last_error().decode())
         return bad, ng.value
 
-    def run_audit(self, arena, offsets, tag_begin=None, secondary_begin=None, scores=None, sources=None, secondary_cap=0):
+    def run_audit(self, arena, offsets, tag_begin=None, secondary_begin=None, scores=None, sources=None, secondary_cap=0, reply_flags=None):
         """The audit row's tag lists from the general pipeline in audit mode: (lists, verdicts); lists[i] = (final_tags, evidence_tags,
-        dropped_tags_with_reason) as bytes, ';'-joined.  Line ingest unless tag_begin is given."""
+        dropped_tags_with_reason) as bytes, ';'-joined.  Line ingest unless tag_begin is given.  reply_flags: has_score per file
+        (tp_run_replies: a reply without scores keeps its order)."""
         arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         ptr = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)
         tb, sb, sc, sr = ptr(tag_begin, np.uint64), ptr(secondary_begin, np.uint64), ptr(scores, np.float64), ptr(sources, np.uint8)
+        rf = ptr(reply_flags, np.uint8)
         n = (len(tb) if tb is not None else len(offsets)) - 1
         offs3 = np.zeros(5 * n + 1, dtype=np.uint64)
         ver = np.zeros(n, dtype=VERDICT_DTYPE)
@@ -267,8 +271,8 @@ class HostSim:
         while True:
             text = np.zeros(cap, dtype=np.uint8)
             d = lambda a: None if a is None else a.ctypes.data
-            rc = self._L.sim_run_audit(self._h, arena.ctypes.data, offsets.ctypes.data, d(tb), d(sb), d(sc), d(sr), int(secondary_cap), n, text.ctypes.data, cap,
-                                       offs3.ctypes.data, ver.ctypes.data, self.review_bits.ctypes.data)
+            rc = self._L.sim_run_audit_flags(self._h, arena.ctypes.data, offsets.ctypes.data, d(tb), d(sb), d(sc), d(sr), int(secondary_cap), n, text.ctypes.data, cap,
+                                             offs3.ctypes.data, ver.ctypes.data, self.review_bits.ctypes.data, d(rf))
             if rc == -1:
                 cap *= 4
                 continue
@@ -622,7 +626,8 @@ def joytag_replies(seed, n):
     return prim, sec
 
 
-# bodies the reference throws on, and one whose order the scored ingest cannot keep
+# bodies the reference throws on (3), and lists without scores whose default scores rise along the list (2): ParseJoyTags leaves
+# those unsorted (Program.cs:487)
 BAD_REPLIES = [(b"", 3), (b"not json", 3), (b'["smile"]', 3), (b'{"tags": [{"tag": "smile", "score": "0.9"}]}', 3), (b'{"tags": [{"tag": "smile", "score": null}]}', 3),
                (b'{"tags": [{"tag": "smile", "confidence": [1]}]}', 3), (b'{"tags": ["smile",]}', 3), (b'{"tags": ["smile"]} x', 3),
                (b'{"tags": ["smile", {"tag": "dress"}, "long_hair"]}', 2), (b'{"tags": [{"tag": "dress"}, "smile"]}', 2),
@@ -649,7 +654,32 @@ def check_joytag_replies(engine, oracle):
     assert list(d["status"]) == [st for _, st in BAD_REPLIES]
     want = oracle.run_replies([b for b, _ in BAD_REPLIES])
     assert [int(x) for x in want.reply_status] == [st if st != 2 else 0 for _, st in BAD_REPLIES]
-    assert all(d["tag_begin"][i + 1] == d["tag_begin"][i] for i, (_, st) in enumerate(BAD_REPLIES) if st)
+    assert all((d["tag_begin"][i + 1] == d["tag_begin"][i]) == (st == 3) for i, (_, st) in enumerate(BAD_REPLIES))
+    # an unsorted list gives the same captions and verdicts sorted or not (SelectTags sorts by score itself, Program.cs:651-655)
+    got = engine.run_scored(d["arena"], d["tag_offsets"], d["tag_begin"], d["scores"], d["sources"])
+    assert_same_results(got, want, engine.histogram_dict(got.histogram), "replies without scores")
+    if hasattr(engine, "run_replies"):
+        got = engine.run_replies(d)
+        assert_same_results(got, want, engine.histogram_dict(got.histogram), "replies without scores, order kept")
+
+
+# Replies without a score anywhere whose default scores rise along the list: string elements score 1.0 - order * 0.001, an object
+# without "score" / "confidence" 0.5 (Program.cs:470, 476).  The evidence set and the dropped tags are listed in the reply's order
+# then (Program.cs:627-631, 723-727), not by score.
+UNSORTED_REPLIES = [b'{"tags": [{"tag": "dress"}, "smile", {"name": "watermark"}, "long_hair", {"tag": ":bad"}, "blue_eyes", "1girl"]}',
+                    b'{"tags": [{"tag": "standing"}, {"tag": "classroom"}, "blue_hair", {"tag": "a\\\"b"}, "text", {"tag": "dress"}, "Smile", "smile"]}',
+                    b'{"tags": ["smile", "dress"]}',
+                    b'{"tags": [{"tag": "dress", "score": 0.2}, "smile", {"tag": "standing", "score": 0.9}]}']
+UNSORTED_SECOND = [b'{"tags": [{"tag": "sitting"}, "smile", "outdoors", {"tag": "dress", "score": 0.4}]}',
+                   b'{"tags": ["classroom", {"tag": "red_eyes"}, "blue_hair"]}',
+                   b'{"tags": [{"tag": "long_hair"}, "dress", "smile"]}',
+                   b'{"tags": []}']
+
+
+def unsorted_reply_lists(oracle, secondary=False, cap=15):
+    """The oracle's audit lists for UNSORTED_REPLIES (with UNSORTED_SECOND as the second replies when asked)."""
+    want = oracle.run_replies(UNSORTED_REPLIES, UNSORTED_SECOND if secondary else None, secondary_cap=cap, detail=True)
+    return want, oracle_audit_lists(want)
 
 
 def changed_action_case():

@@ -466,8 +466,10 @@ int sim_triage_lines(void* h, const uint8_t* arena_in, const uint64_t* offsets, 
 // The audit row's three tag lists (process_file mode 3 + audit_elem, i.e. what k_pipeline and k_emit_audit do on the GPU).
 // Line ingest when tag_begin is null, scored ingest otherwise (two replies to merge when secondary_begin is given).
 // offs3 has AUDIT_COLS (5) n + 1 entries; returns the text size, or -1 when cap is too small (offs3 is filled either way).
-long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin, const double* scores,
-                        const uint8_t* sources, int secondary_cap, uint64_t n, uint8_t* text, uint64_t cap, uint64_t* offs3, tp_verdict* verdicts, uint32_t* review_bits) {
+// reply_flags: per file, bit 0 = ParseJoyTags sorted the (primary) reply (tp_replies::has_score); null = every reply was sorted.
+long long sim_run_audit_flags(void* h, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin, const double* scores,
+                              const uint8_t* sources, int secondary_cap, uint64_t n, uint8_t* text, uint64_t cap, uint64_t* offs3, tp_verdict* verdicts, uint32_t* review_bits,
+                              const uint8_t* reply_flags) {
     const Sim& s = *(Sim*)h;
     const DevTables& t = s.dt;
     std::vector<uint8_t> all;
@@ -483,7 +485,8 @@ long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, 
         FileWs ws = ws_bind(wsmem.data(), L, (uint32_t)(f & 63));
         FileIn in{};
         if (tag_begin) { in.arena = arena; in.tag_offsets = offsets; in.tag_lo = tag_begin[f]; in.tag_hi = tag_begin[f + 1]; in.scores = scores; in.sources = sources;
-                         in.merged = secondary_begin != nullptr; in.tag_mid = secondary_begin ? secondary_begin[f] : in.tag_hi; in.secondary_cap = secondary_cap; }
+                         in.merged = secondary_begin != nullptr; in.tag_mid = secondary_begin ? secondary_begin[f] : in.tag_hi; in.secondary_cap = secondary_cap;
+                         in.keep_order = reply_flags != nullptr && !(reply_flags[f] & 1u); }
         else { in.text = arena + offsets[f]; in.len = LB; }
         FileOut fo;
         process_file(t, in, ws, fo, fired.data(), t.n_facets ? facets.data() : nullptr, 3);
@@ -507,6 +510,11 @@ long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, 
     if (all.size() > cap) return -1;
     if (!all.empty()) std::memcpy(text, all.data(), all.size());
     return (long long)all.size();
+}
+
+long long sim_run_audit(void* h, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint64_t* secondary_begin, const double* scores,
+                        const uint8_t* sources, int secondary_cap, uint64_t n, uint8_t* text, uint64_t cap, uint64_t* offs3, tp_verdict* verdicts, uint32_t* review_bits) {
+    return sim_run_audit_flags(h, arena, offsets, tag_begin, secondary_begin, scores, sources, secondary_cap, n, text, cap, offs3, verdicts, review_bits, nullptr);
 }
 
 // The wave stages in audit mode on an emulated wavefront: the lean stage (front half, then the back half's detail build), then

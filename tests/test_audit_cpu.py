@@ -121,6 +121,32 @@ def test_audit_lists_scored_and_merged(cap):
         assert [l[:3] for l in lists] == oracle_audit_lists(want)
 
 
+def test_audit_lists_of_replies_that_stay_unsorted():
+    """A reply without scores keeps its order (Program.cs:487): the evidence set and the dropped tags follow that order."""
+    from helpers import UNSORTED_REPLIES, UNSORTED_SECOND, unsorted_reply_lists
+    cfg = shipped_config()
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    d = sim.decode_joytag_replies(UNSORTED_REPLIES)
+    assert list(d["status"]) == [2, 2, 0, 0] and list(d["has_score"]) == [0, 0, 0, 1]
+    want, exp = unsorted_reply_lists(orc)
+    lists, ver = sim.run_audit(d["arena"], d["tag_offsets"], tag_begin=d["tag_begin"], scores=d["scores"], sources=d["sources"], reply_flags=d["has_score"])
+    assert [l[:3] for l in lists] == exp
+    assert all(ver[i].tobytes() == want.verdicts[i].tobytes() for i in range(len(exp)))
+    # sorted, the same files list the same tags in another order (and the same final tags)
+    lists2, ver2 = sim.run_audit(d["arena"], d["tag_offsets"], tag_begin=d["tag_begin"], scores=d["scores"], sources=d["sources"])
+    assert [l[0] for l in lists2] == [e[0] for e in exp] and ver2.tobytes() == ver.tobytes()
+    assert lists2[0][1] != exp[0][1] and sorted(lists2[0][1].split(b";")) == sorted(exp[0][1].split(b";"))
+    assert [l[:3] for l in lists2[2:]] == exp[2:]
+    # two replies per file: the primary one keeps its order, the secondary one is sorted by LimitSecondaryTags in any case
+    d = sim.decode_joytag_replies(UNSORTED_REPLIES, UNSORTED_SECOND)
+    for cap in (15, 1):
+        want, exp = unsorted_reply_lists(orc, secondary=True, cap=cap)
+        lists, ver = sim.run_audit(d["arena"], d["tag_offsets"], tag_begin=d["tag_begin"], secondary_begin=d["secondary_begin"], scores=d["scores"],
+                                   secondary_cap=cap, reply_flags=d["has_score"])
+        assert [l[:3] for l in lists] == exp, cap
+        assert all(ver[i].tobytes() == want.verdicts[i].tobytes() for i in range(len(exp)))
+
+
 # ---- review records (BuildReviewRecord / AppendReviewLog, Program.cs:826-890) -----------------------------------------------
 def review_args(n, vocab_file="top_tags.txt"):
     return {"names": ["%d.png" % i for i in range(n)], "vocab_file": vocab_file, "used_profile": "sgrui",

@@ -672,6 +672,33 @@ def test_cached_tagger_replies_decode_like_parse_joy_tags():
     check_joytag_replies(pipe_for(cfg), Oracle(cfg))
 
 
+def test_replies_without_scores_keep_their_order():
+    """tp_run_replies: a reply in which no element carries a score is not sorted by ParseJoyTags (Program.cs:487), so the audit
+    row lists its evidence and its dropped tags in the reply's order; the secondary reply of a pair is sorted by
+    LimitSecondaryTags whatever it holds (Program.cs:805)."""
+    from helpers import UNSORTED_REPLIES, UNSORTED_SECOND
+    cfg = shipped_config()
+    p, o = pipe_for(cfg), Oracle(cfg)
+    audit = _review_args(len(UNSORTED_REPLIES))
+    d = p.decode_joytag_replies(UNSORTED_REPLIES)
+    assert list(d["status"]) == [2, 2, 0, 0] and list(d["has_score"]) == [0, 0, 0, 1]
+    got = p.run_replies(d, audit=audit)
+    want = o.run_replies(UNSORTED_REPLIES, detail=True, audit=audit)
+    _check_audit(got, want)
+    _check_review(got, want)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), "unsorted replies")
+    assert_same_results(p.run_replies(d), want, p.histogram_dict(got.histogram), "unsorted replies, plain run")
+    sorted_run = p.run_scored(d["arena"], d["tag_offsets"], d["tag_begin"], d["scores"], d["sources"], audit=audit)
+    assert sorted_run.audit_lists[0][1] != got.audit_lists[0][1] and sorted_run.audit_lists[0][0] == got.audit_lists[0][0]
+    d = p.decode_joytag_replies(UNSORTED_REPLIES, UNSORTED_SECOND)
+    for cap in (15, 1):
+        got = p.run_replies(d, secondary_cap=cap, audit=audit)
+        want = o.run_replies(UNSORTED_REPLIES, UNSORTED_SECOND, secondary_cap=cap, detail=True, audit=audit)
+        _check_audit(got, want)
+        _check_review(got, want)
+        assert_same_results(got, want, p.histogram_dict(got.histogram), "unsorted replies, merged, cap %d" % cap)
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`bench.py --gpus 2` as its own launcher, both ranks on the one GPU of this box, sums through gloo (RCCL refuses two ranks on
     one GPU): the ranks' shards go through tp_run_lines_device, the summed histogram adds up, and rank 0 prints the line."""
