@@ -68,6 +68,8 @@ enum : uint32_t {
     FL_SUBJ_MALE = 1u << 26,   //   it is in MaleSubjectTokens (Program.cs:30-32, 835)
     FL_SUBJ_GIRL = 1u << 27,   //   it holds "girl" (Program.cs:836)
     FL_SUBJ_MULTI = 1u << 28,  //   it starts with "multiple_" or matches ^\d+(girl|girls|boy|boys)$ (Program.cs:837; \d is the Unicode category Nd)
+    FL_SPLIT = 1u << 31,       // a force-allowed tag that holds ',' (or white space at a piece's end): the line ingest keeps it (Program.cs:1123) and its
+                               //   join + re-split (Program.cs:604, 578) cuts it into the pieces DevTables::split_ids lists
     FL_FIX = 1u << 30,         // NormalizeTag leaves it alone and it is not blank
     FL_FENCE = 1u << 29,       // holds '`': StripCodeFences may act on a line with it (Program.cs:595, 1189-1210)
     FL_LEAF2 = 1u << 24,       // FL_REACH2, and each step is a non-blank string that NormalizeTag leaves alone (whatever a step's own
@@ -304,6 +306,8 @@ constexpr uint32_t NO_ID = 0xFFFFFFFFu;
 constexpr uint32_t EMPTY_ID = 0;          // the empty string is always id 0
 constexpr int MAX_TOTAL_TAGS = 42;        // Program.cs:38
 constexpr int N_BANNED = 9;               // BannedFinalTags, Program.cs:33-35
+constexpr int MAX_SPLIT = 4;              // force-allowed tags the line ingest cuts into pieces (FL_SPLIT), and pieces of one
+constexpr int MAX_SPLIT_PIECES = 8;
 constexpr int TOP_TAGS = 20;              // TopJoyTags of a review record, Program.cs:860
 static_assert(AUD_TOP + TOP_TAGS <= AUD_FLAGS, "the flag word lies behind the top tags");
 constexpr int MAX_ALWAYS_ADD = 64;
@@ -418,6 +422,11 @@ struct DevTables {
     uint32_t prefix_simple;      // the same for the prefix tags, and none of them has steps
     uint32_t prefix_flags[MAX_TOTAL_TAGS], prefix_len[MAX_TOTAL_TAGS];   // flags and byte length per prefix tag
     uint32_t banned_ids[N_BANNED];   // BannedFinalTags (Program.cs:33-35) in ordinal-ignore-case order, the order BuildReviewRecord lists them in (Program.cs:828)
+    // FL_SPLIT strings: split_src[k] is cut into the strings split_ids[k][0 .. split_cnt[k]) (SplitTags of it, as they stand: the
+    // candidates' NormalizeTag sites see them next); split_commas[k] = the ',' it holds (LooksBad of the joined line counts them);
+    // split_grow = how many candidates one token can become at most (1 without such strings)
+    uint32_t n_split, split_grow;
+    uint32_t split_src[MAX_SPLIT], split_cnt[MAX_SPLIT], split_commas[MAX_SPLIT], split_ids[MAX_SPLIT][MAX_SPLIT_PIECES];
     uint32_t seed_ci_limit;      // candidates below this index have !(score < 0.28)  (BuildEvidenceTags, Program.cs:724)
     uint32_t style_ci_limit;     // candidates below this index have score >= 0.60     (DetermineStyleQualityCap, Program.cs:706)
 };

@@ -1112,6 +1112,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                     int kind = fast_token(t, s, i, j, special, high, id, rr, vdyn, dlen);
                     if (kind == 1) {
                         if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) { h1[blk] = id; r1[blk] = rr; keep[blk] = true; }
+                        if (rr.flags & FL_SPLIT) dyn_survivor = true;   // the join + re-split cuts it up: general kernel
                     } else if (kind == 3) {
                         dyn_survivor = true;                       // declines the file below
                     } else if (kind == 2) {
@@ -1785,7 +1786,7 @@ TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, c
             const int kind = fast_token(t, s, i, j, special, high, id, rr, vdyn, dlen);
             if (kind == 1) {
                 if ((rr.flags & FL_LEN2) && !(rr.flags & FL_DROP)) {
-                    if (rr.next != id && !triage) decline = true;  // NormalizeTag would change it again
+                    if ((rr.next != id && !triage) || (rr.flags & FL_SPLIT)) decline = true;  // NormalizeTag would change it again; the join + re-split would cut it up
                     const uint32_t slot = big_put(w, L, id, tix);
                     if (slot == NO_ID) decline = true;
                     cid = id;

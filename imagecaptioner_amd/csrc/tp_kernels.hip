@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void k_wave_sizes(DevTables t, const uint8_t* 
             uint64_t len = offsets[f + 1] - offsets[f];
             if (len > 0x7FFFFFFFull) { atomicOr(status, 1u); len = 0; }
             LB = (uint32_t)len;
-            T = count_commas(arena + offsets[f], LB) + 1;
+            T = (count_commas(arena + offsets[f], LB) + 1) * t.split_grow;   // (a token can become several candidates: FL_SPLIT)
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {

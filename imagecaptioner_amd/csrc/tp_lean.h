@@ -565,7 +565,7 @@ TP_HD_FLAT bool lean_front(W& w, const TT& t, LeanFrontLds& L, const LeanShared&
             if (w.ballot(keep_it) != 0 && lane == 0) L.cpos[LEAN_CPOS_NOTE] = 1;
         }
         // LooksBad's phrases and code fences are looked for in the raw line (Program.cs:592-596): any token holding one declines
-        if (id != NO_ID && (f & (FL_PHRASE | FL_FENCE))) decline = true;
+        if (id != NO_ID && (f & (FL_PHRASE | FL_FENCE | FL_SPLIT))) decline = true;
         kept = id != NO_ID && (f & FL_LEN2) && !(f & FL_DROP);     // Length >= 2, !ShouldDropTag (Program.cs:600-601)
         if (kept && hop) decline = true;                           // NormalizeTag would change it again at the next site: tp_fast.h follows such hops
         if (w.ballot(decline) != 0) return LEAN_NO(5);

@@ -702,8 +702,7 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         }
         TP_PIPE_STAMP(12)
         if (!rejected) {
-            // SplitTags -> NormalizeTag -> Length >= 2 -> !ShouldDropTag -> Distinct (Program.cs:598-602); the join and the second
-            // SplitTags (Program.cs:604, 578) return the same strings because no surviving tag holds ',' or white space.
+            // SplitTags -> NormalizeTag -> Length >= 2 -> !ShouldDropTag -> Distinct (Program.cs:598-602)
             uint32_t i = a;
             for (;;) {
                 uint32_t j = i;
@@ -728,19 +727,47 @@ TP_HD void process_file(const DevTables& t, const FileIn& in, FileWs& ws, FileOu
         }
         TP_PIPE_STAMP(13)
         if (unsupported) { v.flags = TP_F_UNSUPPORTED; return; }
+        // which of the configuration's FL_SPLIT strings a kept tag is (t.n_split otherwise)
+        auto split_index = [&](H h) -> uint32_t {
+            if (h_is_dyn(h) || !(t.flags[h_id(h)] & FL_SPLIT)) return t.n_split;
+            for (uint32_t k = 0; k < t.n_split; ++k) if (t.split_src[k] == h_id(h)) return k;
+            return t.n_split;
+        };
         if (mode == 2) {
             // Existing-caption triage stops here: LooksBad of the kept tags joined with ", " (Program.cs:206-207, 604, 1141-1147)
             bool bad = rejected || n == 0;
-            uint32_t units = 0;
+            uint32_t units = 0, commas = n ? n - 1 : 0;
             for (uint32_t i = 0; i < n && !bad; ++i) {
                 H h = ws.hnd[i];
                 if (h_is_dyn(h)) units += h_len(h);                // ASCII: one UTF-16 unit per byte (a phrase would have dropped it)
                 else { if (t.flags[h_id(h)] & FL_PHRASE) bad = true; units += t.rec[h_id(h)].len16; }
+                if (t.n_split) { const uint32_t k = split_index(h); if (k < t.n_split) commas += t.split_commas[k]; }   // a kept tag's own commas count too (Program.cs:1145)
             }
-            if (!bad && n <= 2 && units + 2 * (n - 1) > 40) bad = true;
+            if (!bad && commas < 2 && units + 2 * (n - 1) > 40) bad = true;
             v.flags = bad ? (uint8_t)TP_F_TRIAGE_BAD : (uint8_t)0;
             v.n_candidates = (uint16_t)(n > 0xFFFF ? 0xFFFF : n);
             return;
+        }
+        // The join and the second SplitTags (Program.cs:604, 578) return the kept tags as they are, except a force-allowed tag
+        // that holds ',': its pieces take its place, each a candidate of its own.  In place: tags without pieces go first
+        // (the list shrinks), then the list grows from its end.
+        if (t.n_split) {
+            uint32_t m = 0, grown = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                const H h = ws.hnd[i];
+                const uint32_t k = split_index(h);
+                if (k < t.n_split && t.split_cnt[k] == 0) continue;
+                grown += k < t.n_split ? t.split_cnt[k] : 1u;
+                ws.hnd[m++] = h;
+            }
+            if (grown > ws.cap_t) { v.flags = TP_F_UNSUPPORTED; return; }
+            for (uint32_t i = m, dst = grown; i-- > 0;) {
+                const H h = ws.hnd[i];
+                const uint32_t k = split_index(h);
+                if (k == t.n_split) { ws.hnd[--dst] = h; continue; }
+                for (uint32_t q = t.split_cnt[k]; q-- > 0;) ws.hnd[--dst] = (H)t.split_ids[k][q];
+            }
+            n = grown;
         }
         // ParseTagCandidatesFromLine scores, Program.cs:581-583
         for (uint32_t i = 0; i < n; ++i) {

@@ -753,6 +753,19 @@ void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std
         W fl = from_utf8(out.fallback_line.data(), out.fallback_line.size());
         for (auto& tok : split_tags(fl)) in.id(normalize_basic(tok));
     }
+    // A force-allowed tag survives ShouldDropTag whatever it holds (Program.cs:1123), so the line ingest keeps one that holds ','
+    // (an alias value can be such a string) and its join + re-split (Program.cs:604, 578) cuts it into SplitTags' pieces, each a
+    // candidate of its own from there on.  The pieces are interned as they stand; FL_SPLIT marks the string.
+    std::vector<std::pair<W, std::vector<W>>> splits;
+    for (auto& s : ld.force_allow.order) {
+        if (s.size() < 2) continue;                               // Length >= 2 comes first (Program.cs:600)
+        std::vector<W> pieces = split_tags(s);
+        if (pieces.size() == 1 && pieces[0] == s) continue;
+        if (splits.size() >= (size_t)MAX_SPLIT || pieces.size() > (size_t)MAX_SPLIT_PIECES)
+            throw ConfigError("more than 4 force-allowed tags (trigger / always-add) hold ',', or one holds more than 7: not representable");
+        for (auto& p : pieces) in.id(p);
+        splits.emplace_back(s, pieces);
+    }
     // close under NormalizeTagBasic, the alias lookup and NormalizeTag
     size_t closed = 0;
     auto close = [&]() {
@@ -777,10 +790,6 @@ void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std
     }
     const uint32_t N = (uint32_t)in.text.size();
 
-    // A force-allowed tag survives ShouldDropTag even when it holds ',' or white space, and the line ingest's join + re-split
-    // (Program.cs:604, 578) would then cut it in two; the kernels do not model that.
-    for (auto& s : ld.force_allow.order)
-        for (wc c : s) if (c == ',' || is_space(c)) throw ConfigError("a force-allowed tag (trigger / always-add) holds ',' or white space: not representable");
 
     // ---- per-string attributes ----
     out.strings.resize(N);
@@ -814,6 +823,7 @@ void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std
         if (s.size() >= 2) f |= FL_LEN2;
         if (Loader::has_looks_bad_phrase(lowered(s))) f |= FL_PHRASE;
         if (s.find((wc)'`') != W::npos) f |= FL_FENCE;
+        for (auto& sp : splits) if (folded(sp.first) == folded(s)) f |= FL_SPLIT;
         f |= ld.bucket_of(s, mask) << FL_BUCKET_SHIFT;
         if (mask & CM_HAIR) f |= FL_HAIR;
         if (mask & CM_EYES) f |= FL_EYES;
@@ -973,6 +983,15 @@ void compile_tables(const tp_config& cfg, HostTables& out, const std::vector<std
     {   // BannedFinalTags in the order OrderBy(OrdinalIgnoreCase) lists them (Program.cs:828): compared upper-cased
         static const char* const kBannedSorted[N_BANNED] = {"1boy", "2boys", "3boys", "4boys", "boy", "male", "male_focus", "multiple_boys", "yaoi"};
         for (int k = 0; k < N_BANNED; ++k) sc.banned_ids[k] = id_of(widen(kBannedSorted[k]));
+    }
+    sc.n_split = (uint32_t)splits.size();
+    sc.split_grow = 1;
+    for (uint32_t k = 0; k < sc.n_split; ++k) {
+        sc.split_src[k] = id_of(splits[k].first);
+        sc.split_cnt[k] = (uint32_t)splits[k].second.size();
+        sc.split_commas[k] = (uint32_t)std::count(splits[k].first.begin(), splits[k].first.end(), (wc)',');
+        for (uint32_t q = 0; q < sc.split_cnt[k]; ++q) sc.split_ids[k][q] = id_of(splits[k].second[q]);
+        sc.split_grow = std::max(sc.split_grow, sc.split_cnt[k]);
     }
     sc.drop_unknown = (ld.known_found && ld.strict) ? 1 : 0;
     sc.allow_nonempty = ld.allow.size() > 0 ? 1 : 0;

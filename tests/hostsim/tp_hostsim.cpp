@@ -64,7 +64,7 @@ void run(const Sim& s, const uint8_t* arena, const uint64_t* offsets, const uint
         for (uint64_t f = w0; f < w1; ++f) {
             uint32_t tf, lf;
             if (tag_begin) { tf = (uint32_t)(tag_begin[f + 1] - tag_begin[f]); lf = (uint32_t)(offsets[tag_begin[f + 1]] - offsets[tag_begin[f]]); }
-            else { lf = (uint32_t)(offsets[f + 1] - offsets[f]); tf = commas(arena + offsets[f], lf) + 1; }
+            else { lf = (uint32_t)(offsets[f + 1] - offsets[f]); tf = (commas(arena + offsets[f], lf) + 1) * t.split_grow; }
             T = std::max(T, tf); LB = std::max(LB, lf);
         }
         WsLayout L = ws_layout(T, LB, t.final_cap, t.evidence_grow, t.lit_words);
@@ -479,7 +479,7 @@ long long sim_run_audit_flags(void* h, const uint8_t* arena, const uint64_t* off
     for (uint64_t f = 0; f < n; ++f) {
         uint32_t T, LB;
         if (tag_begin) { T = (uint32_t)(tag_begin[f + 1] - tag_begin[f]); LB = (uint32_t)(offsets[tag_begin[f + 1]] - offsets[tag_begin[f]]); }
-        else { LB = (uint32_t)(offsets[f + 1] - offsets[f]); T = commas(arena + offsets[f], LB) + 1; }
+        else { LB = (uint32_t)(offsets[f + 1] - offsets[f]); T = (commas(arena + offsets[f], LB) + 1) * t.split_grow; }
         WsLayout L = ws_layout(std::max(T, 1u), LB, t.final_cap, t.evidence_grow, t.lit_words);
         std::vector<uint8_t> wsmem(L.total, 0xCD);
         FileWs ws = ws_bind(wsmem.data(), L, (uint32_t)(f & 63));

@@ -76,9 +76,27 @@ _SHAPE_LINES = [
     "beret, bob cut, 1girl, smile",
     "x",
     "",
+    # tokens that an alias turns into a force-allowed tag with a comma (FORCE_ALLOWED_COMMAS): the join and re-split of
+    # Program.cs:604, 578 make each piece a candidate, with the scores of the candidates behind them moving along
+    "1girl, ab, smile, dress, long hair",
+    "xy, 1girl, AB, xy, blue eyes, x",
+    "1girl, a, y, xy, standing",
+    "gone, 1girl, smile, dress, classroom",
+    "ab",
+    "xy, gone",
+    "1girl, xyz, ab, xy, gone, smile, dress, long hair, blue eyes, standing, classroom, a,_b",
 ]
 
+# A trigger and always-add entries that hold commas, and aliases whose values are those strings.  NormalizeTag makes the trigger
+# "a,_b"; IsValidTag refuses every string with a comma, so none of them is ever added by AddOne (Program.cs:695), but ShouldDropTag
+# lets them through the line ingest (Program.cs:1123), whose joined line SplitTags cuts at their commas (Program.cs:604, 578).
+FORCE_ALLOWED_COMMAS = dict(profile=_j({"Trigger": "a, b", "AlwaysAdd": ["x,y", "smile", ",,", "p;,q.,r"]}),
+                            lexicon=_j({"aliases": {"ab": "A, b", "xy": "x,y", "gone": ",,", "xyz": "p;,q.,r", "bare foot": "barefoot"},
+                                        "implied": {"x": ["feet"], "q": ["y"]}}))
+
 SHAPES = {
+    "force_allowed_commas": lambda: shipped_config(strict_known=False, strict_known_explicit=True, **FORCE_ALLOWED_COMMAS),
+    "force_allowed_commas_strict": lambda: shipped_config(**FORCE_ALLOWED_COMMAS),
     "lexicon_alt_keys": lambda: shipped_config(lexicon=LEXICON_ALT_KEYS),
     "lexicon_alt_keys_open": lambda: shipped_config(lexicon=LEXICON_ALT_KEYS, strict_known=False, strict_known_explicit=True),
     "actions_category_map": lambda: shipped_config(actions=ACTIONS_CATEGORY_MAP, strict_known=False, strict_known_explicit=True),
@@ -107,7 +125,8 @@ REJECTED = {
     # ToLowerInvariant (final and medial sigma both fold to the capital): which spelling a caption shows depends on insertion order
     "case_mapping_twins": lambda: shipped_config(lexicon=_j({"implied": {"smile": ["abς"]}}),
                                                  vocabulary="1girl\nsmile\nabσ\n".encode("utf-8"), vocabulary_is_json=0),
-    # a force-allowed tag with a comma survives the filters whole and is then cut in two by the line ingest's join and re-split
-    "trigger_with_comma": lambda: shipped_config(profile=_j({"Trigger": "a, b"})),
-    "always_add_with_comma": lambda: shipped_config(profile=_j({"AlwaysAdd": ["x,y"]})),
+    # force-allowed tags with commas are cut up by the line ingest's join and re-split; the tables hold four such tags of up to
+    # eight pieces each
+    "five_tags_with_commas": lambda: shipped_config(profile=_j({"Trigger": "a,b", "AlwaysAdd": ["c,d", "e,f", "g,h", "i,j"]})),
+    "nine_pieces": lambda: shipped_config(profile=_j({"Trigger": "a,b,c,d,e,f,g,h,i"})),
 }

@@ -601,11 +601,19 @@ def test_loader_shapes_match_the_oracle(name):
     cfg = SHAPES[name]()
     p = pipe_for(cfg)
     lines = shape_lines()
-    got, want = p.run_texts(lines), Oracle(cfg).run_texts(lines)
+    o = Oracle(cfg)
+    got, want = p.run_texts(lines), o.run_texts(lines)
     assert_same_results(got, want, p.histogram_dict(got.histogram), name)
+    if name.startswith("force_allowed_commas"):
+        # a force-allowed tag with a comma: its pieces are the candidates (Program.cs:604, 578), in audit mode and triage too
+        assert want.verdicts["n_candidates"][lines.index("ab")] == 2
+        audit = _review_args(len(lines))
+        _check_audit(p.run_texts(lines, audit=audit), o.run_texts(lines, detail=True, audit=audit))
+        texts = lines + ["xy, " + "z" * 40, "x, " + "z" * 40, "gone, " + "z" * 40, "ab" + " " * 50 + ", smile"]
+        assert list(p.triage_texts(texts)) == list(o.triage_texts(texts))
 
 
-@pytest.mark.parametrize("name", ["case_mapping_twins", "trigger_with_comma", "always_add_with_comma"])
+@pytest.mark.parametrize("name", ["case_mapping_twins", "five_tags_with_commas", "nine_pieces"])
 def test_tables_this_build_refuses(name):
     """Tables the reference loads and this build cannot represent: tp_create fails with TP_E_CONFIG and says why."""
     from imagecaptioner_amd import TagPipeError

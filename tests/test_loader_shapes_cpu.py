@@ -14,6 +14,16 @@ def test_loader_shapes_match_the_oracle(name):
     want = o.run_texts(lines)
     for got in (s.run_texts(lines), s.run_texts_lean(lines)):
         assert_same_results(got, want, s.histogram_dict(got.histogram), name)
+    if name.startswith("force_allowed_commas"):
+        # the pieces of a cut-up tag are candidates: "ab" alone gives "a" and "_b" (the second is no valid tag)
+        i = lines.index("ab")
+        assert want.verdicts["n_candidates"][i] == 2 and want.verdicts["n_dropped"][i] >= 1
+        i = lines.index("xy, gone")
+        assert want.verdicts["n_candidates"][i] == 2                       # "x", "y"; ",," has no pieces
+        # existing-caption triage reads the joined line, commas inside a kept tag included (Program.cs:1145-1146)
+        texts = lines + ["xy, " + "z" * 40, "x, " + "z" * 40, "gone, " + "z" * 40, "ab" + " " * 50 + ", smile"]
+        bad, _ = s.triage_texts(texts)
+        assert list(bad) == list(o.triage_texts(texts))
 
 
 def test_the_shapes_do_what_the_reference_says():
