@@ -174,6 +174,11 @@ struct tp_ctx {
     size_t ws_budget = (size_t)64 << 30;
     bool no_fast = false;            // TAGPIPE_NO_FAST=1: every file takes the general kernel (testing aid)
     bool use_lean = false;           // the lean stage runs ahead of the wave stages (TAGPIPE_NO_LEAN=1 turns it off: testing aid)
+    // A corpus whose files the lean stage mostly declines (a kept alias-chain member in every file, say) pays for its front
+    // half and gets nothing: after a range of which it took less than a quarter, the next lean_rest ranges go to the general
+    // wave stages directly, then one range tries it again.  Results do not depend on it (TAGPIPE_LEAN_ADAPT=0: always try).
+    bool lean_adapt = true;
+    int lean_rest = 0;
     bool no_fused = true;            // TAGPIPE_FUSED=1: the plain run's back half, caption offsets and caption bytes as ONE kernel (k_lean_bx).  Off by default:
                                      // measured on c2 (1M files) the fused kernel takes 2.86 ms where k_lean_b + scan + k_emit_runs take 2.2 ms
     uint64_t fused_reruns = 0;       // ranges the fused back half had to hand back to the separate kernels
@@ -240,11 +245,14 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
     const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast && !io.audit;   // tagger replies: the wave kernel's scored front
     // audit mode over tag lines: the lean stage lists what it takes (interned ids, tp_lean.h), everything else takes the general kernel
     const bool audit_lean = io.audit && c->use_lean && c->dt.fast_ok && !io.tag_begin && io.mode == 0 && !c->no_fast;
+    bool lean_now = c->use_lean && io.mode == 0 && !io.tag_begin;
+    if (lean_now && c->lean_adapt && !c->learning && c->lean_rest > 0 && n >= 4096) { --c->lean_rest; lean_now = false; }
+    bool lean_ran = false;
     const bool use_fast = use_scored || audit_lean || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast && !io.audit);
     // The plain run over tag lines (no detail arrays, no audit lists): the lean stage's back half, the caption offsets and the
     // caption bytes are one kernel (k_lean_bx); the stages behind the front half run before it, so that every file's caption
     // length is known or computed there.
-    const bool fused = allow_fused && use_fast && !use_scored && !audit_lean && c->use_lean && io.mode == 0 && !io.fired && !io.facet_choice && !c->no_fused;
+    const bool fused = allow_fused && use_fast && !use_scored && !audit_lean && lean_now && io.mode == 0 && !io.fired && !io.facet_choice && !c->no_fused;
     uint8_t* const sc_bytes = (uint8_t*)c->w->scalars.p;
     tp_counters* const d_bx_counters = (tp_counters*)(sc_bytes + 64);
     uint32_t* const d_ticket = (uint32_t*)(sc_bytes + 128);
@@ -282,14 +290,17 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
             c->w->slow_list0.need(n * 4);
             uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
             HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
-            fa.stage = 0; fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
-            hipEvent_t pm = next_event(), pe = next_event();
-            HIP_OK(launch_fast(c->dt, fa, s, pm));
-            record(pe);
-            if (st.timed) st.lean_ev.push_back({p0, pm, pe});
-            // what the lean stage declines: the general wave stages in audit mode (one token per lane, then two); the long-file
-            // stage keeps no lists, so what the second declines is the general kernel's
-            fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+            if (lean_now) {
+                fa.stage = 0; fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
+                hipEvent_t pm = next_event(), pe = next_event();
+                HIP_OK(launch_fast(c->dt, fa, s, pm));
+                record(pe);
+                if (st.timed) st.lean_ev.push_back({p0, pm, pe});
+                lean_ran = true;
+                // what the lean stage declines: the general wave stages in audit mode (one token per lane, then two); the long-file
+                // stage keeps no lists, so what the second declines is the general kernel's
+                fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+            }
             fa.stage = 1; fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
             HIP_OK(launch_fast(c->dt, fa, s));
             fa.stage = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
@@ -299,7 +310,8 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
         // through the long-file stage, and what is left to the general kernel.  Later stages learn their item counts on the device.
         fa.item_list = nullptr; fa.item_count = nullptr;
-        if (c->use_lean && io.mode == 0) {
+        if (lean_now) {
+            lean_ran = true;
             // stage 0: the lean stage takes the common shape of a file; the stages below see what it declines
             c->w->slow_list0.need(n * 4);
             uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
@@ -326,8 +338,10 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         record(p1);
         if (st.timed) st.fast_ev.emplace_back(p0, p1);
         HIP_OK(hipMemcpyAsync(&c->host_scalars[0], d_slow_count, 4, hipMemcpyDeviceToHost, s));
+        if (lean_ran) HIP_OK(hipMemcpyAsync(&c->host_scalars[3], (uint32_t*)(d_total + 6), 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         n_slow = (uint32_t)c->host_scalars[0];
+        if (lean_ran && n >= 4096) c->lean_rest = (uint64_t)(uint32_t)c->host_scalars[3] * 4 > n * 3 ? 15 : 0;   // it took less than a quarter: rest
         item_list = c->w->slow_list.as<uint32_t>();
     }
     const bool want_ids = use_fast || (io.histogram != nullptr && io.mode == 0);   // rows of tag ids: the wave kernels' output, and what the histogram kernel counts
@@ -878,6 +892,7 @@ void load_tables(tp_ctx* c, const std::vector<std::string>* learned) {
     compute_fallback(c);
     c->use_lean = lean_ok(c->dt);
     if (const char* b = std::getenv("TAGPIPE_NO_LEAN")) if (b[0] == '1') c->use_lean = false;
+    if (const char* b = std::getenv("TAGPIPE_LEAN_ADAPT")) c->lean_adapt = b[0] != '0';
     c->dt_dev.need(sizeof(DevTables));
     HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));
     for (void* p : old_mem) (void)hipFree(p);
