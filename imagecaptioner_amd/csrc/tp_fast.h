@@ -758,6 +758,66 @@ TP_HD __attribute__((always_inline)) bool fast_tail(W& w, const DevTables& t, Ba
         own0 = lane < nf ? L.fin[lane] : NO_ID;
         own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
         gnext[0] = own0; gnext[1] = own1;                          // NormalizeTag leaves every element alone
+    } else if (t.closure_tables && t.reach_levels_ok) {
+        // Every element brings the list of its own closure in the order ExpandImpliedTags appends it, with the round of each
+        // entry (DevTables::reach_ent, or the two steps of its record); a round's additions over all elements are ordered by
+        // element, then by place in the element's list, and a string counts where it comes first.  So every entry goes into
+        // the set under the key (round, element, place), and the lowest key of a string stays in its slot; afterwards the
+        // slots that are not the elements' own hold exactly the strings to append, and the keys' order is their order:
+        // one trip to the tables for all rounds together instead of one per round.
+        set_clear(w, L);
+        if (lane < nf) { bool created; set_put(w, L, own0, 0, created); }   // nf <= 64 here, and 256 slots cannot fill up
+        const uint32_t nf_seeds = nf;
+        Rec rs;
+        rs.flags = 0; rs.next = EMPTY_ID; rs.step_cnt = 0; rs.step0 = rs.step1 = NO_ID;
+        uint32_t e0 = 0, e1 = 0;
+        if (lane < nf) { rs = t.rec[own0]; e0 = t.reach_off[own0]; e1 = t.reach_off[own0 + 1]; }
+        w.sync();
+        gnext[0] = rs.next; gflags[0] = rs.flags;
+        const bool edge = lane < nf && (rs.flags & FL_EDGE) != 0;
+        if (w.ballot(edge)) {
+            const bool own_steps = (rs.flags & FL_REACH2) != 0;
+            const uint32_t ne = !edge ? 0u : own_steps ? (rs.step_cnt < 2 ? rs.step_cnt : 2u) : e1 - e0;
+            bool full = ne > 0xFFFFu;
+            for (uint32_t k0 = 0; k0 < ne && !full; k0 += 4) {          // four entries' loads at a time
+                uint32_t id[4], round[4];
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (k0 + j < ne) {
+                        if (own_steps) { id[j] = k0 + j ? rs.step1 : rs.step0; round[j] = 1; }
+                        else { const uint64_t e = *(const uint64_t*)(t.reach_ent + 2 * (size_t)(e0 + k0 + j)); id[j] = (uint32_t)e; round[j] = (uint32_t)(e >> 58); }
+                    }
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (k0 + j < ne) { bool created; if (set_put(w, L, id[j], round[j] << 24 | lane << 16 | (k0 + j), created) == NO_ID) full = true; }
+            }
+            if (w.ballot(full)) return false;
+            w.sync();
+            // the new strings: four slots per lane; their keys and ids side by side in the (unused on this path) flag and
+            // length columns, then every new string's place is the number of new strings with a lower key
+            uint32_t wid[4], wkey[4], mine = 0;
+            for (uint32_t j = 0; j < 4; ++j) {
+                wid[j] = L.set_key[4 * lane + j]; wkey[j] = L.set_min[4 * lane + j];
+                if (wid[j] == NO_ID || wkey[j] == 0) wkey[j] = 0xFFFFFFFFu; else ++mine;
+            }
+            const uint32_t incl = w.scan_incl(mine), grown = w.bcast(incl, 63);
+            if (nf + grown > FIN_MAX) return false;
+            uint32_t at = incl - mine;
+            for (uint32_t j = 0; j < 4; ++j) if (wkey[j] != 0xFFFFFFFFu) L.fattr[at++] = wkey[j];
+            w.sync();
+            uint32_t rank[4] = {0, 0, 0, 0};
+            for (uint32_t i = 0; i < grown; ++i) {
+                const uint32_t k = L.fattr[i];
+                for (uint32_t j = 0; j < 4; ++j) rank[j] += (uint32_t)(k < wkey[j]);
+            }
+            for (uint32_t j = 0; j < 4; ++j) if (wkey[j] != 0xFFFFFFFFu) { L.fin[nf + rank[j]] = wid[j]; L.set_min[4 * lane + j] = 0; }
+            nf += grown;
+            w.sync();
+            own0 = lane < nf ? L.fin[lane] : NO_ID;
+            own1 = lane + 64 < nf ? L.fin[lane + 64] : NO_ID;
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < NF) {          // NormalizeTag and flags of what the closure added
+                const uint32_t idx = (uint32_t)blk * 64 + lane;
+                if (idx >= nf_seeds && idx < nf) { const Rec ra = t.rec[blk == 0 ? own0 : own1]; gnext[blk] = ra.next; gflags[blk] = ra.flags; }
+            }
+        }
     } else {
         set_clear(w, L);
         if (lane < nf) { bool created; set_put(w, L, own0, 0, created); }   // nf <= 64 here, and 256 slots cannot fill up
@@ -1450,7 +1510,12 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                         if (r2[blk].step_cnt > 0) add(r2[blk].step0, r2[blk].s0_info);
                         if (r2[blk].step_cnt > 1) add(r2[blk].step1, r2[blk].s1_info);
                     } else {
-                        for (uint32_t m = t.reach_off[t2[blk]]; m < t.reach_off[t2[blk] + 1] && !full; ++m) add(t.reach_ent[2 * m], t.reach_ent[2 * m + 1]);
+                        const uint32_t m1 = t.reach_off[t2[blk] + 1];
+                        for (uint32_t m = t.reach_off[t2[blk]]; m < m1 && !full; m += 4) {      // four entries' loads at a time
+                            uint64_t e[4];
+                            for (uint32_t j = 0; j < 4; ++j) if (m + j < m1) e[j] = *(const uint64_t*)(t.reach_ent + 2 * (size_t)(m + j));
+                            for (uint32_t j = 0; j < 4; ++j) if (m + j < m1) add((uint32_t)e[j], (uint32_t)(e[j] >> 32));
+                        }
                     }
                 }
             }
