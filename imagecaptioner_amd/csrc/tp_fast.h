@@ -1480,6 +1480,29 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                     ev_penis |= ((i0 | i1) >> 25) & 1u;
                 }
             }
+        } else if (!count && t.closure_tables) {
+            // nobody asks how many: the literals and the feet / penis facts of every closure member, no set
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < nblk) {
+                if (ev_seed[blk] && (r2[blk].flags & FL_EDGE)) {
+                    auto note = [&](uint32_t info) {
+                        const uint32_t li = info & 0xFFFFFFu;
+                        if (li != 0xFFFFFFu) w.lds_or(&L.ebits[li >> 5], 1u << (li & 31));
+                        ev_feet |= (info >> 24) & 1u;
+                        ev_penis |= (info >> 25) & 1u;
+                    };
+                    if (r2[blk].flags & FL_REACH2) {
+                        if (r2[blk].step_cnt > 0) note(r2[blk].s0_info);
+                        if (r2[blk].step_cnt > 1) note(r2[blk].s1_info);
+                    } else {
+                        const uint32_t m1 = t.reach_off[t2[blk] + 1];
+                        for (uint32_t m = t.reach_off[t2[blk]]; m < m1; m += 4) {              // four entries' loads at a time
+                            uint32_t info[4];
+                            for (uint32_t j = 0; j < 4; ++j) if (m + j < m1) info[j] = t.reach_ent[2 * (size_t)(m + j) + 1];
+                            for (uint32_t j = 0; j < 4; ++j) if (m + j < m1) note(info[j]);
+                        }
+                    }
+                }
+            }
         } else {
             if (m_far && !t.closure_tables) return false;
             set_clear(w, L);
