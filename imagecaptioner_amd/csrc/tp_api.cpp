@@ -179,6 +179,7 @@ struct tp_ctx {
     // wave stages directly, then one range tries it again.  Results do not depend on it (TAGPIPE_LEAN_ADAPT=0: always try).
     bool lean_adapt = true;
     int lean_rest = 0;
+    bool stage1_idle = false;        // the first general wave stage took under a tenth of what the lean stage declined in the last range: a small grid for it
     bool no_fused = true;            // TAGPIPE_FUSED=1: the plain run's back half, caption offsets and caption bytes as ONE kernel (k_lean_bx).  Off by default:
                                      // measured on c2 (1M files) the fused kernel takes 2.86 ms where k_lean_b + scan + k_emit_runs take 2.2 ms
     uint64_t fused_reruns = 0;       // ranges the fused back half had to hand back to the separate kernels
@@ -268,6 +269,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
     if (use_fast) {
         c->w->fin32.need(n * fast_fin_stride() * 4);
         c->w->slow_list.need(n * 4);
+        c->w->slow_list0.need(n * 4);
         c->w->slow_list1.need(n * 4);
         c->w->slow_list2.need(n * 4);
         uint32_t* d_slow_count1 = d_slow_count + 1;
@@ -322,26 +324,45 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
             HIP_OK(launch_fast(c->dt, fa, s, pm));
             record(pe);
             if (st.timed) st.lean_ev.push_back({p0, pm, pe});
+            HIP_OK(hipMemcpyAsync(&c->host_scalars[3], d_slow_count0, 4, hipMemcpyDeviceToHost, s));   // how many it declined (the counter is used again below)
             bxa = fa;
             fa.front_only = 0;
             fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
         }
         fa.stage = 1; fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
+        fa.grid_cap = lean_ran && c->stage1_idle ? 512u : 0u;     // (a stage that took next to nothing of its list last time: blocks cost their set-up)
         HIP_OK(launch_fast(c->dt, fa, s));
+        fa.grid_cap = 0;
+        if (lean_ran) HIP_OK(hipMemcpyAsync(&c->host_scalars[4], d_slow_count1, 4, hipMemcpyDeviceToHost, s));   // how many of them it handed on
         fa.stage = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
         fa.slow_list = c->w->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
         HIP_OK(launch_fast(c->dt, fa, s));
-        fa.stage = 3; fa.item_list = c->w->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
+        // third stage, three sizes of per-file state (smallest first: more files at once); the first two stages' lists and
+        // counters have been read by now and take what the sizes hand on
+        uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);
+        HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
+        HIP_OK(hipMemsetAsync(d_slow_count1, 0, 4, s));
+        fa.stage = 3; fa.long_size = 0; fa.item_list = c->w->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
+        fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0;
+        HIP_OK(launch_fast(c->dt, fa, s));
+        fa.long_size = 1; fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+        fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
+        HIP_OK(launch_fast(c->dt, fa, s));
+        fa.long_size = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
         fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
         HIP_OK(launch_fast(c->dt, fa, s));
         }
         record(p1);
         if (st.timed) st.fast_ev.emplace_back(p0, p1);
         HIP_OK(hipMemcpyAsync(&c->host_scalars[0], d_slow_count, 4, hipMemcpyDeviceToHost, s));
-        if (lean_ran) HIP_OK(hipMemcpyAsync(&c->host_scalars[3], (uint32_t*)(d_total + 6), 4, hipMemcpyDeviceToHost, s));
+        if (lean_ran && audit_lean) HIP_OK(hipMemcpyAsync(&c->host_scalars[3], (uint32_t*)(d_total + 6), 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         n_slow = (uint32_t)c->host_scalars[0];
-        if (lean_ran && n >= 4096) c->lean_rest = (uint64_t)(uint32_t)c->host_scalars[3] * 4 > n * 3 ? 15 : 0;   // it took less than a quarter: rest
+        if (lean_ran && n >= 4096) {
+            const uint64_t declined = (uint32_t)c->host_scalars[3];
+            c->lean_rest = declined * 4 > n * 3 ? 15 : 0;          // it took less than a quarter: rest
+            if (!audit_lean) c->stage1_idle = declined >= 1024 && ((uint64_t)(uint32_t)c->host_scalars[4]) * 10 > declined * 9;   // the stage behind it handed on over nine in ten
+        }
         item_list = c->w->slow_list.as<uint32_t>();
     }
     const bool want_ids = use_fast || (io.histogram != nullptr && io.mode == 0);   // rows of tag ids: the wave kernels' output, and what the histogram kernel counts
@@ -445,7 +466,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
                     fb.stage = 2; fb.item_list = c->w->slow_list1.as<uint32_t>(); fb.item_count = d_slow_count + 1;
                     fb.slow_list = c->w->slow_list2.as<uint32_t>(); fb.slow_count = d_slow_count + 2;
                     HIP_OK(launch_fast(c->dt, fb, s));
-                    fb.stage = 3; fb.item_list = c->w->slow_list2.as<uint32_t>(); fb.item_count = d_slow_count + 2;
+                    fb.stage = 3; fb.long_size = 2; fb.item_list = c->w->slow_list2.as<uint32_t>(); fb.item_count = d_slow_count + 2;
                     fb.slow_list = c->w->slow_list0.as<uint32_t>(); fb.slow_count = d_slow_count0;
                     HIP_OK(launch_fast(c->dt, fb, s));
                     HIP_OK(hipMemcpyAsync(&c->host_scalars[5], d_slow_count0, 4, hipMemcpyDeviceToHost, s));

@@ -1822,41 +1822,52 @@ struct ScoredFront {
 // candidate alone (otherwise two candidates may merge, which this path does not follow): everything else goes to the
 // general kernel.
 // ================================================================================================================
+// The state is sized three ways (tokens, line bytes): a wavefront's latencies are hidden by the other wavefronts of its SIMD,
+// and how many of those there are is a matter of how many files' state fits the CU's LDS (44 KB each for the largest size:
+// three to a CU; 16 KB for the smallest: ten).
 constexpr uint32_t LONG_LINE_MAX = 8192;
 constexpr uint32_t LONG_TOK_MAX = 1024;
-constexpr uint32_t LONG_SET_SLOTS = 2048;
 
-struct alignas(16) LongLds : LineLds<LONG_LINE_MAX, LONG_TOK_MAX> {
-    uint32_t big_key[LONG_SET_SLOTS];    // token ids, for the first-occurrence filter (Distinct, Program.cs:602)
-    uint32_t big_min[LONG_SET_SLOTS];    // ... smallest token index per id
-    uint32_t c_id[LONG_TOK_MAX];         // per token: the id NormalizeTag gives it, NO_ID when it is no candidate (any more)
-    uint32_t c_fl[LONG_TOK_MAX];         // that string's flags
-    uint16_t c_len[LONG_TOK_MAX];        // its byte length
-    uint16_t c_slot[LONG_TOK_MAX];       // its slot in the big set
+template <uint32_t LINE, uint32_t TOK>
+struct alignas(16) LongLdsT : LineLds<LINE, TOK> {
+    static constexpr uint32_t SET_SLOTS = 2 * TOK;
+    uint32_t big_key[SET_SLOTS];         // token ids, for the first-occurrence filter (Distinct, Program.cs:602)
+    uint32_t big_min[SET_SLOTS];         // ... smallest token index per id
+    uint32_t c_id[TOK];                  // per token: the id NormalizeTag gives it, NO_ID when it is no candidate (any more)
+    uint32_t c_fl[TOK];                  // that string's flags
+    uint16_t c_len[TOK];                 // its byte length
+    uint16_t c_slot[TOK];                // its slot in the big set
 };
+typedef LongLdsT<LONG_LINE_MAX, LONG_TOK_MAX> LongLds;           // the largest size
+typedef LongLdsT<LONG_LINE_MAX, 512> LongLds512;
+typedef LongLdsT<4096, 256> LongLds256;
 
-template <class W>
-TP_HD uint32_t big_put(W& w, LongLds& L, uint32_t key, uint32_t order) {
-    uint32_t s = (key * 2654435761u) >> 21;                        // 11 bits
-    for (uint32_t probe = 0; probe < LONG_SET_SLOTS; ++probe) {
+template <class W, class LL>
+TP_HD uint32_t big_put(W& w, LL& L, uint32_t key, uint32_t order) {
+    static_assert((LL::SET_SLOTS & (LL::SET_SLOTS - 1)) == 0, "a power of two");
+    uint32_t s = ((key * 2654435761u) >> 16) & (LL::SET_SLOTS - 1);
+    for (uint32_t probe = 0; probe < LL::SET_SLOTS; ++probe) {
         uint32_t old = w.lds_cas(&L.big_key[s], NO_ID, key);
         if (old == NO_ID || old == key) { w.lds_min(&L.big_min[s], order); return s; }
-        s = (s + 1) & (LONG_SET_SLOTS - 1);
+        s = (s + 1) & (LL::SET_SLOTS - 1);
     }
     return NO_ID;
 }
 
-template <class W>
-TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
+template <class W, class LL>
+TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
                      uint32_t* fired, uint16_t* facet_choice, bool triage = false) {
+    constexpr uint32_t TOK_MAX = LL::TOK_CAP;
     const uint32_t lane = w.lane();
+    w.tick(0);
     Scan sc;
     if (!scan_line<true>(w, L, cls, text, len, sc)) return false;
     const uint8_t* s = sc.s;
     const uint32_t T = sc.ncomma + 1;
-    if (T > LONG_TOK_MAX) return false;
-    static_assert(LONG_SET_SLOTS == 2048, "32 words per lane and array");
-    for (uint32_t k = 0; k < 8; ++k) { w.fill16(&L.big_key[256 * k + 4 * lane], 0xFFFFFFFFu); w.fill16(&L.big_min[256 * k + 4 * lane], 0xFFFFFFFFu); }
+    if (T > TOK_MAX) return false;
+    w.tick(25);
+    static_assert(LL::SET_SLOTS % 256 == 0, "four words per lane and step");
+    for (uint32_t k = 0; k < LL::SET_SLOTS / 256; ++k) { w.fill16(&L.big_key[256 * k + 4 * lane], 0xFFFFFFFFu); w.fill16(&L.big_min[256 * k + 4 * lane], 0xFFFFFFFFu); }
     w.sync();
 
     // ---- tokens -> ids (Program.cs:598-602), 64 at a time -------------------------------------------------------------------
@@ -1889,10 +1900,11 @@ TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, c
                 if (!t.drop_unknown && dlen >= 2 && vdyn) decline = true;   // a string outside the tables would survive
             }
         }
-        if (tix < LONG_TOK_MAX) L.c_id[tix] = cid;
+        if (tix < TOK_MAX) L.c_id[tix] = cid;
     }
     if (w.ballot(decline)) return false;
     w.sync();
+    w.tick(26);
     if (triage) {
         // Existing-caption triage: LooksBad of the kept tags joined with ", " (Program.cs:206-207, 604, 1141-1147)
         uint32_t k = 0, units = 0;
@@ -1984,6 +1996,7 @@ TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, c
     ev_feet = w.ballot(ev_feet) != 0;
     ev_penis = w.ballot(ev_penis) != 0;
     w.sync();
+    w.tick(27);
 
     // ---- bucket fills (Program.cs:661-699): every bucket walks the candidates in order -------------------------------------------
     const int style_cap = style_n < 2 ? 2 : (style_n > 4 ? 4 : (int)style_n);
@@ -2012,6 +2025,7 @@ TP_HD bool long_file(W& w, const DevTables& t, LongLds& L, const uint32_t* rc, c
     }
     w.sync();
 
+    w.tick(28);
     auto evidence = [&](uint32_t& ne, bool& feet, bool& penis) -> bool { ne = n_evidence; feet = ev_feet; penis = ev_penis; return true; };
     TailIn ti;
     ti.nr = nr; ti.n = n; ti.n_selected = nr; ti.n_dropped = n_dropped;

@@ -109,6 +109,25 @@ struct DevWave {
     __device__ void fill16(uint32_t* lds_dst, uint32_t v) const { *(uint4*)lds_dst = make_uint4(v, v, v, v); }
 };
 
+// The commas of a text, counted by the whole wavefront eight bytes per lane and step (aligned words; what they hold beyond the
+// text's ends is masked out).
+__device__ inline uint32_t wave_count_commas(const uint8_t* p, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u, shift = (uint32_t)((uintptr_t)p & 7);
+    const uint64_t* base = (const uint64_t*)(p - shift);
+    const uint32_t words = (shift + n + 7) >> 3;
+    uint32_t c = 0;
+    for (uint32_t i = lane; i < words; i += 64) {
+        uint64_t x = base[i] ^ 0x2C2C2C2C2C2C2C2Cull;               // a zero byte where the text holds ','
+        uint64_t z = (x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full;
+        z = ~(z | x | 0x7F7F7F7F7F7F7F7Full);                        // bit 7 of every zero byte
+        const uint32_t lo = i == 0 ? shift : 0u, hi = (i + 1) * 8 > shift + n ? shift + n - i * 8 : 8u;   // bytes [lo, hi) of the word are text
+        if (lo) z &= ~0ull << (8 * lo);
+        if (hi < 8) z &= ~(~0ull << (8 * hi));
+        c += (uint32_t)__popcll(z);
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(c), 63);
+}
+
 constexpr int FAST_WAVES_PER_BLOCK = 4;
 
 // The files a wavefront declines, handed on in batches: one atomic on the list's counter per DECLINE_BATCH files instead
@@ -145,23 +164,39 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
     __shared__ uint8_t cls[256];                                // byte classes of the line scan
     extern __shared__ uint32_t rc_lds[];                        // the rule cache, t.rc_words words (dynamic LDS)
     if (a.item_list && (uint64_t)blockIdx.x * FAST_WAVES_PER_BLOCK >= (uint64_t)*a.item_count) return;   // a later stage with nothing left for this block
-    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
-    __syncthreads();
     __shared__ DeclineBuf dbuf[FAST_WAVES_PER_BLOCK];
     uint32_t n_declined = 0;
-    FastLds& L = lds[wave_in_block()];
     DevWave w;
     const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n_items = a.item_list ? (uint64_t)*a.item_count : a.file_end - a.file0;
+    // A stage that works through an earlier stage's list: most of what reaches it and is not its to take has too many tokens,
+    // which a count of the commas shows for a fraction of the line scan.  A block none of whose files fits hands them on before
+    // it has set anything up (the rule cache is 18 KB with a few hundred rules, and such blocks can be most of the grid).
+    auto fits = [&](uint64_t f) {
+        const uint64_t o = a.offsets[f], len64 = a.offsets[f + 1] - o;
+        return len64 <= FAST_LINE_MAX && !(a.item_list && wave_count_commas(a.arena + o, (uint32_t)len64) >= 64u * NT);
+    };
+    if (a.item_list) {
+        bool any = false;
+        for (uint64_t i = wave_global; i < n_items && !any; i += n_waves) any = fits(a.file0 + a.item_list[i]);
+        if (!__syncthreads_or(any ? 1 : 0)) {
+            for (uint64_t i = wave_global; i < n_items; i += n_waves) decline_push(dbuf[wave_in_block()], n_declined, a.item_list[i], a.slow_list, a.slow_count);
+            decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
+            return;
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
+    __syncthreads();
+    FastLds& L = lds[wave_in_block()];
     for (uint64_t i = wave_global; i < n_items; i += n_waves) {
         const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
         uint64_t o = a.offsets[f];
         uint64_t len64 = a.offsets[f + 1] - o;
         bool done = false;
         FastOut out;
-        if (len64 <= FAST_LINE_MAX) {
+        if (fits(f)) {
             LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
             if (AUD) { const uint64_t r = f - a.file0; aud.row = a.aud32 + r * AUD_STRIDE; aud.cnt = a.audit_cnt + r * AUDIT_COLS; aud.len = a.audit_len + r * AUDIT_COLS; aud.rbits = a.review_bits + r; }
             done = fast_file<NT, 2, DevWave, LineFront, AUD>(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
@@ -384,13 +419,15 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
     decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
 }
 
-// Third stage: the files the second declined, up to LONG_TOK_MAX tokens in LONG_LINE_MAX bytes; one wavefront per block.
-template <bool TR>
+// Third stage: the files the second declined, up to LL::TOK_CAP tokens in LL::LINE_CAP bytes (three sizes, smallest first: what
+// one declines for its size the next takes); one wavefront per block.
+template <bool TR, class LL>
 __device__ __forceinline__ void long_body(const DevTables& t, const FastArgs& a) {
-    __shared__ LongLds L;
+    __shared__ LL L;
     __shared__ uint8_t cls[256];
-    extern __shared__ uint32_t rc_lds[];
-    for (uint32_t i = threadIdx.x; i < t.rc_words; i += blockDim.x) rc_lds[i] = t.rc[i];
+    // The rule cache stays in device memory here: a copy per one-wavefront block (18 KB with a few hundred rules) would decide
+    // how many files a CU holds at once, and a long file reads it once for hundreds of tokens.
+    const uint32_t* rc_lds = t.rc;
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = byte_class(i);
     __syncthreads();
     DevWave w;
@@ -401,7 +438,7 @@ __device__ __forceinline__ void long_body(const DevTables& t, const FastArgs& a)
         uint64_t len64 = a.offsets[f + 1] - o;
         bool done = false;
         FastOut out;
-        if (len64 <= LONG_LINE_MAX) {
+        if (len64 <= LL::LINE_CAP && (LL::TOK_CAP == LONG_TOK_MAX || wave_count_commas(a.arena + o, (uint32_t)len64) < LL::TOK_CAP)) {
             done = long_file(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
                              a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR);
         }
@@ -418,9 +455,16 @@ __device__ __forceinline__ void long_body(const DevTables& t, const FastArgs& a)
         }
         w.sync();
     }
+#ifdef TP_PROF
+    w.flush();
+#endif
 }
-__global__ __launch_bounds__(64) void k_long(DevTables t, FastArgs a) { long_body<false>(t, a); }
-__global__ __launch_bounds__(64) void k_long_triage(DevTables t, FastArgs a) { long_body<true>(t, a); }
+__global__ __launch_bounds__(64) void k_long(DevTables t, FastArgs a) { long_body<false, LongLds>(t, a); }
+__global__ __launch_bounds__(64) void k_long512(DevTables t, FastArgs a) { long_body<false, LongLds512>(t, a); }
+__global__ __launch_bounds__(64) void k_long256(DevTables t, FastArgs a) { long_body<false, LongLds256>(t, a); }
+__global__ __launch_bounds__(64) void k_long_triage(DevTables t, FastArgs a) { long_body<true, LongLds>(t, a); }
+__global__ __launch_bounds__(64) void k_long512_triage(DevTables t, FastArgs a) { long_body<true, LongLds512>(t, a); }
+__global__ __launch_bounds__(64) void k_long256_triage(DevTables t, FastArgs a) { long_body<true, LongLds256>(t, a); }
 
 // ------------------------------------------------------------------------------------------------
 // k_wave_sizes
@@ -1493,7 +1537,7 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
     static const unsigned after_lean1 = env_blocks("TAGPIPE_AFTER_LEAN_BLOCKS", 256u * 16u);
     static const unsigned after_lean2 = env_blocks("TAGPIPE_AFTER_LEAN_BLOCKS2", 512u);
     const bool after_lean = a.tables != nullptr && a.stage >= 1 && a.stage <= 3;
-    const unsigned cap = after_lean ? (a.stage == 1 ? after_lean1 : after_lean2) : (a.stage == 1 ? max_blocks : 256u * 8u);
+    const unsigned cap = a.grid_cap ? a.grid_cap : after_lean ? (a.stage == 1 ? after_lean1 : after_lean2) : (a.stage == 1 ? max_blocks : 256u * 8u);
     unsigned blocks = (unsigned)(want < cap ? want : cap);
     const bool tr = a.triage != 0;
     if (a.stage == 0) {
@@ -1512,7 +1556,15 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
         else hipLaunchKernelGGL(k_lean_b, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
     } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 3 && a.aud32) return hipErrorInvalidValue;   // the long-file stage keeps no audit lists: the caller hands its files to the general kernel
-    else if (a.stage == 3) hipLaunchKernelGGL(tr ? k_long_triage : k_long, dim3((unsigned)(n < (after_lean ? after_lean2 : 4096u) ? n : (after_lean ? after_lean2 : 4096u))), dim3(64), t.rc_words * sizeof(uint32_t), s, t, a);
+    else if (a.stage == 3) {
+        // as many one-wavefront blocks as the CUs hold at once for the size's LDS (the grid strides over the list)
+        const unsigned per_cu = a.long_size == 0 ? 9u : a.long_size == 1 ? 5u : 3u;
+        const dim3 grid((unsigned)(n < 256u * per_cu ? n : 256u * per_cu));
+        const size_t dyn = 0;
+        if (a.long_size == 0) hipLaunchKernelGGL(tr ? k_long256_triage : k_long256, grid, dim3(64), dyn, s, t, a);
+        else if (a.long_size == 1) hipLaunchKernelGGL(tr ? k_long512_triage : k_long512, grid, dim3(64), dyn, s, t, a);
+        else hipLaunchKernelGGL(tr ? k_long_triage : k_long, grid, dim3(64), dyn, s, t, a);
+    }
     else if (a.stage == 2) hipLaunchKernelGGL(a.aud32 ? k_fast2_audit : tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(a.aud32 ? k_fast_audit : tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     return hipGetLastError();

@@ -27,6 +27,16 @@ def main():
     cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
     corpus = make_corpus(cfgname, n, seed=1234)
+    min_tokens = int(os.environ.get("PROF_MIN_TOKENS", "0"))        # only the files with at least so many tokens (the long-file stage's share)
+    if min_tokens:
+        o = corpus.offsets.astype(np.int64)
+        commas = np.add.reduceat((corpus.arena == ord(",")).astype(np.int64), o[:-1])
+        keep = np.nonzero(commas + 1 >= min_tokens)[0]
+        lens = (o[1:] - o[:-1])[keep]
+        arena = np.concatenate([corpus.arena[o[i]:o[i + 1]] for i in keep])
+        corpus.arena, corpus.offsets = arena, np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        n = len(keep)
+        print("files with >=", min_tokens, "tokens:", n)
     pipe = TagPipe(Config(device=0, **corpus.config_kwargs))
     dev = torch.device("cuda", 0)
     arena = torch.cat([torch.from_numpy(corpus.arena).to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)])
@@ -59,6 +69,8 @@ def main():
         print("%-20s %6.2f %%  %8.0f cycles/file" % (name, 100.0 * buf[k + 1] / tot, buf[k + 1] / n))
     for k, name in enumerate(LEAN_NAMES):
         print("lean %-15s %6.2f %%  %8.0f cycles/file" % (name, 100.0 * buf[16 + k] / tot, buf[16 + k] / n))
+    for k, name in enumerate(["long scan", "long tokens", "long candidates+evidence", "long buckets"]):
+        print("%-26s %8.0f cycles/file" % (name, buf[25 + k] / n))
 
 
 if __name__ == "__main__":
