@@ -299,13 +299,26 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
                 record(pe);
                 if (st.timed) st.lean_ev.push_back({p0, pm, pe});
                 lean_ran = true;
-                // what the lean stage declines: the general wave stages in audit mode (one token per lane, then two); the long-file
-                // stage keeps no lists, so what the second declines is the general kernel's
+                // what the lean stage declines: the general wave stages in audit mode (one token per lane, then two, then the
+                // long-file stage); what they all decline is the general kernel's
                 fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
             }
             fa.stage = 1; fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
             HIP_OK(launch_fast(c->dt, fa, s));
             fa.stage = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
+            fa.slow_list = c->w->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
+            HIP_OK(launch_fast(c->dt, fa, s));
+            // the long-file stage, three sizes as in the plain run (the first two stages' lists and counters are free again)
+            if (lean_ran) HIP_OK(hipMemcpyAsync(&c->host_scalars[3], d_slow_count0, 4, hipMemcpyDeviceToHost, s));   // how many the lean stage declined
+            HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
+            HIP_OK(hipMemsetAsync(d_slow_count1, 0, 4, s));
+            fa.stage = 3; fa.long_size = 0; fa.item_list = c->w->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
+            fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0;
+            HIP_OK(launch_fast(c->dt, fa, s));
+            fa.long_size = 1; fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+            fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
+            HIP_OK(launch_fast(c->dt, fa, s));
+            fa.long_size = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
             fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
             HIP_OK(launch_fast(c->dt, fa, s));
         } else {
@@ -355,7 +368,6 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         record(p1);
         if (st.timed) st.fast_ev.emplace_back(p0, p1);
         HIP_OK(hipMemcpyAsync(&c->host_scalars[0], d_slow_count, 4, hipMemcpyDeviceToHost, s));
-        if (lean_ran && audit_lean) HIP_OK(hipMemcpyAsync(&c->host_scalars[3], (uint32_t*)(d_total + 6), 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         n_slow = (uint32_t)c->host_scalars[0];
         if (lean_ran && n >= 4096) {

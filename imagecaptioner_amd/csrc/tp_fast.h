@@ -1854,9 +1854,10 @@ TP_HD uint32_t big_put(W& w, LL& L, uint32_t key, uint32_t order) {
     return NO_ID;
 }
 
-template <class W, class LL>
+// AUD: audit mode - the file's other lists go to its audit row (LeanAudit), as fast_file leaves them.
+template <bool AUD = false, class W, class LL>
 TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
-                     uint32_t* fired, uint16_t* facet_choice, bool triage = false) {
+                     uint32_t* fired, uint16_t* facet_choice, bool triage = false, const LeanAudit aud = LeanAudit{nullptr, nullptr, nullptr, nullptr}) {
     constexpr uint32_t TOK_MAX = LL::TOK_CAP;
     const uint32_t lane = w.lane();
     w.tick(0);
@@ -1935,6 +1936,9 @@ TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const 
     uint32_t n = 0, n_dropped = 0, style_n = 0, made = 0;
     bool ev_feet = false, ev_penis = false, full = false, far_no_table = false;
     uint64_t any_edge = 0;
+    // audit mode: bytes of the dropped tags' and the first tagger tags' text, review bits, seeds so far and their bytes
+    uint32_t dbytes = 0, tbytes = 0, rb = 0, n_seed = 0, ebytes = 0;
+    if (AUD && (!t.reach_levels_ok || !count)) return false;
     for (uint32_t base = 0; base < T; base += 64) {
         const uint32_t tix = base + lane;
         const uint32_t id = tix < T ? L.c_id[tix] : NO_ID;
@@ -1945,6 +1949,18 @@ TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const 
         n += popc64(m);
         const bool nonblank = act && !(f & FL_BLANK);
         const bool bad = nonblank && (!(f & FL_VALID) || (f & FL_DROP));
+        if constexpr (AUD) {
+            // DroppedTagsWithReason in candidate order (Program.cs:630-631, 682), the first TOP_TAGS raw candidates (Program.cs:860),
+            // what BuildReviewRecord finds among the normalised raw candidates (Program.cs:827-837)
+            const uint64_t mb = w.ballot(bad);
+            if (n_dropped + popc64(mb) > AUD_TOP - AUD_DROPPED) return false;   // no room in the row
+            if (bad) { aud.row[AUD_DROPPED + n_dropped + w.rank(mb)] = id | ((f & FL_VALID) ? 0x80000000u : 0u); dbytes += (uint32_t)L.c_len[tix] + AUDIT_REASON_LEN; }
+            if (act && ci < (uint32_t)TOP_TAGS) { aud.row[AUD_TOP + ci] = id; tbytes += L.c_len[tix]; }
+            if (nonblank) {
+                rb |= (f & (FL_SUBJ_MALE | FL_SUBJ_GIRL | FL_SUBJ_MULTI)) >> 10;
+                if (f & FL_BANNED) for (int k = 0; k < N_BANNED; ++k) if (id == t.banned_ids[k]) rb |= 1u << k;
+            }
+        }
         n_dropped += popc64(w.ballot(bad));
         style_n += popc64(w.ballot(act && fl_bucket(f) == B_STYLE && ci < t.style_ci_limit));
         const bool ok = nonblank && !bad && !(f & FL_PREFIX);      // AddOne's tests; prefix tags are already in
@@ -1962,9 +1978,17 @@ TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const 
             }
             const bool edge = seed && (r.flags & FL_EDGE);
             any_edge |= w.ballot(edge);
+            // audit mode: the set's order values make the evidence list (see fast_file): a seed's is its place among the seeds,
+            // a closure member's (round, seed, place in the seed's list)
+            const uint32_t spos = n_seed + w.rank(m_seed);
+            n_seed += popc64(m_seed);
+            uint32_t place = 0;
             auto add = [&](uint32_t x, uint32_t info) {            // one member of a seed's closure
                 bool created = true;
-                if (count) { if (set_put(w, L, x, 0, created) == NO_ID) { full = true; return; } }
+                const uint32_t order = AUD ? ((info >> 26) ? (info >> 26) : 1u) << 24 | spos << 16 | place : 0u;
+                if (AUD && place > 0xFFFFu) { full = true; return; }
+                ++place;
+                if (count) { if (set_put(w, L, x, order, created) == NO_ID) { full = true; return; } }
                 if (created) {
                     ++made;
                     const uint32_t li = info & 0xFFFFFFu;
@@ -1973,12 +1997,13 @@ TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const 
                 ev_feet |= (info >> 24) & 1u;
                 ev_penis |= (info >> 25) & 1u;
             };
-            if (count && seed) { bool created; if (set_put(w, L, id, 0, created) == NO_ID) full = true; made += created; }
+            if (count && seed) { bool created; if (set_put(w, L, id, AUD ? spos : 0u, created) == NO_ID) full = true; made += created; }
+            if constexpr (AUD) { if (seed) { aud.row[AUD_EVIDENCE + spos] = id; ebytes += L.c_len[tix]; } }
             w.sync();
             if (edge) {
-                if (r.flags & FL_REACH2) {
-                    if (r.step_cnt > 0) add(r.step0, r.s0_info);
-                    if (r.step_cnt > 1) add(r.step1, r.s1_info);
+                if (r.flags & FL_REACH2) {                          // (its two steps belong to the first round)
+                    if (r.step_cnt > 0) add(r.step0, r.s0_info & 0x3FFFFFFu);
+                    if (r.step_cnt > 1) add(r.step1, r.s1_info & 0x3FFFFFFu);
                 } else if (!t.closure_tables) {
                     far_no_table = true;
                 } else {
@@ -1996,6 +2021,37 @@ TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const 
     ev_feet = w.ballot(ev_feet) != 0;
     ev_penis = w.ballot(ev_penis) != 0;
     w.sync();
+    if constexpr (AUD) {
+        // the evidence list behind the seeds: the set's slots whose order value is a closure member's hold exactly the strings
+        // the rounds append, and the order values' order is theirs (four slots per lane; the keys side by side in the big
+        // set's array, which nothing reads any more)
+        if (n_evidence > AUD_DROPPED - AUD_EVIDENCE) return false;
+        uint32_t wid[4], wkey[4], mine = 0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            wid[j] = L.set_key[4 * lane + j]; wkey[j] = L.set_min[4 * lane + j];
+            if (wid[j] == NO_ID || wkey[j] < (1u << 24)) wkey[j] = 0xFFFFFFFFu; else ++mine;
+        }
+        const uint32_t incl = w.scan_incl(mine), grown = w.bcast(incl, 63);
+        uint32_t at = incl - mine;
+        for (uint32_t j = 0; j < 4; ++j) if (wkey[j] != 0xFFFFFFFFu) L.big_key[at++] = wkey[j];
+        w.sync();
+        uint32_t rank[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < grown; ++i) {
+            const uint32_t k = L.big_key[i];
+            for (uint32_t j = 0; j < 4; ++j) rank[j] += (uint32_t)(k < wkey[j]);
+        }
+        for (uint32_t j = 0; j < 4; ++j) if (wkey[j] != 0xFFFFFFFFu) { aud.row[AUD_EVIDENCE + n_seed + rank[j]] = wid[j]; ebytes += t.attr2[2 * (size_t)wid[j] + 1]; }
+        const uint32_t total = n_seed + grown;
+        dbytes = w.sum(dbytes); tbytes = w.sum(tbytes); ebytes = w.sum(ebytes);
+        const uint32_t rbits = w.or_all(rb), ntop = n < (uint32_t)TOP_TAGS ? n : (uint32_t)TOP_TAGS;
+        if (lane == 0) {
+            aud.cnt[AUDIT_EVIDENCE] = total; aud.len[AUDIT_EVIDENCE] = ebytes + (total ? total - 1 : 0u);
+            aud.cnt[AUDIT_DROPPED] = n_dropped; aud.len[AUDIT_DROPPED] = dbytes + (n_dropped ? n_dropped - 1 : 0u);
+            aud.cnt[AUDIT_TOP] = ntop; aud.len[AUDIT_TOP] = tbytes + (ntop ? ntop - 1 : 0u);
+            *aud.rbits = rbits;
+        }
+        w.sync();
+    }
     w.tick(27);
 
     // ---- bucket fills (Program.cs:661-699): every bucket walks the candidates in order -------------------------------------------
@@ -2030,7 +2086,7 @@ TP_HD bool long_file(W& w, const DevTables& t, LL& L, const uint32_t* rc, const 
     TailIn ti;
     ti.nr = nr; ti.n = n; ti.n_selected = nr; ti.n_dropped = n_dropped;
     ti.settled = false; ti.rejected = sc.rejected; ti.kid = nullptr;
-    return fast_tail<2>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice);
+    return fast_tail<2, AUD>(w, t, L, rc, ti, evidence, out, fin32, fired, facet_choice, aud);
 }
 
 }  // namespace tp

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
 
 // Third stage: the files the second declined, up to LL::TOK_CAP tokens in LL::LINE_CAP bytes (three sizes, smallest first: what
 // one declines for its size the next takes); one wavefront per block.
-template <bool TR, class LL>
+template <bool TR, class LL, bool AUD = false>
 __device__ __forceinline__ void long_body(const DevTables& t, const FastArgs& a) {
     __shared__ LL L;
     __shared__ uint8_t cls[256];
@@ -439,8 +439,10 @@ __device__ __forceinline__ void long_body(const DevTables& t, const FastArgs& a)
         bool done = false;
         FastOut out;
         if (len64 <= LL::LINE_CAP && (LL::TOK_CAP == LONG_TOK_MAX || wave_count_commas(a.arena + o, (uint32_t)len64) < LL::TOK_CAP)) {
-            done = long_file(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
-                             a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR);
+            LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
+            if (AUD) { const uint64_t r = f - a.file0; aud.row = a.aud32 + r * AUD_STRIDE; aud.cnt = a.audit_cnt + r * AUDIT_COLS; aud.len = a.audit_len + r * AUDIT_COLS; aud.rbits = a.review_bits + r; }
+            done = long_file<AUD>(w, t, L, rc_lds, cls, a.arena + o, (uint32_t)len64, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
+                                  a.fired ? a.fired + f * t.fired_words : nullptr, a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, TR, aud);
         }
         if (w.lane() == 0) {
             if (done) {
@@ -465,6 +467,9 @@ __global__ __launch_bounds__(64) void k_long256(DevTables t, FastArgs a) { long_
 __global__ __launch_bounds__(64) void k_long_triage(DevTables t, FastArgs a) { long_body<true, LongLds>(t, a); }
 __global__ __launch_bounds__(64) void k_long512_triage(DevTables t, FastArgs a) { long_body<true, LongLds512>(t, a); }
 __global__ __launch_bounds__(64) void k_long256_triage(DevTables t, FastArgs a) { long_body<true, LongLds256>(t, a); }
+__global__ __launch_bounds__(64) void k_long_audit(DevTables t, FastArgs a) { long_body<false, LongLds, true>(t, a); }
+__global__ __launch_bounds__(64) void k_long512_audit(DevTables t, FastArgs a) { long_body<false, LongLds512, true>(t, a); }
+__global__ __launch_bounds__(64) void k_long256_audit(DevTables t, FastArgs a) { long_body<false, LongLds256, true>(t, a); }
 
 // ------------------------------------------------------------------------------------------------
 // k_wave_sizes
@@ -1555,15 +1560,14 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
         if (a.fired || a.facet_choice || a.aud32) hipLaunchKernelGGL(k_lean_b_detail, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
         else hipLaunchKernelGGL(k_lean_b, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
     } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
-    else if (a.stage == 3 && a.aud32) return hipErrorInvalidValue;   // the long-file stage keeps no audit lists: the caller hands its files to the general kernel
     else if (a.stage == 3) {
         // as many one-wavefront blocks as the CUs hold at once for the size's LDS (the grid strides over the list)
         const unsigned per_cu = a.long_size == 0 ? 9u : a.long_size == 1 ? 5u : 3u;
         const dim3 grid((unsigned)(n < 256u * per_cu ? n : 256u * per_cu));
         const size_t dyn = 0;
-        if (a.long_size == 0) hipLaunchKernelGGL(tr ? k_long256_triage : k_long256, grid, dim3(64), dyn, s, t, a);
-        else if (a.long_size == 1) hipLaunchKernelGGL(tr ? k_long512_triage : k_long512, grid, dim3(64), dyn, s, t, a);
-        else hipLaunchKernelGGL(tr ? k_long_triage : k_long, grid, dim3(64), dyn, s, t, a);
+        if (a.long_size == 0) hipLaunchKernelGGL(a.aud32 ? k_long256_audit : tr ? k_long256_triage : k_long256, grid, dim3(64), dyn, s, t, a);
+        else if (a.long_size == 1) hipLaunchKernelGGL(a.aud32 ? k_long512_audit : tr ? k_long512_triage : k_long512, grid, dim3(64), dyn, s, t, a);
+        else hipLaunchKernelGGL(a.aud32 ? k_long_audit : tr ? k_long_triage : k_long, grid, dim3(64), dyn, s, t, a);
     }
     else if (a.stage == 2) hipLaunchKernelGGL(a.aud32 ? k_fast2_audit : tr ? k_fast2_triage : k_fast2, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else hipLaunchKernelGGL(a.aud32 ? k_fast_audit : tr ? k_fast_triage : k_fast, dim3(blocks), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);

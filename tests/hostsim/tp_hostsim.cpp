@@ -574,6 +574,21 @@ long long sim_run_audit_wave(void* h, const uint8_t* arena_in, const uint64_t* o
             for (int l = 1; l < 64; ++l) if (done[l] != done[0]) g_err = "lanes disagree on the audit-mode verdict";
             if (done[0]) stage = 1 + nt;
         }
+        for (int size = 0; size < 3 && !stage && t.fast_ok; ++size) {   // the long-file stage's three sizes of state (4 + size)
+            static LongLds256 l256;
+            static LongLds512 l512;
+            static LongLds l1024;
+            if (len > (size == 0 ? LongLds256::LINE_CAP : LONG_LINE_MAX)) continue;
+            std::memset((void*)&l256, 0xCD, sizeof l256); std::memset((void*)&l512, 0xCD, sizeof l512); std::memset((void*)&l1024, 0xCD, sizeof l1024);
+            sh.run([&](int lane) {
+                emu::Wave w{&sh, (uint32_t)lane};
+                done[lane] = size == 0 ? long_file<true>(w, t, l256, t.rc, cls_table(), line, len, outs[lane], fin32.data(), fired.data(), t.n_facets ? facets.data() : nullptr, false, aud)
+                           : size == 1 ? long_file<true>(w, t, l512, t.rc, cls_table(), line, len, outs[lane], fin32.data(), fired.data(), t.n_facets ? facets.data() : nullptr, false, aud)
+                                       : long_file<true>(w, t, l1024, t.rc, cls_table(), line, len, outs[lane], fin32.data(), fired.data(), t.n_facets ? facets.data() : nullptr, false, aud);
+            });
+            for (int l = 1; l < 64; ++l) if (done[l] != done[0]) g_err = "lanes disagree on the long-file audit verdict";
+            if (done[0]) stage = 4 + size;
+        }
         stage_of[f] = (uint8_t)stage;
         verdicts[f] = stage ? outs[0].verdict : tp_verdict{};
         review_bits[f] = stage ? rbits : 0;

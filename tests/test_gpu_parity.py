@@ -304,7 +304,7 @@ def test_audit_row_known_answer():
                                 b"coverage_stop_reason,coverage_trace")
 
 
-@pytest.mark.parametrize("name,n", [("c3c", 4000), ("c1", 4000), ("c4", 3000)])
+@pytest.mark.parametrize("name,n", [("c3c", 4000), ("c1", 4000), ("c4", 3000), ("c5", 3000)])
 def test_audit_mode_stays_in_the_wave_stages(name, n):
     """Audit mode beyond the lean stage: a file it declines (c3c: every file holds a tag that moves one alias hop per NormalizeTag
     site; c1: spellings the lean stage does not take) gets its lists from the general wave stages, in the reference's insertion
