@@ -305,7 +305,8 @@ def main():
         out["config"]["end_to_end_files_per_s"] = n / best
         out["config"]["end_to_end"] = {"files_per_s": n / best, "ms_per_call": best * 1e3, "calls_timed": args.e2e_runs,
                                        "what": "tp_run_lines: pinned host arena + offsets in (H2D %.2f GB), all kernels, captions + offsets + verdicts + histogram + "
-                                               "detail arrays back to host memory (D2H %.2f GB); best of the timed calls; no file-system time" %
+                                               "detail arrays back to host memory (D2H %.2f GB), in pieces of 131072 files whose copies run beside the kernels of the piece between them; "
+                                               "best of the timed calls; no file-system time" %
                                                ((in_bytes + 8 * n) / 1e9, (int(cap_bytes) + 8 * n + 16 * n) / 1e9)}
 
     if world == 1 and args.cpu_sample > 0:

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -197,11 +198,26 @@ struct tp_ctx {
                           &audit_cnt, &audit_len, &out_audit, &out_audit_offsets, &out_review_bits, &aud32})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : pipe_events) (void)hipEventDestroy(e);
+        for (hipStream_t q : pipe_streams) if (q) (void)hipStreamDestroy(q);
     }
     hipEvent_t event(size_t i) {
         while (events.size() <= i) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); events.push_back(e); }
         return events[i];
     }
+    // tp_run_lines over host buffers in pieces: the next piece's lines go to the device, the piece before's captions come
+    // back, while the kernels work on the current one - three streams, events between them (no timing on these)
+    hipStream_t pipe_streams[3] = {nullptr, nullptr, nullptr};       // in, run, out
+    std::vector<hipEvent_t> pipe_events;
+    hipStream_t pipe_stream(int k) {
+        if (!pipe_streams[k]) HIP_OK(hipStreamCreateWithFlags(&pipe_streams[k], hipStreamNonBlocking));
+        return pipe_streams[k];
+    }
+    hipEvent_t pipe_event(size_t i) {
+        while (pipe_events.size() <= i) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); pipe_events.push_back(e); }
+        return pipe_events[i];
+    }
+    bool no_overlap = false;         // TAGPIPE_NO_OVERLAP=1: the host-pointer run copies in, computes and copies out in turn (testing aid)
 };
 
 namespace {
@@ -215,6 +231,11 @@ struct RunIo {
     uint64_t* caption_offsets; tp_verdict* verdicts; uint64_t* histogram; tp_counters* counters; uint32_t* fired; uint16_t* facet_choice;
     hipStream_t stream; int mode;
     bool audit; uint64_t* audit_offsets; uint32_t* review_bits;    // audit: every file takes the general kernel in mode 3; the lists' text goes to ctx->out_audit
+    // the host-pointer run in pieces: files per range (0: the usual 2^24), what to do before a range's first kernel and after
+    // its last one (bytes0 .. bytes1: the range's captions)
+    uint64_t range_files = 0;
+    std::function<void(uint64_t f0, uint64_t f1)> before_range;
+    std::function<void(uint64_t f0, uint64_t f1, uint64_t bytes0, uint64_t bytes1)> after_range;
 };
 
 // One range of files [f0, f1): wave-per-file kernel, general kernel for what it declined, caption offsets, emit.
@@ -577,11 +598,14 @@ int run_device(tp_ctx* c, RunIo io, uint64_t* caption_bytes, uint64_t* audit_byt
     hipEvent_t e_begin = timed ? c->event(0) : nullptr, e_end = timed ? c->event(1) : nullptr;
     if (timed) HIP_OK(hipEventRecord(e_begin, s));
     int rc = TP_OK;
-    const uint64_t range_max = (uint64_t)1 << 24;              // files per range: bounds the per-range index buffers
+    const uint64_t range_max = io.range_files ? io.range_files : (uint64_t)1 << 24;   // files per range: bounds the per-range index buffers
     for (uint64_t f0 = 0; f0 < n; f0 += range_max) {
-        int r = run_range(c, io, f0, std::min(n, f0 + range_max), st);
+        const uint64_t f1 = std::min(n, f0 + range_max), bytes0 = st.total;
+        if (io.before_range) io.before_range(f0, f1);
+        int r = run_range(c, io, f0, f1, st);
         if (r != TP_OK) rc = r;
         if (r != TP_OK && r != TP_E_CAPACITY) break;
+        if (io.after_range && r == TP_OK) io.after_range(f0, f1, bytes0, st.total);
     }
     if (timed) HIP_OK(hipEventRecord(e_end, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -653,13 +677,34 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
              const double* scores, const uint8_t* sources, uint64_t n_tags, uint64_t n_files, tp_result* out,
              const uint64_t* secondary_begin = nullptr, int secondary_cap = 0, const uint8_t* reply_flags = nullptr) {
     HIP_OK(hipSetDevice(c->device));
-    hipStream_t s = nullptr;
     const DevTables& t = c->dt;
+    // Tag lines in pieces of PIECE files when there are several of them: while the kernels work on one piece the next one's
+    // lines are on their way to the device and the captions of the one before on their way back (the bus carries both
+    // directions at once, and either copy takes several times as long as the kernels).  Audit mode and tagger replies go in turn.
+    const uint64_t PIECE = 131072;
+    const bool overlap = !tag_begin && !c->audit && !c->no_overlap && n_files >= 2 * PIECE;
+    hipStream_t s = overlap ? c->pipe_stream(1) : nullptr;
+    hipStream_t s_in = overlap ? c->pipe_stream(0) : s, s_out = overlap ? c->pipe_stream(2) : s;
+    const uint64_t n_pieces = overlap ? (n_files + PIECE - 1) / PIECE : 0;
     c->in_arena.need(arena_bytes + 64);
     c->in_offsets.need(n_offsets * 8);
+    auto piece_in = [&](uint64_t k) {                               // piece k's lines to the device, then its event
+        if (k >= n_pieces) return;
+        const uint64_t f0 = k * PIECE, f1 = std::min(n_files, f0 + PIECE), b0 = offsets[f0], b1 = offsets[f1];
+        if (b1 > b0) HIP_OK(hipMemcpyAsync((uint8_t*)c->in_arena.p + b0, arena + b0, b1 - b0, hipMemcpyHostToDevice, s_in));
+        if (f1 == n_files) HIP_OK(hipMemsetAsync((uint8_t*)c->in_arena.p + arena_bytes, 0, 64, s_in));
+        HIP_OK(hipEventRecord(c->pipe_event(1 + k), s_in));
+    };
+    if (overlap) {
+        HIP_OK(hipMemcpyAsync(c->in_offsets.p, offsets, n_offsets * 8, hipMemcpyHostToDevice, s_in));
+        HIP_OK(hipEventRecord(c->pipe_event(0), s_in));
+        HIP_OK(hipStreamWaitEvent(s, c->pipe_event(0), 0));
+        piece_in(0);
+    } else {
     if (arena_bytes) HIP_OK(hipMemcpyAsync(c->in_arena.p, arena, arena_bytes, hipMemcpyHostToDevice, s));
     HIP_OK(hipMemsetAsync((uint8_t*)c->in_arena.p + arena_bytes, 0, 64, s));   // the lean stage reads whole 16-byte pieces: what lies behind the last line is not left to chance (a byte outside ASCII there sends that file the long way)
     HIP_OK(hipMemcpyAsync(c->in_offsets.p, offsets, n_offsets * 8, hipMemcpyHostToDevice, s));
+    }
     if (tag_begin) {
         c->in_tag_begin.need((n_files + 1) * 8); c->in_scores.need(std::max<uint64_t>(n_tags, 1) * 8); c->in_sources.need(std::max<uint64_t>(n_tags, 1));
         HIP_OK(hipMemcpyAsync(c->in_tag_begin.p, tag_begin, (n_files + 1) * 8, hipMemcpyHostToDevice, s));
@@ -683,7 +728,7 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     c->out_counters.need(sizeof(tp_counters));
     c->out_fired.need(std::max<uint64_t>(n_files * t.fired_words, 1) * 4);
     c->out_facets.need(std::max<uint64_t>(n_files * t.n_facets, 1) * 2);
-    c->out_captions.need(std::max<uint64_t>(arena_bytes + n_files * 96, 4096));
+    c->out_captions.need(std::max<uint64_t>(overlap ? 2 * arena_bytes + n_files * 128 : arena_bytes + n_files * 96, 4096));
     HIP_OK(hipMemsetAsync(c->out_hist.p, 0, hist_n * 8, s));
     HIP_OK(hipMemsetAsync(c->out_counters.p, 0, sizeof(tp_counters), s));
 
@@ -708,17 +753,52 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
         io.review_bits = c->out_review_bits.as<uint32_t>();
     }
     uint64_t cap_bytes = 0, audit_bytes = 0;
-    int rc = run_device(c, io, &cap_bytes, &audit_bytes);
-    if (rc != TP_OK) return rc;
-
     std::unique_ptr<HostResult> r(new HostResult());
+    bool captions_back = false;                                   // the pieces' captions went back as they were written
+    if (overlap) {
+        // the result's arrays exist before the run; the captions' size is a guess (twice the input and 128 bytes a file: an
+        // array that turns out too small is given up for one copy at the end)
+        r->captions.resize(c->out_captions.cap);
+        r->caption_offsets.resize(n_files + 1);
+        r->verdicts.resize(n_files);
+        r->fired.resize(std::max<uint64_t>(n_files * t.fired_words, 1));
+        r->facet_choice.resize(std::max<uint64_t>(n_files * t.n_facets, 1));
+        const uint64_t host_cap = c->out_captions.cap;
+        captions_back = true;
+        io.range_files = PIECE;
+        io.before_range = [&](uint64_t f0, uint64_t) {
+            const uint64_t k = f0 / PIECE;
+            piece_in(k + 1);                                       // the next piece's lines start out before this piece's kernels are queued
+            HIP_OK(hipStreamWaitEvent(s, c->pipe_event(1 + k), 0));
+        };
+        io.after_range = [&](uint64_t f0, uint64_t f1, uint64_t b0, uint64_t b1) {
+            const uint64_t k = f0 / PIECE;
+            hipEvent_t done = c->pipe_event(1 + n_pieces + k);
+            HIP_OK(hipEventRecord(done, s));
+            HIP_OK(hipStreamWaitEvent(s_out, done, 0));
+            if (b1 > host_cap) captions_back = false;
+            if (captions_back && b1 > b0) HIP_OK(hipMemcpyAsync(r->captions.data() + b0, (const uint8_t*)c->out_captions.p + b0, b1 - b0, hipMemcpyDeviceToHost, s_out));
+            HIP_OK(hipMemcpyAsync(r->caption_offsets.data() + f0, (const uint64_t*)c->out_offsets.p + f0, (f1 - f0 + 1) * 8, hipMemcpyDeviceToHost, s_out));
+            HIP_OK(hipMemcpyAsync(r->verdicts.data() + f0, (const tp_verdict*)c->out_verdicts.p + f0, (f1 - f0) * sizeof(tp_verdict), hipMemcpyDeviceToHost, s_out));
+            if (t.fired_words) HIP_OK(hipMemcpyAsync(r->fired.data() + f0 * t.fired_words, (const uint32_t*)c->out_fired.p + f0 * t.fired_words, (f1 - f0) * t.fired_words * 4, hipMemcpyDeviceToHost, s_out));
+            if (t.n_facets) HIP_OK(hipMemcpyAsync(r->facet_choice.data() + f0 * t.n_facets, (const uint16_t*)c->out_facets.p + f0 * t.n_facets, (f1 - f0) * t.n_facets * 2, hipMemcpyDeviceToHost, s_out));
+        };
+    }
+    int rc = run_device(c, io, &cap_bytes, &audit_bytes);
+    if (rc != TP_OK) { if (overlap) { (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(s_out); } return rc; }
+
+    r->histogram.resize(hist_n);
+    tp_counters ctr{};
+    if (overlap) {
+        HIP_OK(hipStreamSynchronize(s_out));                       // (the run's own stream is idle: run_device waited for it)
+        if (!captions_back) { r->captions.resize(std::max<uint64_t>(cap_bytes, 1)); if (cap_bytes) HIP_OK(hipMemcpyAsync(r->captions.data(), c->out_captions.p, cap_bytes, hipMemcpyDeviceToHost, s)); }
+        HIP_OK(hipMemcpyAsync(r->histogram.data(), c->out_hist.p, hist_n * 8, hipMemcpyDeviceToHost, s));
+    } else {
     r->captions.resize(std::max<uint64_t>(cap_bytes, 1));
     r->caption_offsets.resize(n_files + 1);
     r->verdicts.resize(std::max<uint64_t>(n_files, 1));
-    r->histogram.resize(hist_n);
     r->fired.resize(std::max<uint64_t>(n_files * t.fired_words, 1));
     r->facet_choice.resize(std::max<uint64_t>(n_files * t.n_facets, 1));
-    tp_counters ctr{};
     // every copy back is queued on the stream and waited for once (the buffers are page-locked: the copies are DMA transfers)
     if (cap_bytes) HIP_OK(hipMemcpyAsync(r->captions.data(), c->out_captions.p, cap_bytes, hipMemcpyDeviceToHost, s));
     HIP_OK(hipMemcpyAsync(r->caption_offsets.data(), c->out_offsets.p, (n_files + 1) * 8, hipMemcpyDeviceToHost, s));
@@ -726,6 +806,7 @@ int run_host(tp_ctx* c, const uint8_t* arena, uint64_t arena_bytes, const uint64
     HIP_OK(hipMemcpyAsync(r->histogram.data(), c->out_hist.p, hist_n * 8, hipMemcpyDeviceToHost, s));
     if (n_files * t.fired_words) HIP_OK(hipMemcpyAsync(r->fired.data(), c->out_fired.p, n_files * t.fired_words * 4, hipMemcpyDeviceToHost, s));
     if (n_files * t.n_facets) HIP_OK(hipMemcpyAsync(r->facet_choice.data(), c->out_facets.p, n_files * t.n_facets * 2, hipMemcpyDeviceToHost, s));
+    }
     if (io.audit) {
         r->audit_text.resize(std::max<uint64_t>(audit_bytes, 1));
         r->audit_offsets.resize(n_files * AUDIT_COLS + 1);
@@ -926,6 +1007,7 @@ void load_tables(tp_ctx* c, const std::vector<std::string>* learned) {
     c->use_lean = lean_ok(c->dt);
     if (const char* b = std::getenv("TAGPIPE_NO_LEAN")) if (b[0] == '1') c->use_lean = false;
     if (const char* b = std::getenv("TAGPIPE_LEAN_ADAPT")) c->lean_adapt = b[0] != '0';
+    if (const char* b = std::getenv("TAGPIPE_NO_OVERLAP")) c->no_overlap = b[0] == '1';
     c->dt_dev.need(sizeof(DevTables));
     HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));
     for (void* p : old_mem) (void)hipFree(p);

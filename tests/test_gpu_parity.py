@@ -513,6 +513,26 @@ def test_workspace_chunking_gives_identical_results(monkeypatch):
     assert np.array_equal(whole.histogram, chunked.histogram)
 
 
+def test_host_run_in_pieces_equals_the_run_in_turn(monkeypatch):
+    """tp_run_lines over many files works in pieces (the next piece's lines going in and the last one's captions coming back while
+    the kernels run): the same arrays as copying in, computing and copying out in turn, and the oracle's captions for a sample."""
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus("c5", 300000, seed=77)                        # three pieces, the last one short; long files, so every stage has work
+    cfg = Config(**c.config_kwargs)
+    p = pipe_for(cfg)
+    first = p.run_lines(c.arena, c.offsets)
+    again = p.run_lines(c.arena, c.offsets)                          # the second call finds its buffers at their final sizes
+    monkeypatch.setenv("TAGPIPE_NO_OVERLAP", "1")
+    turn = pipe_for(cfg).run_lines(c.arena, c.offsets)
+    for got in (first, again):
+        assert np.array_equal(got.caption_offsets, turn.caption_offsets) and np.array_equal(got.captions, turn.captions)
+        assert got.verdicts.tobytes() == turn.verdicts.tobytes() and got.counters == turn.counters
+        assert np.array_equal(got.histogram, turn.histogram) and np.array_equal(got.fired, turn.fired) and np.array_equal(got.facet_choice, turn.facet_choice)
+    k = 2000
+    want = Oracle(cfg).run_lines(c.arena[:int(c.offsets[k])], c.offsets[:k + 1], threads=16)
+    assert bytes(first.captions[:int(first.caption_offsets[k])]) == bytes(want.captions[:int(want.caption_offsets[k])])
+
+
 def test_device_api_capacity_and_accumulation():
     import torch
     from imagecaptioner_amd._abi import TP_E_CAPACITY, tp_device_io
