@@ -139,9 +139,10 @@ struct HostResult {
 // What one run works in besides the caller's inputs and outputs.
 struct WorkBufs {
     DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, slow_list_b, tile_state, scalars, workspace;
+    DevBuf hist_parts;               // EmitArgs::hist_parts (grown buffers only: the fixed working memory has no room for it)
     void release() {
         for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &slow_list_b,
-                          &tile_state, &scalars, &workspace})
+                          &tile_state, &scalars, &workspace, &hist_parts})
             b->release();
     }
 };
@@ -549,6 +550,10 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
     ea.fin32 = want_ids ? c->w->fin32.as<uint32_t>() : nullptr; ea.fast_ran = use_fast ? 1 : 0; ea.wave_files_written = fused ? 1 : 0; ea.item_list = item_list; ea.n_items = n_slow; ea.slot_of = slot_of; ea.n_final = n_final;
     ea.caption_offsets = io.caption_offsets; ea.verdicts = io.verdicts; ea.captions = io.captions;
     ea.histogram = io.histogram; ea.counters = io.counters; ea.fpw = fpw_used;
+    if (io.histogram && c->w == &c->own && n >= 4096) {
+        c->w->hist_parts.need((size_t)HIST_PART_BLOCKS * HIST_PART_WORDS * 4);
+        ea.hist_parts = c->w->hist_parts.as<uint32_t>();
+    }
     hipEvent_t q0 = next_event(), q1 = next_event();
     record(q0);
     HIP_OK(launch_emit(c->dt, ea, s));

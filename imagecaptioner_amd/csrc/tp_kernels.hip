@@ -1056,6 +1056,10 @@ __device__ __forceinline__ void emit_runs_body(const DevTables& t, const EmitArg
         if (n_learned) atomicAdd(&learned, n_learned);
         __syncthreads();
         if (threadIdx.x == 0 && learned) atomicAdd((unsigned long long*)&a.histogram[t.n_public], (unsigned long long)learned);
+        if (a.hist_parts) {                                           // k_hist_sum adds the blocks' counters up
+            uint32_t* part = a.hist_parts + (size_t)blockIdx.x * HIST_PART_WORDS;
+            for (uint32_t i = threadIdx.x; i < (t.n_public + 1) / 2; i += blockDim.x) part[i] = bins[i];
+        } else
         for (uint32_t i = threadIdx.x; i < (t.n_public + 1) / 2; i += blockDim.x) {
             const uint32_t v = bins[i];
             if (v & 0xFFFFu) atomicAdd((unsigned long long*)&a.histogram[2 * i], (unsigned long long)(v & 0xFFFFu));
@@ -1330,6 +1334,7 @@ __global__ __launch_bounds__(64) void k_add_counters(tp_counters* dst, const tp_
 // (the caption writer has counted the wave kernels' files).
 __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t id0, int general) {
     __shared__ uint32_t bins[HIST_IDS / 2];
+    static_assert(HIST_IDS / 2 == HIST_PART_WORDS && HISTX_IDS / 2 <= HIST_PART_WORDS, "a block's counters fit its part of EmitArgs::hist_parts");
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const uint32_t span = t.n_public - id0 < HIST_IDS ? t.n_public - id0 : HIST_IDS;
     __shared__ uint32_t learned;                                // tags that are learned strings: counted with the tags in no table (first pass only)
@@ -1337,6 +1342,8 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
     const uint64_t n = a.file_end - a.file0;
     const uint64_t per_block = (n + gridDim.x - 1) / gridDim.x;
     const uint64_t b0 = a.file0 + per_block * blockIdx.x, b1 = b0 + per_block < a.file_end ? b0 + per_block : a.file_end;
+    if (a.hist_parts && per_block <= HIST_FILES_PER_FLUSH && b0 >= b1)      // no files: the part still takes part in the sum
+        for (uint32_t i = threadIdx.x; i < (span + 1) / 2; i += blockDim.x) a.hist_parts[(size_t)blockIdx.x * HIST_PART_WORDS + i] = 0;
     for (uint64_t c0 = b0; c0 < b1; c0 += HIST_FILES_PER_FLUSH) {
         const uint64_t c1 = c0 + HIST_FILES_PER_FLUSH < b1 ? c0 + HIST_FILES_PER_FLUSH : b1;
         for (uint32_t i = threadIdx.x; i < HIST_IDS / 2; i += blockDim.x) bins[i] = 0;
@@ -1355,16 +1362,22 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
                 }
             }
         };
-        uint32_t nf[NF], nf_next[NF];
+        // sizes two steps ahead, rows one step ahead: a step's loads are on their way while the step before counts
+        uint32_t nf[NF], nf1[NF], nf2[NF];
         uint32_t n_learned = 0;
-        sizes(c0 + wave, nf);
-        for (uint64_t f = c0 + wave; f < c1; f += NF * waves) {
-            sizes(f + NF * waves, nf_next);
-            uint2 x[NF];
+        auto rows = [&](uint64_t f, const uint32_t (&n_)[NF], uint2 (&x)[NF]) {
             TP_UNROLL for (int k = 0; k < NF; ++k) {
                 x[k] = make_uint2(0, 0);
-                if (2 * lane < nf[k]) x[k] = *(const uint2*)(a.fin32 + (f + (uint64_t)k * waves - a.file0) * FAST_FIN_MAX + 2 * lane);
+                if (2 * lane < n_[k]) x[k] = *(const uint2*)(a.fin32 + (f + (uint64_t)k * waves - a.file0) * FAST_FIN_MAX + 2 * lane);
             }
+        };
+        uint2 x[NF], x1[NF];
+        sizes(c0 + wave, nf);
+        sizes(c0 + wave + NF * waves, nf1);
+        rows(c0 + wave, nf, x);
+        for (uint64_t f = c0 + wave; f < c1; f += NF * waves) {
+            sizes(f + 2 * NF * waves, nf2);
+            rows(f + NF * waves, nf1, x1);
             auto count = [&](uint32_t id, bool live) {
                 const uint32_t k = id - id0;
 #ifdef HIST_X_NOATOM
@@ -1376,11 +1389,15 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
                 n_learned += (uint32_t)(live && id0 == 0 && id >= t.n_public && id < t.n_strings);
             };
             TP_UNROLL for (int k = 0; k < NF; ++k) { count(x[k].x, 2 * lane < nf[k]); count(x[k].y, 2 * lane + 1 < nf[k]); }
-            TP_UNROLL for (int k = 0; k < NF; ++k) nf[k] = nf_next[k];
+            TP_UNROLL for (int k = 0; k < NF; ++k) { nf[k] = nf1[k]; nf1[k] = nf2[k]; x[k] = x1[k]; }
         }
         if (n_learned) atomicAdd(&learned, n_learned);
         __syncthreads();
         if (threadIdx.x == 0 && learned) { atomicAdd((unsigned long long*)&a.histogram[t.n_public], (unsigned long long)learned); learned = 0; }
+        if (a.hist_parts && per_block <= HIST_FILES_PER_FLUSH) {      // (one flush per block: k_hist_sum adds the blocks' counters up)
+            uint32_t* part = a.hist_parts + (size_t)blockIdx.x * HIST_PART_WORDS;
+            for (uint32_t i = threadIdx.x; i < (span + 1) / 2; i += blockDim.x) part[i] = bins[i];
+        } else
 #ifdef HIST_X_NOFLUSH
         if (span == 12345)
 #endif
@@ -1391,6 +1408,16 @@ __global__ __launch_bounds__(1024) void k_hist(DevTables t, EmitArgs a, uint32_t
         }
         __syncthreads();
     }
+}
+
+// The blocks' counters (EmitArgs::hist_parts) added up into the histogram: one thread per word of two counters.
+__global__ __launch_bounds__(256) void k_hist_sum(const uint32_t* parts, uint32_t n_blocks, uint32_t words, uint64_t* histogram) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) { const uint32_t v = parts[(size_t)b * HIST_PART_WORDS + i]; lo += v & 0xFFFFu; hi += v >> 16; }
+    if (lo) histogram[2 * i] += lo;
+    if (hi) histogram[2 * i + 1] += hi;
 }
 
 // Files of the general kernel (a.item_list, or every file of the range when it is null): tags may be strings outside the
@@ -1634,7 +1661,9 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
             const uint64_t hwant = ((n + RUN_FILES - 1) / RUN_FILES + EMITH_WAVES - 1) / EMITH_WAVES;
             const unsigned hblocks = (unsigned)(hwant < 256 ? hwant : 256);
             if (!no_hist && a.histogram && t.n_public <= HISTX_IDS && n >= 4096 && n / hblocks + RUN_FILES * EMITH_WAVES < 65536) {
-                hipLaunchKernelGGL(k_emit_runs_hist, dim3(hblocks), dim3(64 * EMITH_WAVES), 0, s, t, a);
+                EmitArgs own = a;
+                own.hist_parts = nullptr;                              // (measured: with so few counters the blocks' own atomics are the cheaper flush)
+                hipLaunchKernelGGL(k_emit_runs_hist, dim3(hblocks), dim3(64 * EMITH_WAVES), 0, s, t, own);
                 wave_files_counted = true;
             } else
                 hipLaunchKernelGGL(k_emit_runs, dim3(blocks), dim3(64 * EMIT_WAVES), 0, s, t, a);
@@ -1652,7 +1681,13 @@ hipError_t launch_emit(const DevTables& t, const EmitArgs& a, hipStream_t s) {
         unsigned hblocks = (unsigned)(hb < 256 ? hb : 256);   // one per CU: the counters take most of its LDS
         const int general = a.n_items ? (wave_files_counted ? 2 : 1) : 0;
         if (!(wave_files_counted && !a.n_items))
-            for (uint32_t id0 = 0; id0 < t.n_public; id0 += HIST_IDS) hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0, general);
+            for (uint32_t id0 = 0; id0 < t.n_public; id0 += HIST_IDS) {
+                hipLaunchKernelGGL(k_hist, dim3(hblocks), dim3(1024), 0, s, t, a, id0, general);
+                if (a.hist_parts && (n + hblocks - 1) / hblocks <= HIST_FILES_PER_FLUSH) {
+                    const uint32_t span = t.n_public - id0 < HIST_IDS ? t.n_public - id0 : HIST_IDS, words = (span + 1) / 2;
+                    hipLaunchKernelGGL(k_hist_sum, dim3((words + 255) / 256), dim3(256), 0, s, a.hist_parts, hblocks, words, a.histogram + id0);
+                }
+            }
     }
     return hipGetLastError();
 }

@@ -127,7 +127,12 @@ struct EmitArgs {
     uint64_t* histogram;          // n_strings + 1, accumulated; may be null
     tp_counters* counters;        // accumulated; may be null
     uint32_t fpw;                 // files per wavefront of the general kernel's run (the stride of its workspace rows)
+    // May be null.  HIST_PART_WORDS words for each of up to HIST_PART_BLOCKS blocks: the histogram kernels' blocks leave their
+    // counters there (two 16-bit counters a word) and one thread per word adds the blocks' words up into the histogram,
+    // instead of every block adding every counter that is not zero to the histogram with an atomic of its own.
+    uint32_t* hist_parts;
 };
+constexpr uint32_t HIST_PART_WORDS = 32768, HIST_PART_BLOCKS = 256;
 
 // Address and size of this device's static working memory (see tp_kernels.hip); `device` must be the current device.
 constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)16 << 20;
