@@ -25,8 +25,8 @@ for c in c1 c3 c3c c4 c5; do
 done
 timeout -k 10 300 python3 bench.py --config c2n --steps 10 --warmup 4 --cpu-sample 0 --e2e-runs 0 > $O/bench_c2n.json 2> $O/bench_c2n.err || { tail -5 $O/bench_c2n.err; exit 1; }
 for a in "c2 200000" "c3c 200000" "c5 100000"; do timeout -k 10 300 python3 tools/audit_timing.py $a >> $O/audit_timing.txt 2>> $O/audit_timing.err || { tail -5 $O/audit_timing.err; exit 1; }; done
-timeout -k 10 300 python3 tools/scored_timing.py > $O/scored_timing.txt 2> $O/scored_timing.err || { tail -5 $O/scored_timing.err; exit 1; }
-timeout -k 10 300 python3 tools/triage_timing.py > $O/triage_timing.txt 2> $O/triage_timing.err || { tail -5 $O/triage_timing.err; exit 1; }
+timeout -k 10 300 python3 tools/scored_timing.py c2 200000 > $O/scored_timing.txt 2> $O/scored_timing.err || { tail -5 $O/scored_timing.err; exit 1; }
+timeout -k 10 300 python3 tools/triage_timing.py c2 1000000 > $O/triage_timing.txt 2> $O/triage_timing.err || { tail -5 $O/triage_timing.err; exit 1; }
 python3 - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r03/bench*.json")):
