@@ -380,8 +380,8 @@ const char* tp_error_needtag_text(void);
 /* Timing of the most recent run on this context (milliseconds, from HIP events on the run's stream). */
 typedef struct tp_timing {
     float total_ms;     /* first kernel start to last kernel end */
-    float select_ms;    /* all wave-per-file kernels: the lean stage (k_lean_a, k_lean_b) and the stages behind it (k_fast, k_fast2, k_long) */
-    float general_ms;   /* thread-per-file pipeline kernel (k_pipeline) over the files k_fast declined */
+    float select_ms;    /* all wave-per-file kernels: the lean stage (k_lean_a, k_lean_b) and the stages behind it (k_fast, k_fast2, the long-file kernels) */
+    float general_ms;   /* thread-per-file pipeline kernel (k_pipeline) over the files every wave-per-file stage declined */
     float emit_ms;      /* caption bytes, histogram, counters (k_emit) */
     float other_ms;     /* sizing, scans, host round trips between kernels */
     uint64_t general_files; /* how many files took the thread-per-file kernel */
@@ -434,9 +434,9 @@ int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t
  *   TP_AUDIT_TOP       TopJoyTags: the tags of the 20 best raw candidates by score, then order (Program.cs:860)
  *   TP_AUDIT_UNKNOWN   the caption's tags outside the vocabulary, in caption order (GetUnknownTags before its sort, Program.cs:817-821)
  * Column c of file i is text[offsets[TP_AUDIT_COLS * i + c] .. offsets[TP_AUDIT_COLS * i + c + 1]); tp_get_audit's pointers live
- * as long as the result.  In audit mode the first wave-per-file stage keeps these lists for the files it takes; a file it
- * declines takes the thread-per-file kernel (the later wave-per-file stages do not keep them), so a run is slower than without
- * it.  n_selected in the verdicts is exact in every mode; n_evidence is counted.
+ * as long as the result.  In audit mode every wave-per-file stage keeps these lists for the files it takes (tag lines; tagger
+ * replies take the thread-per-file kernel), which costs about half a run's speed.  n_selected in the verdicts is exact in every
+ * mode; n_evidence is counted.
  */
 #define TP_AUDIT_KEPT     0
 #define TP_AUDIT_EVIDENCE 1
