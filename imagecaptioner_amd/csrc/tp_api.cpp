@@ -265,7 +265,10 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
     uint64_t* d_total = c->w->scalars.as<uint64_t>();          // [0], [1]: running caption total, ping-pong
     uint32_t* d_status = (uint32_t*)(d_total + 2);
     uint32_t* d_slow_count = d_status + 1;
-    const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast && !io.audit;   // tagger replies: the wave kernel's scored front
+    // audit mode over tagger replies: the scored stage lists what it takes (a reply that keeps its own order is left to the
+    // general kernel: the stage's lanes hold the candidates sorted)
+    const bool audit_scored = io.audit && c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast && c->dt.reach_levels_ok;
+    const bool use_scored = c->dt.fast_ok && io.tag_begin && io.mode == 0 && !c->no_fast && (!io.audit || audit_scored);   // tagger replies: the wave kernel's scored front
     // audit mode over tag lines: the lean stage lists what it takes (interned ids, tp_lean.h), everything else takes the general kernel
     const bool audit_lean = io.audit && c->use_lean && c->dt.fast_ok && !io.tag_begin && io.mode == 0 && !c->no_fast;
     bool lean_now = c->use_lean && io.mode == 0 && !io.tag_begin;
@@ -306,6 +309,11 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         if (use_scored) {
             fa.tag_begin = io.tag_begin; fa.scores = io.scores; fa.sources = io.sources; fa.secondary_begin = io.secondary_begin; fa.secondary_cap = io.secondary_cap;
             fa.stage = 4; fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count; fa.item_list = nullptr; fa.item_count = nullptr;
+            if (audit_scored) {
+                fa.reply_flags = io.reply_flags;
+                c->aud32.need(n * AUD_STRIDE * 4); c->audit_cnt.need(n * AUDIT_COLS * 4); c->audit_len.need(n * AUDIT_COLS * 4);
+                fa.aud32 = c->aud32.as<uint32_t>(); fa.audit_cnt = c->audit_cnt.as<uint32_t>(); fa.audit_len = c->audit_len.as<uint32_t>(); fa.review_bits = io.review_bits + f0;
+            }
             HIP_OK(launch_fast(c->dt, fa, s));
         } else if (audit_lean) {
             c->aud32.need(n * AUD_STRIDE * 4); c->audit_cnt.need(n * AUDIT_COLS * 4); c->audit_len.need(n * AUDIT_COLS * 4);
@@ -574,7 +582,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         c->out_audit.need(std::max<uint64_t>(st.audit_total, 16), true, s);
         AuditArgs aa{};
         aa.file0 = f0; aa.n_items = n; aa.item_list = nullptr; aa.slot_of = slot_of; aa.fpw = fpw_used;
-        aa.fin32 = audit_lean ? c->w->fin32.as<uint32_t>() : nullptr; aa.aud32 = audit_lean ? c->aud32.as<uint32_t>() : nullptr;
+        aa.fin32 = audit_lean || audit_scored ? c->w->fin32.as<uint32_t>() : nullptr; aa.aud32 = audit_lean || audit_scored ? c->aud32.as<uint32_t>() : nullptr;
         aa.wave_T = c->w->wave_T.as<uint32_t>(); aa.wave_LB = c->w->wave_LB.as<uint32_t>(); aa.wave_off = c->w->wave_off.as<uint64_t>(); aa.workspace = c->w->workspace.as<uint8_t>();
         aa.audit_cnt = c->audit_cnt.as<uint32_t>(); aa.offsets = io.audit_offsets; aa.text = c->out_audit.as<uint8_t>();
         HIP_OK(launch_audit(c->dt, aa, s));

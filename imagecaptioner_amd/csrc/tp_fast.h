@@ -1128,7 +1128,6 @@ struct LineFront { static constexpr bool scored = false; };
 template <int NT, int NF, class W, class Front = LineFront, bool AUD = false>
 TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, const uint8_t* cls, const uint8_t* text, uint32_t len, FastOut& out, uint32_t* fin32,
                      uint32_t* fired, uint16_t* facet_choice, bool triage = false, Front* front = nullptr, const LeanAudit aud = LeanAudit{nullptr, nullptr, nullptr, nullptr}) {
-    static_assert(!(AUD && Front::scored), "the audit lists are kept for tag lines only");
     static_assert((NT == 1 || NT == 2) && (NF == 1 || NF == 2), "one or two elements per lane");
     const uint32_t lane = w.lane();
     int nblk = 1;
@@ -1141,6 +1140,8 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
     if constexpr (Front::scored) {
         r1[0] = r1[1] = Rec{FL_BLANK, EMPTY_ID, NO_ID, 0, 0, 0, NO_ID, NO_ID};
         if (!front->run(w, t, L, nblk, n, act, h1, r1, seed_in, strong_in)) return false;
+        ci[0] = lane; ci[1] = 64 + lane;                           // the candidates sit on the lanes in their order
+        if (AUD && front->audit_unfit) return false;              // lists this stage cannot write as interned ids in the reference's order
     } else {
     Scan sc;
     if (!scan_line<NT == 2>(w, L, cls, text, len, sc)) return false;
@@ -1260,7 +1261,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
                 aud.row[AUD_DROPPED + pos] = t2[blk] | ((r2[blk].flags & FL_VALID) ? 0x80000000u : 0u);
                 dbytes += r2[blk].len + AUDIT_REASON_LEN;
             }
-            if (act[blk] && ci[blk] < (uint32_t)TOP_TAGS) { aud.row[AUD_TOP + ci[blk]] = h1[blk]; tbytes += r1[blk].len; }
+            if (!Front::scored && act[blk] && ci[blk] < (uint32_t)TOP_TAGS) { aud.row[AUD_TOP + ci[blk]] = h1[blk]; tbytes += r1[blk].len; }   // (the scored front lists its own)
             if (nonblank2[blk]) { rb |= (r2[blk].flags & (FL_SUBJ_MALE | FL_SUBJ_GIRL | FL_SUBJ_MULTI)) >> 10; banned = banned || (r2[blk].flags & FL_BANNED) != 0; }
         }
         uint32_t rbits = w.or_all(rb);
@@ -1271,7 +1272,7 @@ TP_HD bool fast_file(W& w, const DevTables& t, FastLds& L, const uint32_t* rc, c
         const uint32_t ntop = n < (uint32_t)TOP_TAGS ? n : (uint32_t)TOP_TAGS;
         if (lane == 0) {
             aud.cnt[AUDIT_DROPPED] = n_dropped; aud.len[AUDIT_DROPPED] = dbytes + (n_dropped ? n_dropped - 1 : 0u);
-            aud.cnt[AUDIT_TOP] = ntop; aud.len[AUDIT_TOP] = tbytes + (ntop ? ntop - 1 : 0u);
+            if (!Front::scored) { aud.cnt[AUDIT_TOP] = ntop; aud.len[AUDIT_TOP] = tbytes + (ntop ? ntop - 1 : 0u); }
             *aud.rbits = rbits;
         }
     }
@@ -1588,6 +1589,43 @@ struct ScoredFront {
     // Candidates in no table (strict vocabulary drops them in SelectTags, Program.cs:631-634, but they count): distinct strings
     // among the candidates, those of them with !(score < 0.28) (evidence, Program.cs:724), those in the style bucket with score >= 0.60
     uint32_t extra_dropped = 0, extra_evidence = 0, extra_style = 0;
+    // Audit mode (aud.row set) lists the candidates by name.  The first 20 by (score, order) - TopJoyTags, Program.cs:860: every
+    // entry of a single reply on its own, the merged candidates of two - are written here, where the entries' own scores and
+    // orders still are (the lanes end up in SelectTags' order, which looks at the source rank before the order and joins the
+    // entries of one string).  audit_unfit: a candidate in no table, which has no id to be listed by, or a single reply whose
+    // strings do not stand in the lanes' order (the dropped tags are listed in the order of ParseJoyTags' list, Program.cs:487, 627-631).
+    LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
+    bool audit_unfit = false;
+    // entry e's place among the live entries by (score descending, order, source rank), when below TOP_TAGS: its id into the row
+    TP_HD void top_tags(W& w, const DevTables& t, FastLds& L, uint32_t M, const bool (&live)[2], const uint32_t (&id)[2], const uint64_t (&K)[2],
+                        const uint32_t (&order)[2], const uint32_t (&src)[2]) {
+        uint64_t* Kq = (uint64_t*)L.line;                          // the text is not read any more
+        uint32_t* oq = (uint32_t*)(L.line + 1024);
+        const uint32_t lane = w.lane();
+        uint32_t key2[2];
+        w.sync();
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
+            key2[blk] = live[blk] ? (order[blk] << 8 | (uint32_t)source_rank(src[blk])) : 0xFFFFFFFFu;
+            const uint32_t e = (uint32_t)blk * 64 + lane;
+            if (e < M) { Kq[e] = K[blk]; oq[e] = key2[blk]; }
+        }
+        w.sync();
+        uint32_t before[2] = {0, 0};
+        for (uint32_t f = 0; f < M; ++f) {
+            const uint32_t of = oq[f];
+            if (of == 0xFFFFFFFFu) continue;
+            const uint64_t kf = Kq[f];
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) before[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && of < key2[blk]));
+        }
+        uint32_t tbytes = 0;
+        TP_UNROLL for (int blk = 0; blk < 2; ++blk)
+            if (live[blk] && before[blk] < (uint32_t)TOP_TAGS) { aud.row[AUD_TOP + before[blk]] = id[blk]; tbytes += t.attr2[2 * (size_t)id[blk] + 1]; }
+        tbytes = w.sum(tbytes);
+        const uint32_t n_live = popc64(w.ballot(live[0])) + popc64(w.ballot(live[1]));
+        const uint32_t ntop = n_live < (uint32_t)TOP_TAGS ? n_live : (uint32_t)TOP_TAGS;
+        if (lane == 0) { aud.cnt[AUDIT_TOP] = ntop; aud.len[AUDIT_TOP] = tbytes + (ntop ? ntop - 1 : 0u); }
+        w.sync();
+    }
     uint32_t n_candidates = 0;     // finalCandidates.Count (Program.cs:223): one reply keeps entries with one string apart, the merge of two joins them
 
     // double -> key that sorts ascending where the score sorts descending (finite scores; -0.0 counts as 0.0)
@@ -1612,7 +1650,10 @@ struct ScoredFront {
         if (M64 > 128) return false;
         const uint32_t M = (uint32_t)M64, P = in.merged ? (uint32_t)(in.mid - in.lo) : M;
         nblk = 1; n = 0;
-        if (M == 0) return true;
+        if (M == 0) {
+            if (aud.row && lane == 0) { aud.cnt[AUDIT_TOP] = 0; aud.len[AUDIT_TOP] = 0; }
+            return true;
+        }
         const uint64_t base = in.tag_offsets[in.lo];
         const uint64_t bytes64 = in.tag_offsets[in.hi] - base;
         if (bytes64 > FAST_LINE_MAX) return false;
@@ -1687,6 +1728,8 @@ struct ScoredFront {
         }
         const bool isP[2] = {lane < P, lane + 64 < P};
         bool accept[2] = {valid[0], valid[1]};
+        // TopJoyTags of one reply: its entries as they are, before entries of one string are joined
+        if (aud.row && !in.merged && !w.ballot((valid[0] && unk[0]) || (valid[1] && unk[1]))) top_tags(w, t, L, M, valid, id, K, order, src);
         if (in.merged) {
             // LimitSecondaryTags (Program.cs:801-815), entry by entry: what the primary reply holds passes; of the other entries
             // the `cap` best by (score, order) pass
@@ -1720,7 +1763,7 @@ struct ScoredFront {
         // Entries with one normalised string become one candidate with the best score and the earliest order (ParseJoyTags keeps
         // them apart, MergeCandidateTags and SelectTags join them: Program.cs:444-458, 636-649); its source is the one of lower
         // rank wherever PreferSource is asked with the scores it gets there, which between the two replies is the primary one.
-        bool alive[2] = {false, false};
+        bool alive[2] = {false, false}, joined = false;            // joined: a single reply held two entries of one string
         {
             uint64_t* gK = (uint64_t*)L.line;                      // per set slot: the best key of the entries with that string
             static_assert(FAST_SET_SLOTS * 8 <= FAST_LINE_MAX && FAST_SET_SLOTS / 32 <= FAST_FRULES_MAX / 32, "per-slot columns fit the line buffer and the facet-hit words");
@@ -1742,6 +1785,7 @@ struct ScoredFront {
             w.sync();
             if (w.ballot(full)) return false;
             if (!in.merged && w.ballot((accept[0] && !rep[0]) || (accept[1] && !rep[1]))) {
+                joined = true;
                 // one reply with sources of its own per tag: joined entries of different sources would need PreferSource followed
                 const uint64_t m0 = w.ballot(accept[0]);
                 const uint32_t ref = m0 ? w.bcast(src[0], ctz64(m0)) : w.bcast(src[1], ctz64(w.ballot(accept[1])));
@@ -1769,6 +1813,11 @@ struct ScoredFront {
             extra_dropped = popc64(w.ballot(alive[0] && unk[0])) + (mblk > 1 ? popc64(w.ballot(alive[1] && unk[1])) : 0);
             extra_evidence = popc64(w.ballot(useed[0])) + (mblk > 1 ? popc64(w.ballot(useed[1])) : 0);
             extra_style = popc64(w.ballot(ustrong[0])) + (mblk > 1 ? popc64(w.ballot(ustrong[1])) : 0);
+            if (aud.row) {
+                if (w.ballot((valid[0] && unk[0]) || (valid[1] && unk[1]))) audit_unfit = true;
+                // TopJoyTags of two replies: the merged candidates by their merged scores and orders (one reply's entries were listed above)
+                else if (in.merged) top_tags(w, t, L, M, alive, id, K, order, src);
+            }
             TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (unk[blk]) alive[blk] = false;
         }
         uint32_t k2[2];
@@ -1788,6 +1837,24 @@ struct ScoredFront {
                 before[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && kf2 < k2[blk]));
                 tie = tie || (alive[blk] && kf == K[blk] && kf2 == k2[blk] && f != (uint32_t)blk * 64 + lane);
             }
+        }
+        if (aud.row && !in.merged) {
+            // A single reply is walked in ParseJoyTags' order, (score descending, order) over its entries (Program.cs:487, 627), each
+            // string counting where its first - best - entry stands; the lanes are in (score, source rank, order) of the joined
+            // entries.  The two agree unless scores tie: between strings of different ranks, or where a joined string's earliest
+            // order is not its best entry's.
+            uint32_t earlier[2] = {0, 0};
+            bool ktie = false;
+            for (uint32_t f = 0; f < M; ++f) {
+                const uint32_t kf2 = k2q[f];
+                if (kf2 == 0xFFFFFFFFu) continue;
+                const uint64_t kf = Kq[f];
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
+                    earlier[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && (kf2 & 0xFFFFu) < (k2[blk] & 0xFFFFu)));
+                    ktie = ktie || (alive[blk] && kf == K[blk] && f != (uint32_t)blk * 64 + lane);
+                }
+            }
+            if (w.ballot((alive[0] && earlier[0] != before[0]) || (alive[1] && earlier[1] != before[1])) || (joined && w.ballot(ktie))) audit_unfit = true;
         }
         if (w.ballot(tie)) return false;                           // the insertion order of the merge decides between them: general kernel
         n = popc64(w.ballot(alive[0])) + (mblk > 1 ? popc64(w.ballot(alive[1])) : 0);

@@ -381,7 +381,9 @@ __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_wa
 __global__ __launch_bounds__(64 * LEAN_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TP_LEAN_B_DETAIL_WAVES_PER_SIMD))) void k_lean_b_detail(FastArgs a) { lean_b_body<true>(a); }
 
 // Scored candidates (tagger replies as text and score per tag) through the wave kernel's scored front, two candidates per lane.
-__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables t, FastArgs a) {
+// AUD: audit mode - the file's other lists go to its row of a.aud32, as the line stages leave them.
+template <bool AUD>
+__device__ __forceinline__ void scored_body(const DevTables& t, const FastArgs& a) {
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
     __shared__ uint8_t cls[256];
     extern __shared__ uint32_t rc_lds[];
@@ -401,9 +403,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
         const uint64_t lo = a.tag_begin[f], hi = a.tag_begin[f + 1];
         front.in = ScoredIn{a.arena, a.offsets, lo, a.secondary_begin ? a.secondary_begin[f] : hi, hi, a.scores, a.sources, a.secondary_begin != nullptr, a.secondary_cap};
         FastOut out;
-        const bool done = fast_file<2, 2, DevWave, ScoredFront<DevWave>>(w, t, L, rc_lds, cls, nullptr, 0, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
-                                                                         a.fired ? a.fired + f * t.fired_words : nullptr,
-                                                                         a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, false, &front);
+        LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
+        if (AUD) { const uint64_t r = f - a.file0; aud.row = a.aud32 + r * AUD_STRIDE; aud.cnt = a.audit_cnt + r * AUDIT_COLS; aud.len = a.audit_len + r * AUDIT_COLS; aud.rbits = a.review_bits + r; }
+        front.aud = aud;
+        // a reply without scores keeps its order (Program.cs:487): its lists follow that order, which the lanes do not hold
+        const bool as_it_came = AUD && a.reply_flags && !(a.reply_flags[f] & 1u);
+        const bool done = !as_it_came && fast_file<2, 2, DevWave, ScoredFront<DevWave>, AUD>(w, t, L, rc_lds, cls, nullptr, 0, out, a.fin32 + (f - a.file0) * FAST_FIN_MAX,
+                                                                              a.fired ? a.fired + f * t.fired_words : nullptr,
+                                                                              a.facet_choice ? a.facet_choice + f * t.n_facets : nullptr, false, &front, aud);
         if (done) {
             if (w.lane() == 0) {
                 a.verdicts[f] = out.verdict;
@@ -418,6 +425,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables 
     }
     decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
 }
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored(DevTables t, FastArgs a) { scored_body<false>(t, a); }
+__global__ __launch_bounds__(64 * FAST_WAVES_PER_BLOCK) void k_scored_audit(DevTables t, FastArgs a) { scored_body<true>(t, a); }
 
 // Third stage: the files the second declined, up to LL::TOK_CAP tokens in LL::LINE_CAP bytes (three sizes, smallest first: what
 // one declines for its size the next takes); one wavefront per block.
@@ -1586,7 +1595,7 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
         const dim3 grid_b((unsigned)(want < lean_blocks_b ? want : lean_blocks_b));
         if (a.fired || a.facet_choice || a.aud32) hipLaunchKernelGGL(k_lean_b_detail, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
         else hipLaunchKernelGGL(k_lean_b, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);
-    } else if (a.stage == 4) hipLaunchKernelGGL(k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
+    } else if (a.stage == 4) hipLaunchKernelGGL(a.aud32 ? k_scored_audit : k_scored, dim3((unsigned)(want < 256u * 16u ? want : 256u * 16u)), dim3(64 * FAST_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, t, a);
     else if (a.stage == 3) {
         // as many one-wavefront blocks as the CUs hold at once for the size's LDS (the grid strides over the list)
         const unsigned per_cu = a.long_size == 0 ? 9u : a.long_size == 1 ? 5u : 3u;

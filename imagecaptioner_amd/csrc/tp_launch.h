@@ -32,6 +32,7 @@ struct FastArgs {
     const uint8_t* sources;
     const uint64_t* secondary_begin;   // two replies per file to merge: first tag of the secondary reply (else null)
     int secondary_cap;
+    const uint8_t* reply_flags;   // stage 4 in audit mode: per file, bit 0 = ParseJoyTags sorted the (primary) reply; a reply that kept its order is declined (null: every reply was sorted)
     int triage;                   // 1: existing-caption triage: stop after the candidates, verdict flags carry TP_F_TRIAGE_BAD
     int front_only;               // stage 0: launch the front half alone
     int stage;                    // 0: the lean stage (tp_lean.h); 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)

@@ -434,9 +434,11 @@ int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t
  *   TP_AUDIT_TOP       TopJoyTags: the tags of the 20 best raw candidates by score, then order (Program.cs:860)
  *   TP_AUDIT_UNKNOWN   the caption's tags outside the vocabulary, in caption order (GetUnknownTags before its sort, Program.cs:817-821)
  * Column c of file i is text[offsets[TP_AUDIT_COLS * i + c] .. offsets[TP_AUDIT_COLS * i + c + 1]); tp_get_audit's pointers live
- * as long as the result.  In audit mode every wave-per-file stage keeps these lists for the files it takes (tag lines; tagger
- * replies take the thread-per-file kernel), which costs about half a run's speed.  n_selected in the verdicts is exact in every
- * mode; n_evidence is counted.
+ * as long as the result.  In audit mode every wave-per-file stage keeps these lists for the files it takes, tag lines and
+ * tagger replies alike, which costs about half a run's speed; of the replies the thread-per-file kernel is left with those
+ * that kept their own order (TP_REPLY_ORDER), those with a tag in no table, and a single reply in which scores tie between
+ * tags of different source ranks or around a tag it holds twice.  n_selected in the verdicts is exact in every mode;
+ * n_evidence is counted.
  */
 #define TP_AUDIT_KEPT     0
 #define TP_AUDIT_EVIDENCE 1

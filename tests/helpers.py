@@ -308,6 +308,35 @@ class HostSim:
         raw = text.tobytes()
         return [tuple(raw[int(offs5[5 * i + c]):int(offs5[5 * i + c + 1])] for c in range(5)) for i in range(n)], ver, stage_of
 
+    def run_audit_scored_wave(self, arena, tag_offsets, tag_begin, scores, sources=None, secondary_begin=None, secondary_cap=0):
+        """Tagger replies in audit mode as the wave kernel leaves them: (lists, verdicts, stage_of), as run_audit_wave gives them."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)
+        tag_begin = np.ascontiguousarray(tag_begin, dtype=np.uint64)
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        sources = np.ascontiguousarray(sources if sources is not None else np.zeros(len(scores), np.uint8), dtype=np.uint8)
+        sb = np.ascontiguousarray(secondary_begin, dtype=np.uint64) if secondary_begin is not None else None
+        n = len(tag_begin) - 1
+        offs5 = np.zeros(5 * n + 1, dtype=np.uint64)
+        ver = np.zeros(n, dtype=VERDICT_DTYPE)
+        self.review_bits = np.zeros(n, dtype=np.uint32)
+        stage_of = np.zeros(n, dtype=np.uint8)
+        cap = 1 << 20
+        fn = self._L.sim_run_audit_scored_wave
+        fn.restype = C.c_longlong
+        fn.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        while True:
+            text = np.zeros(cap, dtype=np.uint8)
+            rc = fn(self._h, arena.ctypes.data, tag_offsets.ctypes.data, tag_begin.ctypes.data, sb.ctypes.data if sb is not None else None, scores.ctypes.data,
+                    sources.ctypes.data, int(secondary_cap), n, text.ctypes.data, cap, offs5.ctypes.data, ver.ctypes.data, self.review_bits.ctypes.data, stage_of.ctypes.data)
+            if rc == -1:
+                cap *= 4
+                continue
+            assert rc >= 0, "audit list sizes reported by the scored wave kernel differ from the text of its ids: " + self._L.sim_last_error().decode()
+            break
+        raw = text.tobytes()
+        return [tuple(raw[int(offs5[5 * i + c]):int(offs5[5 * i + c + 1])] for c in range(5)) for i in range(n)], ver, stage_of
+
     def run_scored(self, arena, tag_offsets, tag_begin, scores, sources):
         arena = np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(16, np.uint8)])
         tag_offsets = np.ascontiguousarray(tag_offsets, dtype=np.uint64)

@@ -355,3 +355,50 @@ def test_audit_lists_of_the_wave_stages(name, n):
     class Sub:                                                       # the oracle's records of the files a stage took
         review_jsonl = sub(want.review_jsonl)
     check_review_facts(sub(lists), sim.review_bits[taken], ver[taken], Sub)
+
+
+def sorted_replies(begin, scores, arena, toffs):
+    """Each file's entries in ParseJoyTags' order for a reply with scores (score descending, then as they came: Program.cs:487)."""
+    tags = [arena[int(toffs[i]):int(toffs[i + 1])].tobytes() for i in range(len(toffs) - 1)]
+    perm = []
+    for f in range(len(begin) - 1):
+        lo, hi = int(begin[f]), int(begin[f + 1])
+        perm += sorted(range(lo, hi), key=lambda e: (-scores[e], e))
+    enc = [tags[e] for e in perm]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs[1:] = np.cumsum([len(b) for b in enc])
+    return np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8)[:-1].copy(), offs, scores[perm]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(strict_known=True, strict_known_explicit=True), dict(denylist=b"smile\nlong_hair\n")])
+def test_audit_lists_of_the_scored_wave_kernel(kw):
+    """Tagger replies in audit mode in the wave kernel (its code on an emulated wavefront): final tags, evidence, dropped tags with
+    reason, the top tagger tags (entries of one string apart in a single reply, ties between the two replies' ranks) and the review
+    bits equal the oracle's for every file the kernel takes, whether a single reply comes in score order or not (ParseJoyTags sorts
+    it, Program.cs:487)."""
+    from helpers import check_review_facts
+    from test_merged_cpu import merged_inputs
+    cfg = shipped_config(**kw)
+    sim, orc = HostSim(cfg), Oracle(cfg)
+    arena, toffs, begin, mid, scores = merged_inputs(29, 160)
+    m = len(begin) - 1
+    sarena, stoffs, sscores = sorted_replies(begin, scores, arena, toffs)
+    src = np.zeros(len(scores), np.uint8)
+    cases = [("merged15", orc.run_merged(arena, toffs, begin, mid, scores, 15, detail=True, audit=review_args(m)), dict(secondary_begin=mid, secondary_cap=15), (arena, toffs, scores)),
+             ("merged2", orc.run_merged(arena, toffs, begin, mid, scores, 2, detail=True, audit=review_args(m)), dict(secondary_begin=mid, secondary_cap=2), (arena, toffs, scores)),
+             ("as they come", orc.run_scored(arena, toffs, begin, scores, src, detail=True, audit=review_args(m)), dict(sources=src), (arena, toffs, scores)),
+             ("sorted", orc.run_scored(sarena, stoffs, begin, sscores, src, detail=True, audit=review_args(m)), dict(sources=src), (sarena, stoffs, sscores))]
+    for what, want, extra, (a, o, s) in cases:
+        lists, ver, stage = sim.run_audit_scored_wave(a, o, begin, s, **extra)
+        exp = oracle_audit_lists(want)
+        taken = [i for i in range(m) if stage[i]]
+        # (these replies are full of equal scores and of entries with one string: a single reply with both is the general kernel's)
+        assert len(taken) >= (m * 6 // 10 if what.startswith("merged") else m * 3 // 10), (what, len(taken), m)
+        for i in taken:
+            assert lists[i][:3] == exp[i], (what, i, lists[i][:3], exp[i])
+            assert ver[i].tobytes() == want.verdicts[i].tobytes(), (what, i)
+        sub = lambda seq: [seq[i] for i in taken]
+        class Sub:
+            review_jsonl = sub(want.review_jsonl)
+        check_review_facts(sub(lists), sim.review_bits[taken], ver[taken], Sub)

@@ -326,6 +326,54 @@ def test_audit_mode_stays_in_the_wave_stages(name, n):
         assert deep > n // 4          # evidence lists longer than the final lists: closures of several rounds were listed
 
 
+def test_audit_mode_of_tagger_replies_stays_in_the_wave_kernel():
+    """Tagger replies in audit mode (the reference appends an audit row per image whatever the options, Program.cs:334): the wave
+    kernel lists the dropped tags, the evidence and the top tagger tags itself - one reply per file as it came (ParseJoyTags sorts
+    it) and two replies to merge - so hardly any file needs the thread-per-file kernel; rows and review records equal the oracle's."""
+    from imagecaptioner_amd.corpus import make_corpus
+    n = 3000
+    c = make_corpus("c2", n, seed=808)
+    cfg = Config(**c.config_kwargs)
+    p, o = pipe_for(cfg), Oracle(cfg)
+    raw = bytes(c.arena)
+    rng = np.random.default_rng(4)
+    tags, begin, mid = [], [0], []
+    for i in range(n):
+        toks = raw[int(c.offsets[i]):int(c.offsets[i + 1])].rstrip(b"\n").split(b", ")
+        tags += toks[:max(1, 2 * len(toks) // 3)]
+        mid.append(len(tags))
+        tags += toks
+        begin.append(len(tags))
+    toffs = np.zeros(len(tags) + 1, dtype=np.uint64)
+    toffs[1:] = np.cumsum([len(t) for t in tags])
+    arena = np.frombuffer(b"".join(tags), dtype=np.uint8).copy()
+    scores = rng.random(len(tags)) * 0.8 + 0.2
+    scores[rng.random(len(tags)) < 0.05] = 0.5                       # some equal scores, within a reply and between the two
+    begin, mid = np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64)
+    audit = _review_args(n)
+    idx = np.concatenate([np.arange(int(mid[i]), int(begin[i + 1])) for i in range(n)])       # the second replies alone: every tag once
+    offs1 = np.zeros(len(idx) + 1, dtype=np.uint64)
+    offs1[1:] = np.cumsum([len(tags[k]) for k in idx])
+    arena1 = np.frombuffer(b"".join(tags[k] for k in idx), dtype=np.uint8).copy()
+    begin1 = np.zeros(n + 1, dtype=np.uint64)
+    begin1[1:] = np.cumsum(begin[1:] - mid)
+    for what in ("one reply", "one reply that holds most tags twice", "two replies"):
+        if what != "two replies":
+            a1, o1, b1, s1 = (arena1, offs1, begin1, scores[idx]) if what == "one reply" else (arena, toffs, begin, scores)
+            src = np.zeros(len(s1), np.uint8)
+            got = p.run_scored(a1, o1, b1, s1, src, audit=audit)
+            want = o.run_scored(a1, o1, b1, s1, src, threads=16, detail=True, audit=audit)
+        else:
+            got = p.run_merged(arena, toffs, begin, mid, scores, 15, audit=audit)
+            want = o.run_merged(arena, toffs, begin, mid, scores, 15, threads=16, detail=True, audit=audit)
+        general = p.last_timing()["general_files"]
+        print("c2 tagger replies in audit mode, %s: %d of %d files in the general kernel" % (what, general, n))
+        assert general <= (n // 10 if "twice" not in what else n * 7 // 10), what   # (joined entries and equal scores in one reply: the general kernel's)
+        _check_audit(got, want)
+        _check_review(got, want)
+        assert_same_results(got, want, p.histogram_dict(got.histogram), "c2 replies audit, " + what)
+
+
 @pytest.mark.parametrize("name", ["shipped", "novocab_w07_crlf", "c3", "c5"])
 def test_audit_rows_lines(name):
     if name in ("c3", "c5"):

@@ -26,8 +26,11 @@ arena = np.frombuffer(b"".join(tags), dtype=np.uint8).copy()
 scores = np.round(rng.random(len(tags)) * 0.65 + 0.35, 3)
 begin, mid = np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64)
 p = TagPipe(Config(**c.config_kwargs))
-# one reply per file: the secondary replies alone (every tag once)
+# one reply per file: the secondary replies alone (every tag once), each in the order ParseJoyTags hands a reply with scores on
+# (score descending, then as the tags came: Program.cs:487)
 sec_idx = np.concatenate([np.arange(int(mid[i]), int(begin[i + 1])) for i in range(n)])
+file_of = np.repeat(np.arange(n), (begin[1:] - mid).astype(np.int64))
+sec_idx = sec_idx[np.lexsort((sec_idx, -scores[sec_idx], file_of))]
 one_tags = [tags[k] for k in sec_idx]
 one_offs = np.zeros(len(one_tags) + 1, dtype=np.uint64)
 one_offs[1:] = np.cumsum([len(t) for t in one_tags])
@@ -46,3 +49,12 @@ for _ in range(2):
 print("%s merged: %d files, %.1f tags/file in: device %.2f ms (wave kernel %.2f ms, general kernel %.2f ms on %d files, emit %.2f ms) = %.2f M files/s; mean caption tags %.1f" % (
     name, n, len(tags) / n, tm["total_ms"], tm["select_ms"], tm["general_ms"], tm["general_files"], tm["emit_ms"], n / tm["total_ms"] / 1e3,
     float(r.verdicts["n_tags"].mean())))
+# the same two calls in audit mode (the reference appends an audit row per image whatever the options: Program.cs:334)
+audit = {"names": ["%d.png" % i for i in range(n)], "vocab_file": "top_tags.txt", "used_profile": "none"}
+for what, call in (("scored", lambda: p.run_scored(one_arena, one_offs, one_begin, scores[sec_idx], np.zeros(len(one_tags), np.uint8), audit=audit)),
+                   ("merged", lambda: p.run_merged(arena, offs, begin, mid, scores, 15, audit=audit))):
+    for _ in range(2):
+        call()
+        tm = p.last_timing()
+    print("%s %s, audit mode: device %.2f ms (wave kernel %.2f ms, general kernel %.2f ms on %d files, emit %.2f ms) = %.2f M files/s" % (
+        name, what, tm["total_ms"], tm["select_ms"], tm["general_ms"], tm["general_files"], tm["emit_ms"], n / tm["total_ms"] / 1e3))
