@@ -140,9 +140,10 @@ struct HostResult {
 struct WorkBufs {
     DevBuf wave_T, wave_LB, wave_bytes, wave_off, tile_sums, cap_len, n_final, slot_of, fin32, slow_list, slow_list0, slow_list1, slow_list2, slow_list_b, tile_state, scalars, workspace;
     DevBuf hist_parts;               // EmitArgs::hist_parts (grown buffers only: the fixed working memory has no room for it)
+    DevBuf side_list0, side_list1, side_list2;   // the side chain's lists (grown buffers only)
     void release() {
         for (DevBuf* b : {&wave_T, &wave_LB, &wave_bytes, &wave_off, &tile_sums, &cap_len, &n_final, &slot_of, &fin32, &slow_list, &slow_list0, &slow_list1, &slow_list2, &slow_list_b,
-                          &tile_state, &scalars, &workspace, &hist_parts})
+                          &tile_state, &scalars, &workspace, &hist_parts, &side_list0, &side_list1, &side_list2})
             b->release();
     }
 };
@@ -181,6 +182,22 @@ struct tp_ctx {
     // wave stages directly, then one range tries it again.  Results do not depend on it (TAGPIPE_LEAN_ADAPT=0: always try).
     bool lean_adapt = true;
     int lean_rest = 0;
+    // The stages behind the lean stage's front half run on a stream of their own, beside the back half, when the front half
+    // declined at most one file in 16 of the last range.  Measured: a dozen such files in 200k (c3, c4; 1M for c2) cost the main
+    // stream 0.04 ms as five nearly empty launches in a row, each waiting for its one file: 1 - 3 % of the step; c1 (6 % of
+    // the files) gains 2 %; c5, where a tenth of the files goes that way, loses 2 %: the chain then outlasts the back half.
+    // TAGPIPE_SIDE_CHAIN=0 / 1: never / always; results do not depend on it
+    bool side_chain = true, side_adapt = true;
+    hipStream_t side_q = nullptr;
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    hipStream_t side_stream() {
+        if (!side_q) HIP_OK(hipStreamCreateWithFlags(&side_q, hipStreamNonBlocking));
+        return side_q;
+    }
+    hipEvent_t side_event(int k) {
+        if (!side_ev[k]) HIP_OK(hipEventCreateWithFlags(&side_ev[k], hipEventDisableTiming));
+        return side_ev[k];
+    }
     bool stage1_idle = false;        // the first general wave stage took under a tenth of what the lean stage declined in the last range: a small grid for it
     bool no_fused = true;            // TAGPIPE_FUSED=1: the plain run's back half, caption offsets and caption bytes as ONE kernel (k_lean_bx).  Off by default:
                                      // measured on c2 (1M files) the fused kernel takes 2.86 ms where k_lean_b + scan + k_emit_runs take 2.2 ms
@@ -201,6 +218,8 @@ struct tp_ctx {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         for (hipEvent_t e : pipe_events) (void)hipEventDestroy(e);
         for (hipStream_t q : pipe_streams) if (q) (void)hipStreamDestroy(q);
+        for (hipEvent_t e : side_ev) if (e) (void)hipEventDestroy(e);
+        if (side_q) (void)hipStreamDestroy(side_q);
     }
     hipEvent_t event(size_t i) {
         while (events.size() <= i) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); events.push_back(e); }
@@ -273,7 +292,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
     const bool audit_lean = io.audit && c->use_lean && c->dt.fast_ok && !io.tag_begin && io.mode == 0 && !c->no_fast;
     bool lean_now = c->use_lean && io.mode == 0 && !io.tag_begin;
     if (lean_now && c->lean_adapt && !c->learning && c->lean_rest > 0 && n >= 4096) { --c->lean_rest; lean_now = false; }
-    bool lean_ran = false;
+    bool lean_ran = false, side_ran = false;
     const bool use_fast = use_scored || audit_lean || (c->dt.fast_ok && !io.tag_begin && (io.mode == 0 || io.mode == 2) && !c->no_fast && !io.audit);
     // The plain run over tag lines (no detail arrays, no audit lists): the lean stage's back half, the caption offsets and the
     // caption bytes are one kernel (k_lean_bx); the stages behind the front half run before it, so that every file's caption
@@ -355,45 +374,81 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         // first stage: one token per lane; what it declines goes through the second stage (two per lane), what that declines
         // through the long-file stage, and what is left to the general kernel.  Later stages learn their item counts on the device.
         fa.item_list = nullptr; fa.item_count = nullptr;
+        uint32_t* const d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
+        uint32_t* const d_count_b = (uint32_t*)(sc_bytes + 192);    // the lean stage's back half lists its files from the end of slow_list0
+        uint32_t* const d_side_count = d_count_b + 1;               // [0 .. 2]: the side chain's lists; [3]: the main chain's fourth list while the side chain runs
+        // The files the front half declines (too many tokens for it, as a rule: the expensive ones for the stages below) can go through
+        // those stages on a stream of their own while the back half runs; the files the back half declines follow on this stream.
+        const bool side = lean_now && !fused && c->side_chain && c->w == &c->own && n >= 4096;   // (its stream and events are made on first use: not for the run that must not allocate)
         if (lean_now) {
             lean_ran = true;
             // stage 0: the lean stage takes the common shape of a file; the stages below see what it declines
             c->w->slow_list0.need(n * 4);
-            uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);   // behind the audit totals
             HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
+            HIP_OK(hipMemsetAsync(d_count_b, 0, 20, s));
             fa.stage = 0; fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0; fa.tables = c->dt_dev.as<DevTables>();
             fa.front_only = fused ? 1 : 0;
+            if (!fused) { fa.slow_count_b = d_count_b; fa.item_cap = (uint32_t)n; }
             hipEvent_t pm = next_event(), pe = next_event();
-            HIP_OK(launch_fast(c->dt, fa, s, pm));
+            HIP_OK(launch_fast(c->dt, fa, s, pm, side ? c->side_event(0) : nullptr));
             record(pe);
             if (st.timed) st.lean_ev.push_back({p0, pm, pe});
-            HIP_OK(hipMemcpyAsync(&c->host_scalars[3], d_slow_count0, 4, hipMemcpyDeviceToHost, s));   // how many it declined (the counter is used again below)
+            HIP_OK(hipMemcpyAsync(&c->host_scalars[3], d_slow_count0, 4, hipMemcpyDeviceToHost, s));   // how many each half declined (the counters are used again below)
+            if (!fused) HIP_OK(hipMemcpyAsync(&c->host_scalars[6], d_count_b, 4, hipMemcpyDeviceToHost, s));
+            else c->host_scalars[6] = 0;
             bxa = fa;
-            fa.front_only = 0;
+            fa.front_only = 0; fa.slow_count_b = nullptr;
             fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+            if (!fused) fa.item_count_b = d_count_b;
+        }
+        side_ran = side;
+        if (side) {
+            // the front half's files: every stage below on the side stream, lists of its own, the general kernel's list shared
+            hipStream_t q = c->side_stream();
+            c->w->side_list0.need(n * 4); c->w->side_list1.need(n * 4); c->w->side_list2.need(n * 4); c->w->slow_list_b.need(n * 4);
+            uint32_t* const l0 = c->w->side_list0.as<uint32_t>(); uint32_t* const l1 = c->w->side_list1.as<uint32_t>(); uint32_t* const l2 = c->w->side_list2.as<uint32_t>();
+            HIP_OK(hipStreamWaitEvent(q, c->side_event(0), 0));
+            FastArgs sa = fa;
+            sa.item_count_b = nullptr;
+            sa.stage = 1; sa.slow_list = l0; sa.slow_count = d_side_count;
+            HIP_OK(launch_fast(c->dt, sa, q));
+            sa.stage = 2; sa.item_list = l0; sa.item_count = d_side_count; sa.slow_list = l1; sa.slow_count = d_side_count + 1;
+            HIP_OK(launch_fast(c->dt, sa, q));
+            sa.stage = 3; sa.long_size = 0; sa.item_list = l1; sa.item_count = d_side_count + 1; sa.slow_list = l2; sa.slow_count = d_side_count + 2;
+            HIP_OK(launch_fast(c->dt, sa, q));
+            HIP_OK(hipMemsetAsync(d_side_count, 0, 4, q));        // (the second stage has read it)
+            sa.long_size = 1; sa.item_list = l2; sa.item_count = d_side_count + 2; sa.slow_list = l0; sa.slow_count = d_side_count;
+            HIP_OK(launch_fast(c->dt, sa, q));
+            sa.long_size = 2; sa.item_list = l0; sa.item_count = d_side_count; sa.slow_list = c->w->slow_list.as<uint32_t>(); sa.slow_count = d_slow_count;
+            HIP_OK(launch_fast(c->dt, sa, q));
+            HIP_OK(hipEventRecord(c->side_event(1), q));
+            fa.item_count = nullptr;                               // this stream's stages: the back half's files only
         }
         fa.stage = 1; fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
         fa.grid_cap = lean_ran && c->stage1_idle ? 512u : 0u;     // (a stage that took next to nothing of its list last time: blocks cost their set-up)
         HIP_OK(launch_fast(c->dt, fa, s));
         fa.grid_cap = 0;
+        fa.item_count_b = nullptr;
         if (lean_ran) HIP_OK(hipMemcpyAsync(&c->host_scalars[4], d_slow_count1, 4, hipMemcpyDeviceToHost, s));   // how many of them it handed on
         fa.stage = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
         fa.slow_list = c->w->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
         HIP_OK(launch_fast(c->dt, fa, s));
         // third stage, three sizes of per-file state (smallest first: more files at once); the first two stages' lists and
-        // counters have been read by now and take what the sizes hand on
-        uint32_t* d_slow_count0 = (uint32_t*)(d_total + 6);
-        HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
+        // counters have been read by now and take what the sizes hand on (while the side chain reads the lean stage's list, another)
+        uint32_t* const list3 = side ? c->w->slow_list_b.as<uint32_t>() : c->w->slow_list0.as<uint32_t>();
+        uint32_t* const count3 = side ? d_side_count + 3 : d_slow_count0;
+        if (!side) HIP_OK(hipMemsetAsync(d_slow_count0, 0, 4, s));
         HIP_OK(hipMemsetAsync(d_slow_count1, 0, 4, s));
         fa.stage = 3; fa.long_size = 0; fa.item_list = c->w->slow_list2.as<uint32_t>(); fa.item_count = d_slow_count2;
-        fa.slow_list = c->w->slow_list0.as<uint32_t>(); fa.slow_count = d_slow_count0;
+        fa.slow_list = list3; fa.slow_count = count3;
         HIP_OK(launch_fast(c->dt, fa, s));
-        fa.long_size = 1; fa.item_list = c->w->slow_list0.as<uint32_t>(); fa.item_count = d_slow_count0;
+        fa.long_size = 1; fa.item_list = list3; fa.item_count = count3;
         fa.slow_list = c->w->slow_list1.as<uint32_t>(); fa.slow_count = d_slow_count1;
         HIP_OK(launch_fast(c->dt, fa, s));
         fa.long_size = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
         fa.slow_list = c->w->slow_list.as<uint32_t>(); fa.slow_count = d_slow_count;
         HIP_OK(launch_fast(c->dt, fa, s));
+        if (side) HIP_OK(hipStreamWaitEvent(s, c->side_event(1), 0));
         }
         record(p1);
         if (st.timed) st.fast_ev.emplace_back(p0, p1);
@@ -401,9 +456,12 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         HIP_OK(hipStreamSynchronize(s));
         n_slow = (uint32_t)c->host_scalars[0];
         if (lean_ran && n >= 4096) {
-            const uint64_t declined = (uint32_t)c->host_scalars[3];
+            const uint64_t declined_front = (uint32_t)c->host_scalars[3];
+            const uint64_t declined = declined_front + (audit_lean ? 0u : (uint32_t)c->host_scalars[6]);
+            if (!audit_lean && c->side_adapt) c->side_chain = declined_front * 16 <= n;   // no more of them than the back half's run hides
             c->lean_rest = declined * 4 > n * 3 ? 15 : 0;          // it took less than a quarter: rest
-            if (!audit_lean) c->stage1_idle = declined >= 1024 && ((uint64_t)(uint32_t)c->host_scalars[4]) * 10 > declined * 9;   // the stage behind it handed on over nine in ten
+            const uint64_t stage1_saw = side_ran ? declined - declined_front : declined;
+            if (!audit_lean) c->stage1_idle = stage1_saw >= 1024 && ((uint64_t)(uint32_t)c->host_scalars[4]) * 10 > stage1_saw * 9;   // the stage behind it handed on over nine in ten
         }
         item_list = c->w->slow_list.as<uint32_t>();
     }
@@ -1020,6 +1078,7 @@ void load_tables(tp_ctx* c, const std::vector<std::string>* learned) {
     c->use_lean = lean_ok(c->dt);
     if (const char* b = std::getenv("TAGPIPE_NO_LEAN")) if (b[0] == '1') c->use_lean = false;
     if (const char* b = std::getenv("TAGPIPE_LEAN_ADAPT")) c->lean_adapt = b[0] != '0';
+    if (const char* b = std::getenv("TAGPIPE_SIDE_CHAIN")) { c->side_adapt = false; c->side_chain = b[0] == '1'; }
     if (const char* b = std::getenv("TAGPIPE_NO_OVERLAP")) c->no_overlap = b[0] == '1';
     c->dt_dev.need(sizeof(DevTables));
     HIP_OK(hipMemcpy(c->dt_dev.p, &c->dt, sizeof(DevTables), hipMemcpyHostToDevice));

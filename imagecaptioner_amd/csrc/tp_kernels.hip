@@ -135,22 +135,23 @@ constexpr int FAST_WAVES_PER_BLOCK = 4;
 // million files would spend milliseconds on).
 constexpr uint32_t DECLINE_BATCH = 32;
 struct DeclineBuf { uint32_t item[DECLINE_BATCH]; };
-__device__ inline void decline_flush(DeclineBuf& b, uint32_t& n, uint32_t* list, uint32_t* count) {   // wave-uniform n
+// from_end: the list is filled from entry from_end - 1 downwards (0: from entry 0 upwards)
+__device__ inline void decline_flush(DeclineBuf& b, uint32_t& n, uint32_t* list, uint32_t* count, uint32_t from_end = 0) {   // wave-uniform n
     if (n == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(count, n);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (lane < n) list[base + lane] = b.item[lane];
+    if (lane < n) list[from_end ? from_end - 1 - (base + lane) : base + lane] = b.item[lane];
     n = 0;
 }
-__device__ inline void decline_push(DeclineBuf& b, uint32_t& n, uint32_t item, uint32_t* list, uint32_t* count) {
+__device__ inline void decline_push(DeclineBuf& b, uint32_t& n, uint32_t item, uint32_t* list, uint32_t* count, uint32_t from_end = 0) {
     if ((threadIdx.x & 63u) == 0) b.item[n] = item;
     ++n;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (n == DECLINE_BATCH) decline_flush(b, n, list, count);
+    if (n == DECLINE_BATCH) decline_flush(b, n, list, count, from_end);
 }
 
 // The first stage serves files of at most 64 tokens (and 128 final tags) over the whole range [file0, file_end); the second
@@ -163,13 +164,16 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
     __shared__ FastLds lds[FAST_WAVES_PER_BLOCK];
     __shared__ uint8_t cls[256];                                // byte classes of the line scan
     extern __shared__ uint32_t rc_lds[];                        // the rule cache, t.rc_words words (dynamic LDS)
-    if (a.item_list && (uint64_t)blockIdx.x * FAST_WAVES_PER_BLOCK >= (uint64_t)*a.item_count) return;   // a later stage with nothing left for this block
+    // the list's entries from its front, then those from its end (the lean stage's two halves list their files at either end)
+    const uint32_t n_front = a.item_list && a.item_count ? *a.item_count : 0u, n_back = a.item_list && a.item_count_b ? *a.item_count_b : 0u;
+    const uint64_t n_items = a.item_list ? (uint64_t)n_front + n_back : a.file_end - a.file0;
+    if (a.item_list && (uint64_t)blockIdx.x * FAST_WAVES_PER_BLOCK >= n_items) return;   // a later stage with nothing left for this block
+    auto item = [&](uint64_t i) { return a.item_list[i < n_front ? i : a.item_cap - 1 - (i - n_front)]; };
     __shared__ DeclineBuf dbuf[FAST_WAVES_PER_BLOCK];
     uint32_t n_declined = 0;
     DevWave w;
     const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t n_items = a.item_list ? (uint64_t)*a.item_count : a.file_end - a.file0;
     // A stage that works through an earlier stage's list: most of what reaches it and is not its to take has too many tokens,
     // which a count of the commas shows for a fraction of the line scan.  A block none of whose files fits hands them on before
     // it has set anything up (the rule cache is 18 KB with a few hundred rules, and such blocks can be most of the grid).
@@ -179,9 +183,9 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
     };
     if (a.item_list) {
         bool any = false;
-        for (uint64_t i = wave_global; i < n_items && !any; i += n_waves) any = fits(a.file0 + a.item_list[i]);
+        for (uint64_t i = wave_global; i < n_items && !any; i += n_waves) any = fits(a.file0 + item(i));
         if (!__syncthreads_or(any ? 1 : 0)) {
-            for (uint64_t i = wave_global; i < n_items; i += n_waves) decline_push(dbuf[wave_in_block()], n_declined, a.item_list[i], a.slow_list, a.slow_count);
+            for (uint64_t i = wave_global; i < n_items; i += n_waves) decline_push(dbuf[wave_in_block()], n_declined, item(i), a.slow_list, a.slow_count);
             decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
             return;
         }
@@ -191,7 +195,7 @@ __device__ __forceinline__ void fast_body(const DevTables& t, const FastArgs& a)
     __syncthreads();
     FastLds& L = lds[wave_in_block()];
     for (uint64_t i = wave_global; i < n_items; i += n_waves) {
-        const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
+        const uint64_t f = a.file0 + (a.item_list ? item(i) : i);
         uint64_t o = a.offsets[f];
         uint64_t len64 = a.offsets[f + 1] - o;
         bool done = false;
@@ -334,6 +338,8 @@ __device__ __forceinline__ void lean_b_body(const FastArgs& a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4), (__attribute__((address_space(3))) void*)&L.cr[1][0], 16, 0, 0);
         }
     };
+    uint32_t* const back_count = a.slow_count_b ? a.slow_count_b : a.slow_count;   // its own end of the list, or the front half's
+    const uint32_t from_end = a.slow_count_b ? a.item_cap : 0u;
     uint32_t n0, id0, n1, id1, n2, id2;
     peek(wave_global, n0, id0);
     peek(wave_global + n_waves, n1, id1);
@@ -362,14 +368,14 @@ __device__ __forceinline__ void lean_b_body(const FastArgs& a) {
                     a.slot_of[f] = SLOT_FAST;
                 }
             } else {
-                decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)i, a.slow_list, a.slow_count);
+                decline_push(dbuf[wave_in_block()], n_declined, (uint32_t)i, a.slow_list, back_count, from_end);
             }
             w.sync();
         }
         if (!fetched) records_free();
         n0 = n1; id0 = id1; n1 = n2; id1 = id2;
     }
-    decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, a.slow_count);
+    decline_flush(dbuf[wave_in_block()], n_declined, a.slow_list, back_count, from_end);
 #ifdef TP_PROF
     w.flush();
 #endif
@@ -1566,7 +1572,7 @@ static unsigned env_blocks(const char* name, unsigned dflt) {
     return v >= 1 && v <= 0x7FFFFFFFl ? (unsigned)v : dflt;
 }
 
-hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between) {
+hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between, hipEvent_t after_front) {
     uint64_t n = a.file_end - a.file0;
     if (n == 0) return hipSuccess;
     uint64_t want = (n + FAST_WAVES_PER_BLOCK - 1) / FAST_WAVES_PER_BLOCK;
@@ -1591,6 +1597,7 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
         if (want < 256u * 5u) want = (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK < 256u * 5u ? (n + LEAN_WAVES_PER_BLOCK - 1) / LEAN_WAVES_PER_BLOCK : 256u * 5u;
         hipLaunchKernelGGL(k_lean_a, dim3((unsigned)(want < lean_blocks_a ? want : lean_blocks_a)), dim3(64 * LEAN_WAVES_PER_BLOCK), 0, s, a);
         if (between) { hipError_t e = hipEventRecord(between, s); if (e != hipSuccess) return e; }
+        if (after_front) { hipError_t e = hipEventRecord(after_front, s); if (e != hipSuccess) return e; }
         if (a.front_only) return hipGetLastError();               // the fused back half follows later (launch_lean_bx)
         const dim3 grid_b((unsigned)(want < lean_blocks_b ? want : lean_blocks_b));
         if (a.fired || a.facet_choice || a.aud32) hipLaunchKernelGGL(k_lean_b_detail, grid_b, dim3(64 * LEAN_WAVES_PER_BLOCK), t.rc_words * sizeof(uint32_t), s, a);

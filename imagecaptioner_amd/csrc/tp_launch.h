@@ -26,6 +26,11 @@ struct FastArgs {
     uint32_t* slow_count;
     const uint32_t* item_list;    // null: first stage over the whole range; else the files (relative to file0) the stage before declined:
     const uint32_t* item_count;   //   *item_count of them (read on the device)
+    // The lean stage's list has two ends: the front half's files from entry 0 upwards (slow_count), the back half's from entry
+    // item_cap - 1 downwards (slow_count_b), so that a stage can take either end or both (null: none from that end)
+    const uint32_t* item_count_b;
+    uint32_t item_cap;
+    uint32_t* slow_count_b;       // stage 0: the back half counts its declined files here and lists them from the end (null: with the front half's)
     // scored candidates (stage 4): offsets are tag offsets; the tags of file f are tag_begin[f] .. tag_begin[f + 1]
     const uint64_t* tag_begin;
     const double* scores;
@@ -141,7 +146,8 @@ constexpr int NOALLOC_MAX_DEVICES = 64;
 hipError_t noalloc_scratch(int device, void** ptr, size_t* bytes);
 
 // `between`: when not null and the stage launches two kernels (stage 0), recorded on the stream after the first of them.
-hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between = nullptr);
+// stage 0: `between` and `after_front` (either may be null) are recorded between the front half and the back half
+hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hipEvent_t between = nullptr, hipEvent_t after_front = nullptr);
 hipError_t launch_wave_sizes(const DevTables& t, const uint8_t* arena, const uint64_t* offsets, const uint64_t* tag_begin, const uint32_t* item_list,
                              uint64_t file0, uint64_t n_items, uint32_t fpw, uint32_t* wave_T, uint32_t* wave_LB, uint64_t* wave_bytes, uint32_t* status, hipStream_t s);
 hipError_t launch_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* tile_sums, const uint64_t* base_ptr, uint64_t* total_out, hipStream_t s);

@@ -561,6 +561,29 @@ def test_workspace_chunking_gives_identical_results(monkeypatch):
     assert np.array_equal(whole.histogram, chunked.histogram)
 
 
+@pytest.mark.parametrize("name", ["c5", "c1"])
+def test_side_chain_gives_identical_results(monkeypatch, name):
+    """The files the lean stage's front half declines go through the later stages on a stream of their own beside the back half,
+    the files the back half declines after it (the stage's list is filled from both ends): the same arrays as the stages in a
+    row on one stream, and the oracle's, on corpora where both halves decline files and every later stage has work."""
+    from imagecaptioner_amd.corpus import make_corpus
+    c = make_corpus(name, 30000, seed=99)
+    cfg = Config(**c.config_kwargs)
+    runs = {}
+    for v in ("1", "0"):
+        monkeypatch.setenv("TAGPIPE_SIDE_CHAIN", v)
+        p = pipe_for(cfg)
+        runs[v] = [p.run_lines(c.arena, c.offsets) for _ in range(2)][1]
+        if v == "1":
+            hist = p.histogram_dict(runs[v].histogram)
+    a, b = runs["1"], runs["0"]
+    assert np.array_equal(a.caption_offsets, b.caption_offsets) and np.array_equal(a.captions, b.captions)
+    assert a.verdicts.tobytes() == b.verdicts.tobytes() and a.counters == b.counters
+    assert np.array_equal(a.histogram, b.histogram) and np.array_equal(a.fired, b.fired) and np.array_equal(a.facet_choice, b.facet_choice)
+    want = Oracle(cfg).run_lines(c.arena, c.offsets, threads=16)
+    assert_same_results(a, want, hist, name + " with the side chain")
+
+
 def test_host_run_in_pieces_equals_the_run_in_turn(monkeypatch):
     """tp_run_lines over many files works in pieces (the next piece's lines going in and the last one's captions coming back while
     the kernels run): the same arrays as copying in, computing and copying out in turn, and the oracle's captions for a sample."""
