@@ -183,11 +183,14 @@ struct tp_ctx {
     bool lean_adapt = true;
     int lean_rest = 0;
     // The stages behind the lean stage's front half run on a stream of their own, beside the back half, when the front half
-    // declined at most one file in 16 of the last range.  Measured: a dozen such files in 200k (c3, c4; 1M for c2) cost the main
-    // stream 0.04 ms as five nearly empty launches in a row, each waiting for its one file: 1 - 3 % of the step; c1 (6 % of
-    // the files) gains 2 %; c5, where a tenth of the files goes that way, loses 2 %: the chain then outlasts the back half.
-    // TAGPIPE_SIDE_CHAIN=0 / 1: never / always; results do not depend on it
-    bool side_chain = true, side_adapt = true;
+    // declined between one file in 256 and one in 16 of the last range.  Measured: c1 (6 % of the files) gains 2 - 3 %; c5, where
+    // a tenth of the files goes that way, loses 2 %: the chain then outlasts the back half.  A dozen such files in a range (c2, c3,
+    // c4) cost the main stream 0.04 ms as five nearly empty launches in a row, each waiting for its one file, which the side
+    // chain would hide too (1 - 3 % of the step); it is left out there because kernels that overlap stretch one another's
+    // durations in a kernel trace (k_lean_b: 1.37 ms by events on its stream, 1.72 ms in the trace), so that per-kernel times
+    // no longer add up to the step.  TAGPIPE_SIDE_CHAIN=0 / 1: never / always; results do not depend on it
+    bool side_chain = false, side_adapt = true;
+    uint64_t last_front = 0;         // files the front half declined in the last range
     hipStream_t side_q = nullptr;
     hipEvent_t side_ev[2] = {nullptr, nullptr};
     hipStream_t side_stream() {
@@ -410,6 +413,9 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
             HIP_OK(hipStreamWaitEvent(q, c->side_event(0), 0));
             FastArgs sa = fa;
             sa.item_count_b = nullptr;
+            // grids for about as many files as the front half declined last time (a wavefront each, and as many again): the blocks of a
+            // full-size grid that find nothing to do would still pass through the CUs between the back half's
+            sa.grid_cap = (unsigned)std::min<uint64_t>(64 + c->last_front / 2, 4096);
             sa.stage = 1; sa.slow_list = l0; sa.slow_count = d_side_count;
             HIP_OK(launch_fast(c->dt, sa, q));
             sa.stage = 2; sa.item_list = l0; sa.item_count = d_side_count; sa.slow_list = l1; sa.slow_count = d_side_count + 1;
@@ -458,7 +464,8 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         if (lean_ran && n >= 4096) {
             const uint64_t declined_front = (uint32_t)c->host_scalars[3];
             const uint64_t declined = declined_front + (audit_lean ? 0u : (uint32_t)c->host_scalars[6]);
-            if (!audit_lean && c->side_adapt) c->side_chain = declined_front * 16 <= n;   // no more of them than the back half's run hides
+            c->last_front = declined_front;
+            if (!audit_lean && c->side_adapt) c->side_chain = declined_front * 256 >= n && declined_front * 16 <= n;   // enough of them to matter, no more than the back half's run hides
             c->lean_rest = declined * 4 > n * 3 ? 15 : 0;          // it took less than a quarter: rest
             const uint64_t stage1_saw = side_ran ? declined - declined_front : declined;
             if (!audit_lean) c->stage1_idle = stage1_saw >= 1024 && ((uint64_t)(uint32_t)c->host_scalars[4]) * 10 > stage1_saw * 9;   // the stage behind it handed on over nine in ten

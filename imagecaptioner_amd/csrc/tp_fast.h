@@ -1593,7 +1593,8 @@ struct ScoredFront {
     // entry of a single reply on its own, the merged candidates of two - are written here, where the entries' own scores and
     // orders still are (the lanes end up in SelectTags' order, which looks at the source rank before the order and joins the
     // entries of one string).  audit_unfit: a candidate in no table, which has no id to be listed by, or a single reply whose
-    // strings do not stand in the lanes' order (the dropped tags are listed in the order of ParseJoyTags' list, Program.cs:487, 627-631).
+    // strings do not stand in the lanes' order (the dropped tags are listed in the order of ParseJoyTags' list, Program.cs:487,
+    // 627-631: equal scores between strings of different source ranks, or a joined string whose best entry is not its earliest).
     LeanAudit aud{nullptr, nullptr, nullptr, nullptr};
     bool audit_unfit = false;
     // entry e's place among the live entries by (score descending, order, source rank), when below TOP_TAGS: its id into the row
@@ -1763,7 +1764,8 @@ struct ScoredFront {
         // Entries with one normalised string become one candidate with the best score and the earliest order (ParseJoyTags keeps
         // them apart, MergeCandidateTags and SelectTags join them: Program.cs:444-458, 636-649); its source is the one of lower
         // rank wherever PreferSource is asked with the scores it gets there, which between the two replies is the primary one.
-        bool alive[2] = {false, false}, joined = false;            // joined: a single reply held two entries of one string
+        bool alive[2] = {false, false}, joined = false;            // joined (audit mode): a single reply held two entries of one string,
+        uint32_t list_order[2] = {0, 0};                           //   which stands in the reply's list at the order of its best entry
         {
             uint64_t* gK = (uint64_t*)L.line;                      // per set slot: the best key of the entries with that string
             static_assert(FAST_SET_SLOTS * 8 <= FAST_LINE_MAX && FAST_SET_SLOTS / 32 <= FAST_FRULES_MAX / 32, "per-slot columns fit the line buffer and the facet-hit words");
@@ -1785,7 +1787,18 @@ struct ScoredFront {
             w.sync();
             if (w.ballot(full)) return false;
             if (!in.merged && w.ballot((accept[0] && !rep[0]) || (accept[1] && !rep[1]))) {
-                joined = true;
+                if (aud.row) {
+                    // where a joined string stands in ParseJoyTags' list: at its best entry, the earliest of them when scores tie
+                    auto best_order = [&](uint32_t k) -> uint32_t& { return k < FAST_FIN_MAX ? L.fin[k] : L.fattr[k - FAST_FIN_MAX]; };
+                    static_assert(FAST_SET_SLOTS <= 2 * FAST_FIN_MAX, "a word per set slot in the two arrays");
+                    for (uint32_t k = lane; k < FAST_SET_SLOTS; k += 64) best_order(k) = 0xFFFFFFFFu;
+                    w.sync();
+                    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk)
+                        if (accept[blk] && K[blk] == gK[slot[blk]]) w.lds_min(&best_order(slot[blk]), order[blk]);
+                    w.sync();
+                    TP_UNROLL for (int blk = 0; blk < 2; ++blk) if (blk < mblk) if (accept[blk] && rep[blk]) list_order[blk] = best_order(slot[blk]);
+                    joined = true;
+                }
                 // one reply with sources of its own per tag: joined entries of different sources would need PreferSource followed
                 const uint64_t m0 = w.ballot(accept[0]);
                 const uint32_t ref = m0 ? w.bcast(src[0], ctz64(m0)) : w.bcast(src[1], ctz64(w.ballot(accept[1])));
@@ -1843,18 +1856,21 @@ struct ScoredFront {
             // string counting where its first - best - entry stands; the lanes are in (score, source rank, order) of the joined
             // entries.  The two agree unless scores tie: between strings of different ranks, or where a joined string's earliest
             // order is not its best entry's.
-            uint32_t earlier[2] = {0, 0};
-            bool ktie = false;
-            for (uint32_t f = 0; f < M; ++f) {
-                const uint32_t kf2 = k2q[f];
-                if (kf2 == 0xFFFFFFFFu) continue;
-                const uint64_t kf = Kq[f];
-                TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
-                    earlier[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && (kf2 & 0xFFFFu) < (k2[blk] & 0xFFFFu)));
-                    ktie = ktie || (alive[blk] && kf == K[blk] && f != (uint32_t)blk * 64 + lane);
-                }
+            uint32_t* loq = idq;                                   // (written only after this)
+            TP_UNROLL for (int blk = 0; blk < 2; ++blk) {
+                if (!joined) list_order[blk] = order[blk];
+                const uint32_t e = (uint32_t)blk * 64 + lane;
+                if (blk < mblk && e < M) loq[e] = list_order[blk];
             }
-            if (w.ballot((alive[0] && earlier[0] != before[0]) || (alive[1] && earlier[1] != before[1])) || (joined && w.ballot(ktie))) audit_unfit = true;
+            w.sync();
+            uint32_t earlier[2] = {0, 0};
+            for (uint32_t f = 0; f < M; ++f) {
+                if (k2q[f] == 0xFFFFFFFFu) continue;
+                const uint64_t kf = Kq[f];
+                const uint32_t lf = loq[f];
+                TP_UNROLL for (int blk = 0; blk < 2; ++blk) earlier[blk] += (uint32_t)(kf < K[blk] || (kf == K[blk] && lf < list_order[blk]));
+            }
+            if (w.ballot((alive[0] && earlier[0] != before[0]) || (alive[1] && earlier[1] != before[1]))) audit_unfit = true;
         }
         if (w.ballot(tie)) return false;                           // the insertion order of the merge decides between them: general kernel
         n = popc64(w.ballot(alive[0])) + (mblk > 1 ? popc64(w.ballot(alive[1])) : 0);

@@ -1606,7 +1606,9 @@ hipError_t launch_fast(const DevTables& t, const FastArgs& a, hipStream_t s, hip
     else if (a.stage == 3) {
         // as many one-wavefront blocks as the CUs hold at once for the size's LDS (the grid strides over the list)
         const unsigned per_cu = a.long_size == 0 ? 9u : a.long_size == 1 ? 5u : 3u;
-        const dim3 grid((unsigned)(n < 256u * per_cu ? n : 256u * per_cu));
+        unsigned blocks3 = (unsigned)(n < 256u * per_cu ? n : 256u * per_cu);
+        if (a.grid_cap && a.grid_cap < blocks3) blocks3 = a.grid_cap;
+        const dim3 grid(blocks3);
         const size_t dyn = 0;
         if (a.long_size == 0) hipLaunchKernelGGL(a.aud32 ? k_long256_audit : tr ? k_long256_triage : k_long256, grid, dim3(64), dyn, s, t, a);
         else if (a.long_size == 1) hipLaunchKernelGGL(a.aud32 ? k_long512_audit : tr ? k_long512_triage : k_long512, grid, dim3(64), dyn, s, t, a);

@@ -41,7 +41,7 @@ struct FastArgs {
     int triage;                   // 1: existing-caption triage: stop after the candidates, verdict flags carry TP_F_TRIAGE_BAD
     int front_only;               // stage 0: launch the front half alone
     int stage;                    // 0: the lean stage (tp_lean.h); 1: up to 64 tokens per file; 2: up to 128; 3: long files (one wavefront per block, candidates in LDS)
-    unsigned grid_cap;            // stages 1 and 2: at most so many blocks (0: the launch's own choice)
+    unsigned grid_cap;            // stages 1 to 3: at most so many blocks (0: the launch's own choice)
     int long_size;                // stage 3: 0 = up to 256 tokens in 4 KB, 1 = up to 512 in 8 KB, 2 = up to 1024 in 8 KB
     uint32_t* fired;
     uint16_t* facet_choice;

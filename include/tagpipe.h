@@ -437,7 +437,7 @@ int tp_format_side_files(const tp_ctx* ctx, const tp_verdict* verdicts, uint64_t
  * as long as the result.  In audit mode every wave-per-file stage keeps these lists for the files it takes, tag lines and
  * tagger replies alike, which costs about half a run's speed; of the replies the thread-per-file kernel is left with those
  * that kept their own order (TP_REPLY_ORDER), those with a tag in no table, and a single reply in which scores tie between
- * tags of different source ranks or around a tag it holds twice.  n_selected in the verdicts is exact in every mode;
+ * tags of different source ranks or between a tag it holds twice and another.  n_selected in the verdicts is exact in every mode;
  * n_evidence is counted.
  */
 #define TP_AUDIT_KEPT     0

@@ -393,8 +393,7 @@ def test_audit_lists_of_the_scored_wave_kernel(kw):
         lists, ver, stage = sim.run_audit_scored_wave(a, o, begin, s, **extra)
         exp = oracle_audit_lists(want)
         taken = [i for i in range(m) if stage[i]]
-        # (these replies are full of equal scores and of entries with one string: a single reply with both is the general kernel's)
-        assert len(taken) >= (m * 6 // 10 if what.startswith("merged") else m * 3 // 10), (what, len(taken), m)
+        assert len(taken) >= m * 6 // 10, (what, len(taken), m)
         for i in taken:
             assert lists[i][:3] == exp[i], (what, i, lists[i][:3], exp[i])
             assert ver[i].tobytes() == want.verdicts[i].tobytes(), (what, i)

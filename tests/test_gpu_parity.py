@@ -368,7 +368,7 @@ def test_audit_mode_of_tagger_replies_stays_in_the_wave_kernel():
             want = o.run_merged(arena, toffs, begin, mid, scores, 15, threads=16, detail=True, audit=audit)
         general = p.last_timing()["general_files"]
         print("c2 tagger replies in audit mode, %s: %d of %d files in the general kernel" % (what, general, n))
-        assert general <= (n // 10 if "twice" not in what else n * 7 // 10), what   # (joined entries and equal scores in one reply: the general kernel's)
+        assert general <= n // 10, what
         _check_audit(got, want)
         _check_review(got, want)
         assert_same_results(got, want, p.histogram_dict(got.histogram), "c2 replies audit, " + what)
