@@ -191,6 +191,7 @@ struct tp_ctx {
     // no longer add up to the step.  TAGPIPE_SIDE_CHAIN=0 / 1: never / always; results do not depend on it
     bool side_chain = false, side_adapt = true;
     uint64_t last_front = 0;         // files the front half declined in the last range
+    uint64_t last_stage1_out = 0;    // files the first general wave stage handed on in the last range
     hipStream_t side_q = nullptr;
     hipEvent_t side_ev[2] = {nullptr, nullptr};
     hipStream_t side_stream() {
@@ -438,7 +439,11 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
         if (lean_ran) HIP_OK(hipMemcpyAsync(&c->host_scalars[4], d_slow_count1, 4, hipMemcpyDeviceToHost, s));   // how many of them it handed on
         fa.stage = 2; fa.item_list = c->w->slow_list1.as<uint32_t>(); fa.item_count = d_slow_count1;
         fa.slow_list = c->w->slow_list2.as<uint32_t>(); fa.slow_count = d_slow_count2;
+        // behind the lean stage the second stage's grid is small (few files reach it as a rule); a wavefront per eight files of
+        // what reached it last time when that asks for more (c5, 21,000 of 200,000 files: 0.26 -> 0.22 ms)
+        if (lean_ran) fa.grid_cap = (unsigned)std::min<uint64_t>(std::max<uint64_t>(512, c->last_stage1_out / 8), 4096);
         HIP_OK(launch_fast(c->dt, fa, s));
+        fa.grid_cap = 0;
         // third stage, three sizes of per-file state (smallest first: more files at once); the first two stages' lists and
         // counters have been read by now and take what the sizes hand on (while the side chain reads the lean stage's list, another)
         uint32_t* const list3 = side ? c->w->slow_list_b.as<uint32_t>() : c->w->slow_list0.as<uint32_t>();
@@ -465,6 +470,7 @@ int run_range(tp_ctx* c, RunIo& io, uint64_t f0, uint64_t f1, RunState& st, bool
             const uint64_t declined_front = (uint32_t)c->host_scalars[3];
             const uint64_t declined = declined_front + (audit_lean ? 0u : (uint32_t)c->host_scalars[6]);
             c->last_front = declined_front;
+            c->last_stage1_out = (uint32_t)c->host_scalars[4];
             if (!audit_lean && c->side_adapt) c->side_chain = declined_front * 256 >= n && declined_front * 16 <= n;   // enough of them to matter, no more than the back half's run hides
             c->lean_rest = declined * 4 > n * 3 ? 15 : 0;          // it took less than a quarter: rest
             const uint64_t stage1_saw = side_ran ? declined - declined_front : declined;
