@@ -75,7 +75,14 @@ class PinPool {
     std::mutex mu;
     std::vector<PinBuf> idle;
     size_t idle_bytes = 0;
-    static constexpr size_t MAX_IDLE = 32, MAX_IDLE_BYTES = (size_t)6 << 30;
+    static constexpr size_t MAX_IDLE = 32;
+    // what the pool keeps locked while nobody uses it: 16 GiB (the results of ten million files of the headline corpus are 11), or
+    // TAGPIPE_PIN_POOL_GB
+    const size_t MAX_IDLE_BYTES = [] {
+        size_t gb = 16;
+        if (const char* e = std::getenv("TAGPIPE_PIN_POOL_GB")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 4096) gb = (size_t)v; }
+        return gb << 30;
+    }();
     static void drop(PinBuf& b) { if (b.p) { if (b.pinned) (void)hipHostFree(b.p); else std::free(b.p); } b = PinBuf{}; }
 public:
     PinBuf take(size_t bytes) {
