@@ -41,3 +41,51 @@ for name in ("c1", "c2", "c2n", "c3", "c3c", "c4", "c5"):
         assert got.verdicts[lo:hi].tobytes() == want.verdicts.tobytes(), (name, lo)
     print("%s: %d files, %.1f tags/caption, general kernel %d files; equal to the oracle on files 0..%d and %d..%d (%.0f s)" % (
         name, n, float(got.verdicts["n_tags"].mean()), p.last_timing()["general_files"], prefix, (n - prefix) // 2, (n - prefix) // 2 + prefix, time.time() - t0), flush=True)
+
+# Audit mode (the audit row's lists and the review records, Program.cs:334-341) on `audit_files` files of three configurations,
+# and tagger replies made of the c2 files' tags with scores of their own (one reply per file, and two to merge)
+from test_gpu_parity import _check_audit, _check_review, _review_args  # noqa: E402
+
+audit_files = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000
+for name in ("c2", "c3c", "c5"):
+    t0 = time.time()
+    c = make_corpus(name, audit_files, seed=2027)
+    cfg = Config(**c.config_kwargs)
+    p, o = TagPipe(cfg), Oracle(cfg)
+    audit = _review_args(audit_files)
+    got, want = p.run_lines(c.arena, c.offsets, audit=audit), o.run_lines(c.arena, c.offsets, threads=16, detail=True, audit=audit)
+    _check_audit(got, want)
+    _check_review(got, want)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name + " audit")
+    print("%s in audit mode: %d files, general kernel %d files; audit rows and review records equal to the oracle's (%.0f s)" % (
+        name, audit_files, p.last_timing()["general_files"], time.time() - t0), flush=True)
+    if name != "c2":
+        continue
+    raw = bytes(c.arena)
+    rng = np.random.default_rng(5)
+    tags, begin, mid = [], [0], []
+    for i in range(audit_files):
+        toks = raw[int(c.offsets[i]):int(c.offsets[i + 1])].rstrip(b"\n").split(b", ")
+        tags += toks[:max(1, 2 * len(toks) // 3)]
+        mid.append(len(tags))
+        tags += toks
+        begin.append(len(tags))
+    toffs = np.zeros(len(tags) + 1, dtype=np.uint64)
+    toffs[1:] = np.cumsum([len(t) for t in tags])
+    arena = np.frombuffer(b"".join(tags), dtype=np.uint8).copy()
+    scores = np.round(rng.random(len(tags)) * 0.8 + 0.2, 3)              # three decimals: equal scores within and between the replies
+    begin, mid = np.array(begin, dtype=np.uint64), np.array(mid, dtype=np.uint64)
+    for what in ("one reply per file", "two replies per file"):
+        t0 = time.time()
+        if what.startswith("one"):
+            src = np.zeros(len(tags), np.uint8)
+            got = p.run_scored(arena, toffs, begin, scores, src, audit=audit)
+            want = o.run_scored(arena, toffs, begin, scores, src, threads=16, detail=True, audit=audit)
+        else:
+            got = p.run_merged(arena, toffs, begin, mid, scores, 15, audit=audit)
+            want = o.run_merged(arena, toffs, begin, mid, scores, 15, threads=16, detail=True, audit=audit)
+        _check_audit(got, want)
+        _check_review(got, want)
+        assert_same_results(got, want, p.histogram_dict(got.histogram), "c2 replies, " + what)
+        print("c2 tagger replies in audit mode, %s (%.1f tags a file, tags twice and equal scores among them): general kernel %d of %d files; rows, records and captions equal to the oracle's (%.0f s)" % (
+            what, len(tags) / audit_files, p.last_timing()["general_files"], audit_files, time.time() - t0), flush=True)
