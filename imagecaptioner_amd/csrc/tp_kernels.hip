@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void k_pipeline(DevTables t, PipelineArgs a) {
     }
 }
 
-constexpr uint32_t GEN_STAGE = 4096, AUDIT_STAGE = 4096;   // bytes of LDS staging per wavefront in the general emit kernels
+constexpr uint32_t GEN_STAGE = 4096, AUDIT_STAGE = 4096;   // bytes of LDS staging per wavefront in the general emit kernels (multiples of 16)
 __device__ inline void put_bytes(uint8_t* dst, const uint8_t* src, uint32_t len) {   // src is readable eight bytes past its end
     uint32_t b = 0;
     for (; b + 8 <= len; b += 8) { const uint64_t v = ld64u(src + b); __builtin_memcpy(dst + b, &v, 8); }
@@ -656,13 +656,30 @@ __device__ inline void put_bytes(uint8_t* dst, const uint8_t* src, uint32_t len)
 // record's lists are separated by "\n" (the host sorts and joins them); the unknown-tag column keeps only entries that qualify.
 __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][AUDIT_STAGE];
+    __shared__ uint32_t ids_all[4][AUD_STRIDE + FAST_FIN_MAX];   // a wave-stage file's lists: its audit row, then its caption's tag ids
     uint8_t* stage = stage_all[wave_in_block()];
+    uint32_t* ids = ids_all[wave_in_block()];
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave_global = wave_index();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t i = wave_global; i < a.n_items; i += n_waves) {
-        const uint64_t f = a.file0 + (a.item_list ? a.item_list[i] : i);
-        const uint32_t slot = a.slot_of[f];
+    // One file ahead the wave reads what it needs to know before it can ask for a file's lists: the file, its kind, the columns'
+    // entry counts and places in the text (lanes 0 .. 5), whether the kept tags differ from the caption's (lane 6).
+    struct Meta { uint64_t f; uint32_t slot, cnt; uint64_t off; };
+    auto load_meta = [&](uint64_t i, Meta& m) {
+        m.f = 0; m.slot = 0; m.cnt = 0; m.off = 0;
+        if (i >= a.n_items) return;
+        m.f = a.file0 + (a.item_list ? a.item_list[i] : i);
+        m.slot = a.slot_of[m.f];
+        if (lane < (uint32_t)AUDIT_COLS) m.cnt = a.audit_cnt[(m.f - a.file0) * AUDIT_COLS + lane];
+        if (lane == 6 && a.aud32 != nullptr && m.slot == SLOT_FAST) m.cnt = a.aud32[(m.f - a.file0) * AUD_STRIDE + AUD_FLAGS];
+        if (lane <= (uint32_t)AUDIT_COLS) m.off = a.offsets[m.f * AUDIT_COLS + lane];
+    };
+    Meta m0, m1;
+    load_meta(wave_global, m0);
+    for (uint64_t i = wave_global; i < a.n_items; i += n_waves, m0 = m1) {
+        load_meta(i + n_waves, m1);
+        const uint64_t f = m0.f;
+        const uint32_t slot = m0.slot;
         // a file of the lean stage: its lists are interned ids in its rows of fin32 and aud32; else they are in its workspace
         const bool lean_file = a.aud32 != nullptr && slot == SLOT_FAST;
         const uint32_t* fin_row = lean_file ? a.fin32 + (f - a.file0) * FAST_FIN_MAX : nullptr;
@@ -671,25 +688,114 @@ __global__ __launch_bounds__(256) void k_emit_audit(DevTables t, AuditArgs a) {
         WsLayout L{};
         FileWs ws{};
         if (!lean_file) { L = ws_layout(a.wave_T[w], a.wave_LB[w], t.final_cap, t.evidence_grow, t.lit_words); ws = ws_bind(a.workspace + a.wave_off[w], L, slot & 63, a.fpw); }
-        auto lean_elem = [&](int col, uint32_t k) {
-            const uint32_t v = col == AUDIT_UNKNOWN ? fin_row[k] : col == AUDIT_KEPT ? (aud_row[AUD_FLAGS] ? aud_row[AUD_KEPT + k] : fin_row[k]) : col == AUDIT_EVIDENCE ? aud_row[AUD_EVIDENCE + k] : col == AUDIT_DROPPED ? aud_row[AUD_DROPPED + k] : aud_row[AUD_TOP + k];
-            const uint32_t id = v & 0x7FFFFFFFu;
-            AuditElem e;
-            e.keep = col != AUDIT_UNKNOWN || (t.known_active && !(t.flags[id] & FL_KNOWN));
-            e.p = str_ptr(t, id); e.len = str_len(t, id);
-            e.reason = col != AUDIT_DROPPED ? nullptr : (v >> 31) ? ":policy_drop" : ":invalid_tag";
-            return e;
-        };
+        auto lane_of = [](uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); };
+        uint32_t cnt_[AUDIT_COLS];
+        uint64_t off_[AUDIT_COLS + 1];
+        for (int c = 0; c < AUDIT_COLS; ++c) cnt_[c] = lane_of(m0.cnt, c);
+        for (int c = 0; c <= AUDIT_COLS; ++c) off_[c] = lane_of((uint32_t)m0.off, c) | (uint64_t)lane_of((uint32_t)(m0.off >> 32), c) << 32;
+        if (lean_file) {
+            // every list of the file in one round trip: the entries the counts name, into LDS
+            const bool kept_in_row = lane_of(m0.cnt, 6) != 0;
+            const bool unknown_text = off_[AUDIT_UNKNOWN + 1] != off_[AUDIT_UNKNOWN];
+            const uint32_t fin_unknown = unknown_text ? cnt_[AUDIT_UNKNOWN] : 0u, fin_kept = kept_in_row ? 0u : cnt_[AUDIT_KEPT];   // the caption's ids are the unknown-tag column's, and the kept tags' when those are the caption's
+            const uint32_t n_fin = fin_unknown > fin_kept ? fin_unknown : fin_kept;
+            uint32_t ev[3], dr = 0, tp = 0, kp[2], fn[2];
+            for (uint32_t j = 0; j < 3; ++j) { const uint32_t k = lane + 64 * j; ev[j] = k < cnt_[AUDIT_EVIDENCE] && k < AUD_DROPPED - AUD_EVIDENCE ? aud_row[AUD_EVIDENCE + k] : 0u; }
+            if (lane < cnt_[AUDIT_DROPPED] && lane < AUD_TOP - AUD_DROPPED) dr = aud_row[AUD_DROPPED + lane];
+            if (lane < cnt_[AUDIT_TOP] && lane < AUD_FLAGS - AUD_TOP) tp = aud_row[AUD_TOP + lane];
+            for (uint32_t j = 0; j < 2; ++j) {
+                const uint32_t k = lane + 64 * j;
+                kp[j] = kept_in_row && k < cnt_[AUDIT_KEPT] && k < FAST_FIN_MAX ? aud_row[AUD_KEPT + k] : 0u;
+                fn[j] = k < n_fin && k < FAST_FIN_MAX ? fin_row[k] : 0u;
+            }
+            __builtin_amdgcn_wave_barrier();                        // the last file's entries have been read
+            for (uint32_t j = 0; j < 3; ++j) ids[AUD_EVIDENCE + lane + 64 * j] = ev[j];
+            ids[AUD_DROPPED + lane] = dr;
+            if (lane < AUD_FLAGS - AUD_TOP) ids[AUD_TOP + lane] = tp;
+            for (uint32_t j = 0; j < 2; ++j) { ids[AUD_KEPT + lane + 64 * j] = kept_in_row ? kp[j] : fn[j]; ids[AUD_STRIDE + lane + 64 * j] = fn[j]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         for (int c = 0; c < AUDIT_COLS; ++c) {
-            const uint32_t cnt = a.audit_cnt[(f - a.file0) * AUDIT_COLS + c];
-            if (a.offsets[f * AUDIT_COLS + c + 1] == a.offsets[f * AUDIT_COLS + c]) continue;   // no text: none of the entries qualifies (the usual unknown-tag column)
-            uint8_t* out = a.text + a.offsets[f * AUDIT_COLS + c];
+            const uint32_t cnt = cnt_[c];
+            if (off_[c + 1] == off_[c]) continue;                    // no text: none of the entries qualifies (the usual unknown-tag column)
+            uint8_t* out = a.text + off_[c];
             const uint8_t sep = c >= AUDIT_TOP ? (uint8_t)'\n' : (uint8_t)';';
             uint32_t running = 0, kept_before = 0;
+            if (lean_file) {
+                // Interned ids: an entry's text comes with its 32-byte caption record (strings up to 31 bytes inline) in one round trip, the
+                // group is put together in LDS at the output's 16-byte phase and stored 16 bytes a lane, as the caption writer does.
+                for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    uint32_t v = 0;
+                    if (k < cnt) v = ids[(c == AUDIT_UNKNOWN ? AUD_STRIDE : c == AUDIT_KEPT ? AUD_KEPT : c == AUDIT_EVIDENCE ? AUD_EVIDENCE : c == AUDIT_DROPPED ? AUD_DROPPED : AUD_TOP) + k];
+                    const uint32_t id = v & 0x7FFFFFFFu;
+                    const bool live = k < cnt && (c != AUDIT_UNKNOWN || (t.known_active && !(t.flags[id] & FL_KNOWN)));
+                    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+                    if (live) { const uint4* rp = (const uint4*)(t.emit_rec32 + 8 * (size_t)id); r0 = rp[0]; r1 = rp[1]; }
+                    const uint32_t lenb = r1.w >> 24;
+                    const bool in_rec = lenb != 0xFFu;
+                    const uint32_t n = live ? (in_rec ? lenb : r0.y) : 0u;
+                    const bool reason = c == AUDIT_DROPPED;
+                    const uint64_t m = __ballot(live ? 1 : 0);
+                    const bool first = kept_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0;
+                    kept_before += (uint32_t)__popcll(m);
+                    const uint32_t seg = live ? n + (reason ? AUDIT_REASON_LEN : 0u) + (first ? 0u : 1u) : 0u;
+                    const uint32_t incl = wave_scan_incl(seg);
+                    const uint32_t group = __shfl(incl, 63);
+                    const uint32_t head = (uint32_t)((uintptr_t)(out + running) & 15);
+                    const bool staged = head + group <= AUDIT_STAGE;
+                    if (live) {
+                        uint8_t* dst = (staged ? stage + head : out + running) + (incl - seg);
+                        if (!first) *dst++ = sep;
+                        const uint8_t* sp = t.str_bytes + (in_rec ? 0u : r0.x);
+                        if (staged) {
+                            uint64_t w8[4];
+                            w8[0] = r0.x | (uint64_t)r0.y << 32; w8[1] = r0.z | (uint64_t)r0.w << 32;
+                            w8[2] = r1.x | (uint64_t)r1.y << 32; w8[3] = r1.z | (uint64_t)(r1.w & 0xFFFFFFu) << 32;
+                            if (!in_rec && n) { __builtin_memcpy(&w8[0], sp, 16); __builtin_memcpy(&w8[2], sp + 16, 16); }   // (the string arena has slack behind its end)
+                            const uint32_t n32 = n < 32 ? n : 32, nfull = n32 >> 3;
+                            for (uint32_t q = 0; q < 4; ++q)
+                                if (q < nfull) __builtin_memcpy(dst + 8 * q, &w8[q], 8);
+                            if (n32 & 7) {                                   // the last, partial word in pieces of 4, 2 and 1 bytes
+                                uint64_t x = nfull == 0 ? w8[0] : (nfull == 1 ? w8[1] : (nfull == 2 ? w8[2] : w8[3]));
+                                uint32_t o = 8 * nfull;
+                                if (n32 & 4) { uint32_t y = (uint32_t)x; __builtin_memcpy(dst + o, &y, 4); x >>= 32; o += 4; }
+                                if (n32 & 2) { uint16_t y = (uint16_t)x; __builtin_memcpy(dst + o, &y, 2); x >>= 16; o += 2; }
+                                if (n32 & 1) dst[o] = (uint8_t)x;
+                            }
+                            for (uint32_t done = 32; done < n; ++done) dst[done] = sp[done];
+                        } else {
+                            if (in_rec) { uint8_t bytes[32]; __builtin_memcpy(bytes, &r0, 16); __builtin_memcpy(bytes + 16, &r1, 16); for (uint32_t q = 0; q < n; ++q) dst[q] = bytes[q]; }
+                            else for (uint32_t q = 0; q < n; ++q) dst[q] = sp[q];
+                        }
+                        if (reason) { const char* rs = (v >> 31) ? ":policy_drop" : ":invalid_tag"; for (uint32_t q = 0; q < AUDIT_REASON_LEN; ++q) dst[n + q] = (uint8_t)rs[q]; }
+                    }
+                    if (staged) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        uint8_t* gbase = out + running - head;             // 16-byte aligned
+                        const uint32_t end = head + group, nchunks = (end + 15) >> 4;
+                        for (uint32_t ch = lane; ch < nchunks; ch += 64)
+                            if (16 * ch >= head && 16 * ch + 16 <= end) *(uint4*)(gbase + 16 * ch) = *(const uint4*)(stage + 16 * ch);
+                        if (lane < 32 && nchunks) {                         // the partial first and last pieces, one byte per lane
+                            const uint32_t ch = lane < 16 ? 0u : nchunks - 1;
+                            const uint32_t off = 16 * ch + (lane & 15);
+                            const bool partial = !(16 * ch >= head && 16 * ch + 16 <= end) && (lane < 16 || nchunks > 1);
+                            if (partial && off >= head && off < end) gbase[off] = stage[off];
+                        }
+                        __builtin_amdgcn_wave_barrier();                // the area is read before the next group's bytes are written
+                    }
+                    running += group;
+                }
+                continue;
+            }
             for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 AuditElem e{nullptr, 0, nullptr, false};
-                if (k < cnt) e = lean_file ? lean_elem(c, k) : audit_elem(t, ws, c, k);
+                if (k < cnt) e = audit_elem(t, ws, c, k);
                 const bool live = e.keep;
                 const uint64_t m = __ballot(live ? 1 : 0);
                 const bool first = kept_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0;
@@ -1657,7 +1763,9 @@ hipError_t launch_pipeline(const DevTables& t, const PipelineArgs& a, hipStream_
 hipError_t launch_audit(const DevTables& t, const AuditArgs& a, hipStream_t s) {
     if (a.n_items == 0) return hipSuccess;
     uint64_t want = (a.n_items + 3) / 4;                    // four wavefronts per block
-    unsigned blocks = (unsigned)(want < 256 * 8 ? want : 256 * 8);
+    // many more blocks than fit at once (five or six a CU): a grid of one or two rounds of blocks ends with most CUs idle
+    static const unsigned cap = env_blocks("TAGPIPE_AUDIT_BLOCKS", 256u * 40u);
+    unsigned blocks = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(k_emit_audit, dim3(blocks), dim3(256), 0, s, t, a);
     return hipGetLastError();
 }
