@@ -1005,6 +1005,9 @@ static_assert(RUN_STAGE >= FAST_CAPTION_MAX && RUN_TAGS >= FAST_FIN_MAX, "a sing
 // off_[j] .. off_[j + 1] its place in `captions`.  stage: RUN_STAGE + 48 bytes of LDS of this wavefront's own.
 // HIST: every tag id of the group is also counted in `bins` (LDS, two 16-bit counters a word, ids below n_public) and the
 // learned strings among them in n_learned; STAGE_CAP is the staging area's size.
+#ifndef TP_EMIT_DIAG
+#define TP_EMIT_DIAG 0        // diagnostic builds of the caption writer: 1 = no caption stores, 3 = made-up records instead of the gather (wrong captions: timing only)
+#endif
 template <bool HIST = false, uint32_t STAGE_CAP = RUN_STAGE, class TT>
 __device__ __forceinline__ void emit_group(const TT& t, const uint32_t* rows, uint8_t* captions, uint8_t* stage, uint32_t lane, uint32_t nfile, uint32_t fastmask,
                                            const uint32_t (&n_)[RUN_FILES], const uint64_t (&off_)[RUN_FILES + 1], uint32_t* bins = nullptr, uint32_t* n_learned = nullptr) {
@@ -1051,7 +1054,12 @@ __device__ __forceinline__ void emit_group(const TT& t, const uint32_t* rows, ui
         uint4 r0[RUN_BLOCKS], r1[RUN_BLOCKS];
         TP_UNROLL for (int b = 0; b < RUN_BLOCKS; ++b) {
             r0[b] = make_uint4(0, 0, 0, 0); r1[b] = r0[b];
+#if TP_EMIT_DIAG == 3
+            r0[b] = make_uint4(id[b], 0x61616161u, 0x62626262u, 0x63636363u); r1[b] = make_uint4(0, 0, 0, (8u + (id[b] & 7u)) << 24);   // no record loads (diagnostic build)
+            if (false) {
+#else
             if (64u * b < T) {
+#endif
                 const uint4* rp = (const uint4*)(t.emit_rec32 + 8 * (size_t)(id[b] & 0x7FFFFFFFu));
                 r0[b] = rp[0]; r1[b] = rp[1];
             }
@@ -1097,6 +1105,9 @@ __device__ __forceinline__ void emit_group(const TT& t, const uint32_t* rows, ui
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint8_t* gbase = captions + out0 - head;                      // 16-byte aligned
         const uint32_t end = head + total, nchunks = (end + 15) >> 4;
+#if TP_EMIT_DIAG == 1
+        if (total == 0xFFFFFFFFu)                                      // no stores (diagnostic build)
+#endif
         for (uint32_t c = lane; c < nchunks; c += 64) {
             if (16 * c >= head && 16 * c + 16 <= end) *(uint4*)(gbase + 16 * c) = *(const uint4*)(stage + 16 * c);
         }
