@@ -561,6 +561,19 @@ def test_workspace_chunking_gives_identical_results(monkeypatch):
     assert np.array_equal(whole.histogram, chunked.histogram)
 
 
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict"])
+def test_marks_at_the_scan_step_boundaries(name):
+    """Long lines with a token the line scan has to mark, count or refuse over at every byte offset around its step boundaries
+    (16 bytes a lane, a kilobyte a step in the stages for long lines): equal to the oracle, most of them in the wave stages."""
+    from test_pipeline_logic_cpu import scan_boundary_lines
+    cfg = CONFIGS[name]()
+    lines = scan_boundary_lines()
+    p = pipe_for(cfg)
+    got, want = p.run_texts(lines), Oracle(cfg).run_texts(lines)
+    assert_same_results(got, want, p.histogram_dict(got.histogram), name + " scan boundaries")
+    assert p.last_timing()["general_files"] < len(lines) * 3 // 4
+
+
 @pytest.mark.parametrize("name", ["c5", "c1"])
 def test_side_chain_gives_identical_results(monkeypatch, name):
     """The files the lean stage's front half declines go through the later stages on a stream of their own beside the back half,

@@ -158,6 +158,33 @@ def long_lines(seed, count):
     return lines
 
 
+def scan_boundary_lines():
+    """Long lines (200 to 330 tokens) in which one token the line scan has to mark, count or refuse over - capitals, quotes, runs of
+    blanks or underscores, trailing punctuation, a refusal phrase, a keyword with its colon, a tab, a character outside ASCII, a
+    fence - begins at every byte offset around the scan's step boundaries (multiples of 16 bytes up to 1024 + 48 into the line)."""
+    marks = ["Smile", "'smile'", "long  hair", "long__hair", "smile.", "sorry", "i can't", "positive: smile", "long\thair", "caf\u00e9", "smi`le", "SMILE;", "smile ,dress"]
+    lines = []
+    for at in list(range(0, 36)) + list(range(1000, 1072)):
+        head = ""
+        while len(head) + 8 <= at:
+            head += "dress, "[: min(7, at - len(head))] if at - len(head) < 7 else "dress, "
+        head = head + "x" * (at - len(head)) if at > len(head) else head
+        mark = marks[at % len(marks)]
+        tail = ", ".join(["smile", "long_hair", "1girl", "dress", "blue_eyes", "standing", "hat", "solo"] * (25 + at % 17))
+        lines.append((head + ", " if head and not head.endswith(", ") else head) + mark + ", " + tail)
+    return lines
+
+
+@pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict"])
+def test_marks_at_the_scan_step_boundaries(name):
+    cfg = CONFIGS[name]()
+    o, s = Oracle(cfg), HostSim(cfg)
+    lines = scan_boundary_lines()
+    want, got = o.run_texts(lines), s.run_texts_fast(lines)
+    assert_same_results(got, want, s.histogram_dict(got.histogram), name + " scan boundaries")
+    assert got.n_general < len(lines) * 3 // 4          # (refusal phrases, keywords and fences are the general kernel's)
+
+
 @pytest.mark.parametrize("name", ["shipped", "shipped_nonstrict"])
 def test_long_files_take_the_long_wave_stage(name):
     cfg = CONFIGS[name]()
